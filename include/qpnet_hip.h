@@ -1,0 +1,113 @@
+/*
+ * qpnet_hip.h -- C ABI of libqpnet_hip.so: the MI355X (gfx950) QPNet hot path.
+ *
+ * The reference (bigpon/QPNet) has no native boundary: its hot path is the Python module
+ * src/nets/qpnet.py calling stock torch ops.  The boundary that module would bind if its
+ * hot path were native is defined here; each entry point cites the
+ * reference interface it replaces.  The host-side mirror of the reference's Python surface
+ * (class QPNet etc.) lives in qpnet_amd/qpnet.py and calls ONLY these functions.
+ *
+ * Conventions
+ *   - plain C types; every `d_*` pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch tensors' data_ptr()); `h_*` pointers are host memory.
+ *   - return 0 on success, a negative QPN_E* code otherwise; nothing throws across the ABI.
+ *     qpn_last_error() returns a static, human-readable description of the last failure.
+ *   - the library owns only its handle and the workspaces it allocates in it.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).
+ *   - a handle is bound to the device current at qpn_create(); not thread-safe per handle.
+ *   - there is NO CPU fallback: every compute entry point fails with QPN_ENODEV when no
+ *     HIP device is usable.
+ */
+#ifndef QPNET_HIP_H
+#define QPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QPN_OK 0
+#define QPN_EINVAL (-1)      /* bad argument / unsupported geometry            */
+#define QPN_ENODEV (-2)      /* no usable HIP device / HIP runtime error       */
+#define QPN_ENOMEM (-3)      /* workspace allocation failed                    */
+#define QPN_ERANGE (-4)      /* pitch-dependent gather left its ring (ref: assert qpnet.py:294,417) */
+#define QPN_ESTATE (-5)      /* call order (e.g. decode before set_weights)    */
+
+/* Constructor kwargs of QPNet (reference src/nets/qpnet.py:174-178). */
+typedef struct {
+    int n_quantize, n_aux, n_resch, n_skipch;
+    int dilationF_depth, dilationF_repeat;
+    int dilationA_depth, dilationA_repeat;
+    int kernel_size, upsampling_factor;
+} qpn_config;
+
+typedef struct qpn_handle qpn_handle;
+
+/* library / ABI version (major*1000 + minor) */
+int qpn_version(void);
+
+/* Last error message of this thread's most recent failing call. */
+const char* qpn_last_error(void);
+
+/* Number of fp32 parameters of the geometry = length of the flat parameter vector, which is
+ * the concatenation of state_dict() tensors in registration order, each in its native
+ * PyTorch layout (reference QPNet.__init__, src/nets/qpnet.py:200-235). */
+int64_t qpn_param_count(const qpn_config* cfg);
+
+/* QPNet.__init__ (src/nets/qpnet.py:174-237): validate geometry, build the decode program. */
+int qpn_create(const qpn_config* cfg, qpn_handle** out);
+void qpn_destroy(qpn_handle* h);
+
+/* load_state_dict / .cuda() (reference bin/qpnet_decode.py:286-293): bind the flat fp32
+ * parameter vector (device memory, n == qpn_param_count) and (re)pack the decode tiles.
+ * The vector is read again by every later call; call again after the values change. */
+int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream);
+
+/* mode of qpn_decode */
+#define QPN_MODE_ARGMAX 0
+#define QPN_MODE_SAMPLING 1
+
+/*
+ * QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), all batch rows at once,
+ * one persistent workgroup per utterance, ONE kernel launch for the whole call.
+ *   B          batch rows                         n_x   seed samples per row (x is B x n_x)
+ *   F          frames of h (h is B x n_aux x F; if upsampling_factor==0, F = samples)
+ *   Td         columns of the dilated factors (B x Td), float64 or float32 (d_is_f32)
+ *   h_n_samples[B]  samples to generate per row (n_samples_list)
+ *   maxd       int(nanmax(ceil(dilated_factors))) over the batch (qpnet.py:347-350)
+ *   d_teacher  optional (B x max_n) int64: fed back instead of the pick (teacher forcing)
+ *   d_out      (B x max_n) int64 picks, row-major, max_n = max(h_n_samples)
+ *   d_logits   optional (B x max_n x n_quantize) fp32 per-step logits
+ * Rows are returned in INPUT order; completion-order / list-mutation semantics of the
+ * reference are applied by the Python mirror.  Blocks until the stream has finished.
+ */
+int qpn_decode(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+               const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+               const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+               const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream);
+
+/* Same, split for stream/graph use: enqueue returns after launching; finish synchronises
+ * the stream and returns the device-side status (QPN_ERANGE ...). */
+int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+                       const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+                       const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+                       const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream);
+int qpn_decode_finish(qpn_handle* h, void* stream);
+
+/* Device time (ms) of the persistent decode kernel of the last finished qpn_decode call,
+ * measured with HIP events on the launch stream (bench.py roofline). */
+float qpn_last_decode_kernel_ms(qpn_handle* h);
+
+/* _dilated_index (src/nets/qpnet.py:592-604, tensor path) and _generate_dilated_index
+ * (src/nets/qpnet.py:613-618): d (B x L) float32 -> int64 (B x L), NOT replicated over
+ * channels (the reference's .repeat over n_ch is redundant). */
+int qpn_dilated_index_train(const float* d_d, int B, int64_t L, int dilation, int64_t* d_out, void* stream);
+int qpn_dilated_index_gen_f32(const float* d_d, int64_t n, int dilation, int64_t* d_out, void* stream);
+int qpn_dilated_index_gen_f64(const double* d_d, int64_t n, int dilation, int32_t* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QPNET_HIP_H */

@@ -1,0 +1,66 @@
+"""ctypes binding of libqpnet_hip.so (include/qpnet_hip.h).  No torch types cross this boundary:
+only raw device pointers (tensor.data_ptr()), sizes and the HIP stream handle."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqpnet_hip.so")
+_lib = None
+
+
+class QpnConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "n_quantize", "n_aux", "n_resch", "n_skipch", "dilationF_depth", "dilationF_repeat",
+        "dilationA_depth", "dilationA_repeat", "kernel_size", "upsampling_factor")]
+
+
+class QpnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libqpnet_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+# every symbol include/qpnet_hip.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+_DECODE_ARGS = [_vp, _i, _i, _i64, _i64, _vp, _vp, _vp, _i, C.POINTER(C.c_int64), _i, _i, _u64, _vp, _vp, _vp, _vp]
+SYMBOLS = [
+    ("qpn_version", _i, []),
+    ("qpn_last_error", C.c_char_p, []),
+    ("qpn_param_count", _i64, [C.POINTER(QpnConfig)]),
+    ("qpn_create", _i, [C.POINTER(QpnConfig), C.POINTER(_vp)]),
+    ("qpn_destroy", None, [_vp]),
+    ("qpn_set_weights", _i, [_vp, _vp, C.c_size_t, _vp]),
+    ("qpn_decode", _i, _DECODE_ARGS),
+    ("qpn_decode_enqueue", _i, _DECODE_ARGS),
+    ("qpn_decode_finish", _i, [_vp, _vp]),
+    ("qpn_last_decode_kernel_ms", C.c_float, [_vp]),
+    ("qpn_dilated_index_train", _i, [_vp, _i, _i64, _i, _vp, _vp]),
+    ("qpn_dilated_index_gen_f32", _i, [_vp, _i64, _i, _vp, _vp]),
+    ("qpn_dilated_index_gen_f64", _i, [_vp, _i64, _i, _vp, _vp]),
+]
+
+
+def lib():
+    """Load the HIP library; fails loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). qpnet_amd has no CPU/PyTorch fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise QpnError(rc, lib().qpn_last_error().decode("utf-8", "replace"))
+
+
+def make_config(cfg):
+    return QpnConfig(*cfg.as_tuple())

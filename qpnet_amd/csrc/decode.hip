@@ -1,0 +1,758 @@
+// decode.hip -- persistent autoregressive decode of QPNet on gfx950 (MI355X).
+//
+// Replaces QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559) and the per-sample
+// helpers it calls (_generate_fixed_residual_forward :672-685, _generate_adaptive_residual_forward
+// :642-655, FDilatedConv1d :81-87, _generate_dilated_index :613-624, _preprocess :561-564,
+// _postprocess :566-571).  The reference dispatches ~160 tiny torch ops per generated sample;
+// here the whole utterance is ONE kernel launch: one 1024-thread workgroup per utterance walks a
+// host-built micro-program ("tasks") once per sample.  A task is a 64-lane x 16-deep weight tile
+// (4 KiB, streamed from L2 with coalesced 16-byte loads, prefetched one task ahead across the
+// workgroup barrier) plus an epilogue (gate / residual / skip accumulate / post-net / argmax).
+// All recurrent state of the current step lives in LDS; the per-layer input history ("ring
+// buffers", up to maxd*2^k samples deep) lives in a small L2-resident global block because
+// 15*maxd*C floats exceed one CU's LDS for low pitch (SURVEY.md §7 "Ring-buffer footprint").
+//
+// Arithmetic is the fixed-order fp32 "QPNet-f32" spec of DESIGN.md §3, so results are
+// bit-identical to the CPU oracle; compile with -ffp-contract=off.
+#include "qpn_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+
+// ================================================================== device helpers
+__device__ __forceinline__ float qexp(float x) {
+    x = fminf(fmaxf(x, -87.0f), 88.0f);
+    float n = rintf(x * 0x1.715476p+0f);
+    float r = __builtin_fmaf(n, -0x1.63p-1f, x);
+    r = __builtin_fmaf(n, 0x1.bd0106p-13f, r);
+    float p = 0x1.a01a02p-13f;
+    p = __builtin_fmaf(p, r, 0x1.6c16c2p-10f);
+    p = __builtin_fmaf(p, r, 0x1.111112p-7f);
+    p = __builtin_fmaf(p, r, 0x1.555556p-5f);
+    p = __builtin_fmaf(p, r, 0x1.555556p-3f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    return p * __int_as_float(((int)n + 127) << 23);
+}
+__device__ __forceinline__ float qgate(float zs, float zt) {
+    float ea = qexp(-zs);
+    float eb = qexp(-2.0f * fabsf(zt));
+    float num = 1.0f - eb;
+    float den = (1.0f + ea) * (1.0f + eb);
+    return copysignf(num / den, zt);
+}
+
+// 16-deep chunk of the spec dot product: p = w0*x0, then 15 fma in k order.
+__device__ __forceinline__ float chunk16(const float4 (&w)[4], const float4 (&x)[4]) {
+    float acc = w[0].x * x[0].x;
+    acc = __builtin_fmaf(w[0].y, x[0].y, acc);
+    acc = __builtin_fmaf(w[0].z, x[0].z, acc);
+    acc = __builtin_fmaf(w[0].w, x[0].w, acc);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        acc = __builtin_fmaf(w[j].x, x[j].x, acc);
+        acc = __builtin_fmaf(w[j].y, x[j].y, acc);
+        acc = __builtin_fmaf(w[j].z, x[j].z, acc);
+        acc = __builtin_fmaf(w[j].w, x[j].w, acc);
+    }
+    return acc;
+}
+// stride-halving tree over the R lanes of a row group (R = 1 << logR, lanes contiguous)
+__device__ __forceinline__ float tree_reduce(float acc, int logR) {
+    for (int s = (1 << logR) >> 1; s >= 1; s >>= 1) acc = acc + __shfl_xor(acc, s);
+    return acc;
+}
+__device__ __forceinline__ void load_tile(float4 (&w)[4], const float4* __restrict__ wpk, int woff4, int lane) {
+    const float4* p = wpk + (size_t)woff4 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = p[j * 64];
+}
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ================================================================== small setup kernels
+__global__ void k_pack_gather(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
+}
+
+struct BiasDesc { int64_t auxb[2], convb[2], convPb[2]; int adaptive; int pad; };
+
+// Qb[l][row] = ((b_up * dot(Va[row,:], 1) + ba) + b_conv) [+ b_convP]   
+// one workgroup of 64*k lanes per layer; aux tiles packed natural-row, R = Ap/16.
+__global__ void k_fold_bias(const float4* __restrict__ wpk, const float* __restrict__ flat, const BiasDesc* __restrict__ bd,
+                            int aux_woff4_layer0, int aux_tiles_per_layer, int logRa, int A, int Ap, int C,
+                            float up_b, float* __restrict__ qb) {
+    extern __shared__ float4 smem4[];
+    float* sm = (float*)smem4;
+    const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < Ap; i += blockDim.x) sm[i] = i < A ? 1.0f : 0.0f;
+    __syncthreads();
+    const int R = 1 << logRa, rpt = 64 / R, q = lane & (R - 1);
+    const BiasDesc b = bd[l];
+    for (int t = wave; t < aux_tiles_per_layer; t += nw) {
+        float4 w[4], x[4];
+        load_tile(w, wpk, aux_woff4_layer0 + (l * aux_tiles_per_layer + t) * 256, lane);
+        const float4* xv = (const float4*)(sm + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = xv[j];
+        float rs = tree_reduce(chunk16(w, x), logRa);
+        int row = t * rpt + (lane >> logRa);
+        if (q == 0) {
+            int half = row / C, r = row - half * C;
+            float v = up_b * rs;
+            v = v + flat[b.auxb[half] + r];
+            v = v + flat[b.convb[half] + r];
+            if (b.adaptive) v = v + flat[b.convPb[half] + r];
+            qb[(size_t)l * 2 * C + row] = v;
+        }
+    }
+}
+
+// P[b][f][l][row] = dot(Va_l[row,:], h[b,:,f])  -- aux 1x1 convs hoisted to FRAME rate.
+// grid (F, B); h is (B, A, F).
+__global__ void k_aux_project(const float4* __restrict__ wpk, const float* __restrict__ h, int64_t F,
+                              int aux_woff4_layer0, int aux_tiles_per_layer, int logRa, int A, int Ap, int C, int L,
+                              float* __restrict__ pproj) {
+    extern __shared__ float4 smem4[];
+    float* sm = (float*)smem4;
+    const int64_t f = blockIdx.x; const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < Ap; i += blockDim.x) sm[i] = i < A ? h[((size_t)b * A + i) * F + f] : 0.0f;
+    __syncthreads();
+    const int R = 1 << logRa, rpt = 64 / R, q = lane & (R - 1);
+    float4 x[4];
+    const float4* xv = (const float4*)(sm + 16 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = xv[j];
+    float* out = pproj + ((size_t)b * F + f) * L * 2 * C;
+    const int ntiles = L * aux_tiles_per_layer;
+    for (int t = wave; t < ntiles; t += nw) {
+        float4 w[4];
+        load_tile(w, wpk, aux_woff4_layer0 + t * 256, lane);
+        float v = tree_reduce(chunk16(w, x), logRa);
+        int l = t / aux_tiles_per_layer, tt = t - l * aux_tiles_per_layer;
+        int row = tt * rpt + (lane >> logRa);
+        if (q == 0) out[(size_t)l * 2 * C + row] = v;
+    }
+}
+
+// known[b][i]: n_pad copies of Q/2 (qpnet.py:358) then x % Q (OneHot, qpnet.py:76)
+__global__ void k_known(const int64_t* __restrict__ x, int n_x, int n_pad, int Q, int* __restrict__ known) {
+    const int b = blockIdx.y, n0 = n_pad + n_x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n0) {
+        int v;
+        if (i < n_pad) v = Q / 2;
+        else { int64_t s = x[(size_t)b * n_x + (i - n_pad)] % Q; v = (int)(s < 0 ? s + Q : s); }
+        known[(size_t)b * n0 + i] = v;
+    }
+}
+
+// ================================================================== the persistent decode kernel
+// pitch-dependent tap distance of ring `r` at (padded) time t  (qpnet.py:613-624)
+__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttDesc& u, int64_t ut) {
+    if (!r.adaptive) return r.mult;
+    if (ut < 0) return r.mult;                       // d := 1.0 in the left padding (qpnet.py:361-364)
+    if (u.d_is_f32) {
+        float d = ((const float*)u.dfac)[ut];
+        return -(int)rintf(-d * (float)r.mult);
+    }
+    double d = ((const double*)u.dfac)[ut];
+    return -(int)rint(-d * (double)r.mult);
+}
+
+// Stage everything step t1 needs that does not depend on the sample picked at step t1-1:
+// the gathered past rows of every layer (LDS xp) and the aux terms a[t1] (LDS auxv).
+__device__ __forceinline__ void stage_step(const DecodeParams& p, const UttDesc& u, float* sm, int64_t t1,
+                                           int tid, int nthreads, int* status) {
+    const int L = p.L, C = p.C, C2 = 2 * p.C;
+    const int64_t ut = t1 - u.n_pad;
+    int64_t f; int j;
+    if (ut < 0) { f = 0; j = 0; }                    // replicate pad of the upsampled h (qpnet.py:359)
+    else if (p.U > 0) { f = ut / p.U; j = (int)(ut - f * p.U); }
+    else { f = ut; j = 0; }
+    const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f;
+    const float* pf = u.pproj + (size_t)f * L * C2;
+    for (int i = tid; i < L * C2; i += nthreads) sm[p.o_auxv + i] = __builtin_fmaf(wj, pf[i], p.qb[i]);
+    for (int i = tid; i < L * C; i += nthreads) {
+        const int l = i / C, c = i - l * C;
+        const RingDesc r = p.rings[l];
+        int off = tap_offset(r, u, ut);
+        if (off < 1 || off >= r.len) { if (c == 0) atomicOr(status, 1); off = off < 1 ? 1 : r.len - 1; }
+        int64_t tp = t1 - off;                        // time of the past tap; < 0 -> zeros
+        int slot = (int)(((tp % r.len) + r.len) % r.len);
+        sm[p.o_xp + l * p.Cp + c] = ld_agent(u.ring + r.base + (size_t)slot * C + c);
+    }
+}
+
+__global__ __launch_bounds__(QPN_NT) void k_decode(DecodeParams p) {
+    extern __shared__ float4 smem4[];
+    float* sm = (float*)smem4;
+    int* smi = (int*)smem4;
+    const UttDesc u = p.utts[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = p.C, Q = p.Q;
+
+    for (int i = tid; i < p.lds_floats; i += QPN_NT) sm[i] = 0.0f;
+    __syncthreads();
+    if (tid == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.n0 > 1 ? u.known[1] : 0; }
+    const int64_t Ttot = (int64_t)u.n0 + u.n_samples;
+    if (Ttot < 3) { /* nothing to predict unless n_samples >= 1 and n0 >= 2 (n_pad >= 1 always) */ }
+    stage_step(p, u, sm, 1, tid, QPN_NT, p.status);
+    __syncthreads();
+
+    const Task* __restrict__ tasks = p.tasks + wave;
+    float4 w[4], wn[4];
+    {
+        const Task t0 = tasks[0];
+        if (t0.op & TF_HASW) load_tile(w, p.wpk, t0.woff4, lane);
+    }
+    for (int64_t t = 1; t + 1 < Ttot; ++t) {
+        for (int slot = 0; slot < p.n_slots; ++slot) {
+            const Task tk = tasks[slot * QPN_NW];
+            {   // prefetch the next task's weight tile (wraps into the next step)
+                int ns = slot + 1 == p.n_slots ? 0 : slot + 1;
+                const Task tn = tasks[ns * QPN_NW];
+                if (tn.op & TF_HASW) load_tile(wn, p.wpk, tn.woff4, lane);
+            }
+            if (tk.op & TF_BARRIER) {
+                if (tk.op & TF_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                wg_barrier();
+            }
+            const int op = tk.op & 0xff;
+            const int logR = (tk.op >> 16) & 0xf;
+            if (tk.op & TF_HASW) {
+                const int R = 1 << logR, q = lane & (R - 1);
+                float4 x[4];
+                const float4* xv = (const float4*)(sm + tk.xoff + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = xv[j];
+                float acc = tree_reduce(chunk16(w, x), logR);
+                const int row = tk.row0 + (lane >> logR);
+                const bool lead = q == 0;
+                switch (op) {
+                case OP_PAST:      // a = LDS offset of this layer's past-dot vector (natural rows)
+                    if (lead) sm[tk.a + row] = acc;
+                    break;
+                case OP_Z: {       // rows interleaved (sigmoid_c, tanh_c); a = pd, b = auxv, c = g
+                    const int ch = row >> 1, half = row & 1, nat = half * C + ch;
+                    float z = (acc + sm[tk.a + nat]) + sm[tk.b + nat];
+                    float zo = __shfl_xor(z, R);
+                    if (lead && !half) sm[tk.c + ch] = qgate(z, zo);
+                    break;
+                }
+                case OP_RES:       // a = x in (LDS), b = bias (flat), c = x out (LDS), d = ring index of the consumer or -1
+                    if (lead) {
+                        float v = (acc + p.flat[tk.b + row]) + sm[tk.a + row];
+                        sm[tk.c + row] = v;
+                        if (tk.d >= 0) {
+                            const RingDesc r = p.rings[tk.d];
+                            st_agent(u.ring + r.base + (size_t)(t % r.len) * C + row, v);
+                        }
+                    }
+                    break;
+                case OP_SKIP:      // a = accumulator (LDS), b = bias (flat), c = other accumulator, d = y1
+                    if (lead) {
+                        float v = sm[tk.a + row] + (acc + p.flat[tk.b + row]);
+                        sm[tk.a + row] = v;
+                        if (tk.op & TF_LAST) {
+                            // total = sumF + sumA (qpnet.py:505); a is the A accumulator unless the net has no A layers
+                            float tot = tk.c >= 0 ? sm[tk.c + row] + v : v;
+                            sm[tk.d + row] = tot > 0.0f ? tot : 0.0f;
+                        }
+                    }
+                    break;
+                case OP_POST1:     // b = bias, c = y2
+                    if (lead) { float v = acc + p.flat[tk.b + row]; sm[tk.c + row] = v > 0.0f ? v : 0.0f; }
+                    break;
+                case OP_POST2:     // b = bias, c = logits
+                    if (lead) sm[tk.c + row] = acc + p.flat[tk.b + row];
+                    break;
+                default: break;
+                }
+            } else if (op == OP_CAUSAL) {   // a = channel block; also clears the skip accumulators
+                const int ch = tk.a * 64 + lane;
+                if (ch < C) {
+                    const int a0 = smi[p.o_samp], a1 = smi[p.o_samp + 1];
+                    float v = p.flat[p.causal_w + ((size_t)ch * Q + a0) * 2] + p.flat[p.causal_w + ((size_t)ch * Q + a1) * 2 + 1];
+                    v = v + p.flat[p.causal_b + ch];
+                    sm[p.o_xbuf + ch] = v;
+                    const RingDesc r = p.rings[0];
+                    st_agent(u.ring + r.base + (size_t)(t % r.len) * C + ch, v);
+                }
+                for (int i = tk.a * 64 + lane; i < p.S; i += tk.b * 64) { sm[p.o_skf + i] = 0.0f; sm[p.o_ska + i] = 0.0f; }
+            } else if (op == OP_ARGMAX) {
+                float bv = -INFINITY; int bi = 0x7fffffff;
+                for (int i = lane; i < Q; i += 64) { float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
+                for (int s = 32; s >= 1; s >>= 1) {
+                    float ov = __shfl_xor(bv, s); int oi = __shfl_xor(bi, s);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                const int64_t i = t - (u.n0 - 1);
+                if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
+                if (lane == 0) {
+                    int next;
+                    if (i >= 0) {
+                        u.out[i] = bi;
+                        next = bi;
+                        if (u.teacher) { int64_t s = u.teacher[i] % Q; next = (int)(s < 0 ? s + Q : s); }
+                    } else next = u.known[t + 1];
+                    smi[p.o_samp] = smi[p.o_samp + 1];
+                    smi[p.o_samp + 1] = next;
+                }
+            } else if (op == OP_STAGE) {    // a = first wave of the staging group, b = waves in it
+                if (t + 2 < Ttot)   // the last step has no successor to stage for
+                    stage_step(p, u, sm, t + 1, (wave - tk.a) * 64 + lane, tk.b * 64, p.status);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = wn[j];
+        }
+    }
+}
+
+// ================================================================== host side
+static thread_local char g_err[512] = "";
+void qpn_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* qpn_last_error(void) { return g_err; }
+extern "C" int qpn_version(void) { return 1000; }
+
+int qpn_build_geom(const qpn_config* c, Geom* g) {
+    memset(g, 0, sizeof(*g));
+    if (!c) { qpn_set_error("null config"); return QPN_EINVAL; }
+    g->cfg = *c;
+    if (c->kernel_size != 2) { qpn_set_error("kernel_size must be 2 (reference runQP.py always uses 2)"); return QPN_EINVAL; }
+    if (c->n_quantize < 2 || c->n_aux < 1 || c->n_resch < 1 || c->n_skipch < 1 || c->upsampling_factor < 0 ||
+        c->dilationF_depth < 0 || c->dilationA_depth < 0 || c->dilationF_repeat < 0 || c->dilationA_repeat < 0) {
+        qpn_set_error("bad geometry"); return QPN_EINVAL;
+    }
+    int C = g->C = c->n_resch, S = g->S = c->n_skipch, Q = g->Q = c->n_quantize, A = g->A = c->n_aux;
+    g->U = c->upsampling_factor;
+    g->LF = c->dilationF_depth * c->dilationF_repeat; g->LA = c->dilationA_depth * c->dilationA_repeat; g->L = g->LF + g->LA;
+    if (g->L < 1 || g->L > QPN_MAX_LAYERS) { qpn_set_error("1..%d residual layers supported", QPN_MAX_LAYERS); return QPN_EINVAL; }
+    g->Cp = qpn_pad_k(C); g->Sp = qpn_pad_k(S); g->Ap = qpn_pad_k(A);
+    int64_t o = 0;
+    g->causal_w = o; o += (int64_t)C * Q * 2; g->causal_b = o; o += C;
+    if (g->U > 0) { g->up_w = o; o += g->U; g->up_b = o; o += 1; } else { g->up_w = g->up_b = -1; }
+    const int64_t convsz = (int64_t)C * C * 2 + C, auxsz = (int64_t)C * A + C, sksz = (int64_t)S * C + S, rssz = (int64_t)C * C + C;
+    const int64_t dconv = 2 * ((int64_t)C * C + C);
+    int64_t Fs = o; o += g->LF * convsz; int64_t Ft = o; o += g->LF * convsz;
+    int64_t Fas = o; o += g->LF * auxsz; int64_t Fat = o; o += g->LF * auxsz;
+    int64_t Fsk = o; o += g->LF * sksz; int64_t Frs = o; o += g->LF * rssz;
+    int64_t As = o; o += g->LA * dconv; int64_t At = o; o += g->LA * dconv;
+    int64_t Aas = o; o += g->LA * auxsz; int64_t Aat = o; o += g->LA * auxsz;
+    int64_t Ask = o; o += g->LA * sksz; int64_t Ars = o; o += g->LA * rssz;
+    g->post1_w = o; o += (int64_t)S * S; g->post1_b = o; o += S;
+    g->post2_w = o; o += (int64_t)Q * S; g->post2_b = o; o += Q;
+    g->n_params = o;
+    for (int l = 0; l < g->L; ++l) {
+        LayerGeom& y = g->layers[l];
+        y.adaptive = l >= g->LF;
+        int i = y.adaptive ? l - g->LF : l;
+        int depth = y.adaptive ? c->dilationA_depth : c->dilationF_depth;
+        y.dilation = 1 << (i % depth);
+        if (!y.adaptive) {
+            y.wS = Fs + i * convsz; y.bS = y.wS + (int64_t)C * C * 2;
+            y.wT = Ft + i * convsz; y.bT = y.wT + (int64_t)C * C * 2;
+            y.auxS = Fas + i * auxsz; y.auxSb = y.auxS + (int64_t)C * A;
+            y.auxT = Fat + i * auxsz; y.auxTb = y.auxT + (int64_t)C * A;
+            y.skip = Fsk + i * sksz; y.skipb = y.skip + (int64_t)S * C;
+            y.res = Frs + i * rssz; y.resb = y.res + (int64_t)C * C;
+        } else {
+            y.wS = As + i * dconv; y.bS = y.wS + (int64_t)C * C; y.wSP = y.bS + C; y.bSP = y.wSP + (int64_t)C * C;
+            y.wT = At + i * dconv; y.bT = y.wT + (int64_t)C * C; y.wTP = y.bT + C; y.bTP = y.wTP + (int64_t)C * C;
+            y.auxS = Aas + i * auxsz; y.auxSb = y.auxS + (int64_t)C * A;
+            y.auxT = Aat + i * auxsz; y.auxTb = y.auxT + (int64_t)C * A;
+            y.skip = Ask + i * sksz; y.skipb = y.skip + (int64_t)S * C;
+            y.res = Ars + i * rssz; y.resb = y.res + (int64_t)C * C;
+        }
+    }
+    g->recF = 0; g->recA = 0;
+    for (int l = 0; l < g->L; ++l) (g->layers[l].adaptive ? g->recA : g->recF) += g->layers[l].dilation;
+    return QPN_OK;
+}
+
+extern "C" int64_t qpn_param_count(const qpn_config* cfg) {
+    Geom g; if (qpn_build_geom(cfg, &g) != QPN_OK) return -1; return g.n_params;
+}
+
+struct qpn_handle {
+    Geom g;
+    int device;
+    // decode program
+    std::vector<int> h_map;          // gather map of the packed tile buffer
+    std::vector<Task> h_tasks;
+    int n_slots;
+    int aux_woff4, aux_tiles, logRa;
+    DecodeParams dp;                 // template (pointers filled per call)
+    int* d_map; float* d_wpk; Task* d_tasks; float* d_qb; BiasDesc* d_bd; int* d_status;
+    const float* d_flat; bool have_weights;
+    // per-call workspaces (grow only)
+    float* d_pproj; size_t pproj_cap;
+    float* d_ring; size_t ring_cap;
+    int* d_known; size_t known_cap;
+    UttDesc* d_utts; size_t utts_cap;
+    hipEvent_t ev0, ev1; float last_ms;
+    bool pending;
+};
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// append the tiles of one matrix to the gather map; returns the float4 offset of its first tile.
+// src(row, k) -> flat index (k < K) ; rows in PACKED order.
+template <class F>
+static int pack_matrix(std::vector<int>& map, int rows, int K, int Kp, F src) {
+    const int R = Kp / 16, rpt = 64 / R, tiles = rows / rpt;
+    const int off4 = (int)(map.size() / 4);
+    map.resize(map.size() + (size_t)tiles * 1024);
+    int* m = map.data() + (size_t)off4 * 4;
+    for (int t = 0; t < tiles; ++t)
+        for (int j = 0; j < 4; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    int row = t * rpt + lane / R, q = lane % R, k = 16 * q + 4 * j + e;
+                    int64_t s = k < K ? src(row, k) : -1;
+                    m[((size_t)(t * 4 + j) * 64 + lane) * 4 + e] = (int)s;
+                }
+    return off4;
+}
+
+static int build_program(qpn_handle* h) {
+    Geom& g = h->g;
+    const int C = g.C, S = g.S, Q = g.Q, A = g.A, L = g.L;
+    const int Rc = g.Cp / 16, Rs = g.Sp / 16, Ra = g.Ap / 16;
+    if (Rc > 32 || Rs > 64 || Ra > 64) { qpn_set_error("n_resch <= 512, n_skipch/n_aux <= 1024 supported by the decode kernel"); return QPN_EINVAL; }
+    if ((2 * C) % (64 / Rc) || C % (64 / Rc) || S % (64 / Rc) || S % (64 / Rs) || Q % (64 / Rs) || (2 * C) % (64 / Ra)) {
+        qpn_set_error("channel counts must be multiples of the tile height (n_resch %% %d, n_skipch %% %d, n_quantize %% %d)",
+                      64 / Rc, std::max(64 / Rc, 64 / Rs), 64 / Rs);
+        return QPN_EINVAL;
+    }
+    if (g.n_params >= (int64_t)1 << 31) { qpn_set_error("model too large for 32-bit gather map"); return QPN_EINVAL; }
+    // ---- LDS layout (float offsets, all multiples of 4)
+    DecodeParams& p = h->dp;
+    memset(&p, 0, sizeof(p));
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
+    p.o_xbuf = take((L + 1) * g.Cp); p.o_xp = take(L * g.Cp); p.o_pd = take(L * 2 * C); p.o_auxv = take(L * 2 * C);
+    p.o_g = take(g.Cp); p.o_skf = take(S); p.o_ska = take(S); p.o_y1 = take(g.Sp); p.o_y2 = take(g.Sp); p.o_lg = take(Q);
+    p.o_samp = take(4); p.lds_floats = o;
+    if ((size_t)o * 4 > 160 * 1024) { qpn_set_error("decode state (%d KiB) exceeds the 160 KiB LDS of one CU", o * 4 / 1024); return QPN_EINVAL; }
+    p.C = C; p.Cp = g.Cp; p.S = S; p.Q = Q; p.L = L; p.U = g.U;
+    p.causal_w = g.causal_w; p.causal_b = g.causal_b; p.up_w = g.up_w;
+
+    // ---- packed weight tiles + task list
+    std::vector<int>& map = h->h_map; map.clear();
+    struct Pending { Task t; };
+    std::vector<std::vector<Task>> phases;
+    auto tile_tasks = [&](std::vector<Task>& ph, int op, int off4, int rows, int Kp, int xoff, int a, int b, int c, int d, int flags) {
+        const int R = Kp / 16, rpt = 64 / R, tiles = rows / rpt;
+        for (int t = 0; t < tiles; ++t) {
+            Task k; k.op = op | TF_HASW | flags | (ilog2(R) << 16); k.woff4 = off4 + t * 256; k.xoff = xoff; k.row0 = t * rpt;
+            k.a = a; k.b = b; k.c = c; k.d = d; ph.push_back(k);
+        }
+    };
+    // phase 0: causal lookup (+ clear skip sums) and every layer's past-tap dot
+    std::vector<Task> ph0;
+    {
+        int nblk = (C + 63) / 64;
+        for (int i = 0; i < nblk; ++i) { Task k; memset(&k, 0, sizeof(k)); k.op = OP_CAUSAL; k.a = i; k.b = nblk; ph0.push_back(k); }
+    }
+    std::vector<std::vector<Task>> zph(L), rph(L);
+    for (int l = 0; l < L; ++l) {
+        const LayerGeom y = g.layers[l];
+        auto srcw = [&](int half, int r, int k, int past) -> int64_t {
+            if (!y.adaptive) return (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + (past ? 0 : 1);
+            if (past) return (half ? y.wTP : y.wSP) + (int64_t)r * C + k;
+            return (half ? y.wT : y.wS) + (int64_t)r * C + k;
+        };
+        int off_past = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row / C, row % C, k, 1); });
+        int off_cur = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row & 1, row >> 1, k, 0); });
+        int off_res = pack_matrix(map, C, C, g.Cp, [&](int row, int k) { return y.res + (int64_t)row * C + k; });
+        int off_skip = pack_matrix(map, S, C, g.Cp, [&](int row, int k) { return y.skip + (int64_t)row * C + k; });
+        tile_tasks(ph0, OP_PAST, off_past, 2 * C, g.Cp, p.o_xp + l * g.Cp, p.o_pd + l * 2 * C, 0, 0, 0, 0);
+        tile_tasks(zph[l], OP_Z, off_cur, 2 * C, g.Cp, p.o_xbuf + l * g.Cp, p.o_pd + l * 2 * C, p.o_auxv + l * 2 * C, p.o_g, 0, 0);
+        tile_tasks(rph[l], OP_RES, off_res, C, g.Cp, p.o_g, p.o_xbuf + l * g.Cp, (int)y.resb, p.o_xbuf + (l + 1) * g.Cp, l + 1 < L ? l + 1 : -1, 0);
+        const bool last = l == L - 1;
+        int acc = y.adaptive ? p.o_ska : p.o_skf;
+        int other = last ? (y.adaptive ? (g.LF > 0 ? p.o_skf : -1) : -1) : 0;
+        tile_tasks(rph[l], OP_SKIP, off_skip, S, g.Cp, p.o_g, acc, (int)y.skipb, other, p.o_y1, last ? TF_LAST : 0);
+    }
+    int off_p1 = pack_matrix(map, S, S, g.Sp, [&](int row, int k) { return g.post1_w + (int64_t)row * S + k; });
+    int off_p2 = pack_matrix(map, Q, S, g.Sp, [&](int row, int k) { return g.post2_w + (int64_t)row * S + k; });
+    std::vector<Task> p1, p2, pa;
+    tile_tasks(p1, OP_POST1, off_p1, S, g.Sp, p.o_y1, 0, (int)g.post1_b, p.o_y2, 0, 0);
+    tile_tasks(p2, OP_POST2, off_p2, Q, g.Sp, p.o_y2, 0, (int)g.post2_b, p.o_lg, 0, 0);
+    { Task k; memset(&k, 0, sizeof(k)); k.op = OP_ARGMAX; pa.push_back(k);
+      for (int w = 1; w < QPN_NW; ++w) { Task s; memset(&s, 0, sizeof(s)); s.op = OP_STAGE; s.a = 1; s.b = QPN_NW - 1; pa.push_back(s); } }
+    // aux matrices (natural rows) for the frame-rate projection kernels
+    h->logRa = ilog2(Ra); h->aux_tiles = 2 * C / (64 / Ra);
+    h->aux_woff4 = -1;
+    for (int l = 0; l < L; ++l) {
+        const LayerGeom y = g.layers[l];
+        int off = pack_matrix(map, 2 * C, A, g.Ap, [&](int row, int k) { return (row / C ? y.auxT : y.auxS) + (int64_t)(row % C) * A + k; });
+        if (l == 0) h->aux_woff4 = off;
+    }
+    phases.push_back(ph0);
+    for (int l = 0; l < L; ++l) { phases.push_back(zph[l]); phases.push_back(rph[l]); }
+    phases.push_back(p1); phases.push_back(p2); phases.push_back(pa);
+    // lay the phases out as slots x waves; the ARGMAX/STAGE phase keeps its fixed wave assignment
+    h->h_tasks.clear();
+    int slot = 0;
+    for (size_t pi = 0; pi < phases.size(); ++pi) {
+        const std::vector<Task>& ph = phases[pi];
+        const bool is_last = pi + 1 == phases.size();
+        int ns = (int)((ph.size() + QPN_NW - 1) / QPN_NW);
+        h->h_tasks.resize((size_t)(slot + ns) * QPN_NW);
+        for (int s = 0; s < ns; ++s)
+            for (int w = 0; w < QPN_NW; ++w) {
+                size_t idx = (size_t)s * QPN_NW + w;
+                Task k; memset(&k, 0, sizeof(k)); k.op = OP_NOP;
+                if (idx < ph.size()) k = ph[idx];
+                if (s == 0) k.op |= TF_BARRIER | (is_last ? TF_DRAIN : 0);
+                h->h_tasks[(size_t)(slot + s) * QPN_NW + w] = k;
+            }
+        slot += ns;
+    }
+    h->n_slots = slot;
+    p.n_slots = slot;
+    return QPN_OK;
+}
+
+extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
+    if (!out) { qpn_set_error("null out"); return QPN_EINVAL; }
+    *out = nullptr;
+    qpn_handle* h = new qpn_handle();
+    int rc = qpn_build_geom(cfg, &h->g);
+    if (rc != QPN_OK) { delete h; return rc; }
+    h->d_map = nullptr; h->d_wpk = nullptr; h->d_tasks = nullptr; h->d_qb = nullptr; h->d_bd = nullptr; h->d_status = nullptr;
+    h->d_flat = nullptr; h->have_weights = false;
+    h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
+    h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1;
+    rc = build_program(h);
+    if (rc != QPN_OK) { delete h; return rc; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        // geometry-only handle: usable for qpn_param_count-style queries, every compute call fails loudly
+        h->device = -1; *out = h; return QPN_OK;
+    }
+    QPN_HIP(hipGetDevice(&h->device));
+    *out = h;
+    return QPN_OK;
+}
+
+extern "C" void qpn_destroy(qpn_handle* h) {
+    if (!h) return;
+    if (h->device >= 0) {
+        void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_pproj, h->d_ring, h->d_known, h->d_utts};
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+    }
+    delete h;
+}
+
+static int need_device(qpn_handle* h) {
+    if (!h) { qpn_set_error("null handle"); return QPN_EINVAL; }
+    if (h->device < 0) { qpn_set_error("no HIP device: libqpnet_hip has no CPU fallback"); return QPN_ENODEV; }
+    return QPN_OK;
+}
+
+extern "C" int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream_) {
+    int rc = need_device(h); if (rc) return rc;
+    if (!d_flat || (int64_t)n != h->g.n_params) { qpn_set_error("flat parameter vector must have %lld floats, got %zu", (long long)h->g.n_params, n); return QPN_EINVAL; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const Geom& g = h->g;
+    const size_t nmap = h->h_map.size();
+    if (!h->d_map) {
+        QPN_HIP(hipMalloc(&h->d_map, nmap * sizeof(int)));
+        QPN_HIP(hipMalloc(&h->d_wpk, nmap * sizeof(float)));
+        QPN_HIP(hipMalloc(&h->d_tasks, h->h_tasks.size() * sizeof(Task)));
+        QPN_HIP(hipMalloc(&h->d_qb, (size_t)g.L * 2 * g.C * sizeof(float)));
+        QPN_HIP(hipMalloc(&h->d_bd, (size_t)g.L * sizeof(BiasDesc)));
+        QPN_HIP(hipMalloc(&h->d_status, 64));
+        QPN_HIP(hipMemcpy(h->d_map, h->h_map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
+        QPN_HIP(hipMemcpy(h->d_tasks, h->h_tasks.data(), h->h_tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
+        std::vector<BiasDesc> bd(g.L);
+        for (int l = 0; l < g.L; ++l) {
+            const LayerGeom& y = g.layers[l];
+            bd[l].auxb[0] = y.auxSb; bd[l].auxb[1] = y.auxTb; bd[l].convb[0] = y.bS; bd[l].convb[1] = y.bT;
+            bd[l].convPb[0] = y.bSP; bd[l].convPb[1] = y.bTP; bd[l].adaptive = y.adaptive; bd[l].pad = 0;
+        }
+        QPN_HIP(hipMemcpy(h->d_bd, bd.data(), bd.size() * sizeof(BiasDesc), hipMemcpyHostToDevice));
+        QPN_HIP(hipEventCreate(&h->ev0)); QPN_HIP(hipEventCreate(&h->ev1));
+    }
+    h->d_flat = d_flat;
+    hipLaunchKernelGGL(k_pack_gather, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, h->d_map, h->d_wpk, (int64_t)nmap);
+    float up_b = 0.0f;
+    if (g.U > 0) QPN_HIP(hipMemcpyAsync(&up_b, d_flat + g.up_b, sizeof(float), hipMemcpyDeviceToHost, stream));
+    QPN_HIP(hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(k_fold_bias, dim3(g.L), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_flat, h->d_bd,
+                       h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, up_b, h->d_qb);
+    QPN_HIP(hipGetLastError());
+    QPN_HIP(hipStreamSynchronize(stream));
+    h->have_weights = true;
+    return QPN_OK;
+}
+
+template <class T>
+static int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return QPN_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(p, need * sizeof(T));
+    if (e != hipSuccess) { qpn_set_error("hipMalloc(%zu bytes) failed: %s", need * sizeof(T), hipGetErrorString(e)); return QPN_ENOMEM; }
+    *cap = need;
+    return QPN_OK;
+}
+
+extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+                                  const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+                                  const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+                                  const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream_) {
+    int rc = need_device(h); if (rc) return rc;
+    if (!h->have_weights) { qpn_set_error("qpn_set_weights must be called before qpn_decode"); return QPN_ESTATE; }
+    if (B < 1 || n_x < 1 || F < 1 || !d_x || !d_h || !d_dfac || !h_n_samples || !d_out || maxd < 1) { qpn_set_error("bad decode arguments"); return QPN_EINVAL; }
+    if (mode != QPN_MODE_ARGMAX) { qpn_set_error("mode %d not implemented in this build (argmax only)", mode); return QPN_EINVAL; }
+    const Geom& g = h->g;
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t max_n = 0;
+    for (int b = 0; b < B; ++b) {
+        int64_t n = h_n_samples[b];
+        if (n < 0) { qpn_set_error("negative n_samples"); return QPN_EINVAL; }
+        if (n_x - 1 + n > Td || (g.U > 0 ? (n_x - 1 + n > F * g.U) : (n_x - 1 + n > F))) {
+            qpn_set_error("row %d: n_samples=%lld exceeds the features/dilated factors provided", b, (long long)n); return QPN_EINVAL;
+        }
+        max_n = std::max(max_n, n);
+    }
+    // receptive field and left padding (qpnet.py:351-357)
+    const int64_t RF = (int64_t)g.recA * maxd + g.recF + 1;
+    int64_t n_pad = RF - n_x + 1; if (n_pad < 0) n_pad = 0;
+    const int64_t n0 = n_pad + n_x;
+    if (n0 + max_n >= ((int64_t)1 << 31)) { qpn_set_error("sequence too long"); return QPN_EINVAL; }
+    // ring geometry
+    DecodeParams p = h->dp;
+    size_t ring_floats = 0;
+    for (int l = 0; l < g.L; ++l) {
+        const LayerGeom& y = g.layers[l];
+        int len = (y.adaptive ? y.dilation * maxd : y.dilation) + 1;
+        p.rings[l].base = (int)ring_floats; p.rings[l].len = len; p.rings[l].mult = y.dilation; p.rings[l].adaptive = y.adaptive;
+        ring_floats += (size_t)len * g.C;
+    }
+    ring_floats = (ring_floats + 63) & ~(size_t)63;
+    rc = grow(&h->d_ring, &h->ring_cap, ring_floats * B); if (rc) return rc;
+    rc = grow(&h->d_pproj, &h->pproj_cap, (size_t)B * F * g.L * 2 * g.C); if (rc) return rc;
+    rc = grow(&h->d_known, &h->known_cap, (size_t)B * n0); if (rc) return rc;
+    rc = grow(&h->d_utts, &h->utts_cap, (size_t)B); if (rc) return rc;
+    std::vector<UttDesc> utts(B);
+    const size_t dsz = d_is_f32 ? 4 : 8;
+    for (int b = 0; b < B; ++b) {
+        UttDesc& u = utts[b];
+        u.pproj = h->d_pproj + (size_t)b * F * g.L * 2 * g.C;
+        u.dfac = (const char*)d_dfac + (size_t)b * Td * dsz;
+        u.known = h->d_known + (size_t)b * n0;
+        u.teacher = d_teacher ? d_teacher + (size_t)b * max_n : nullptr;
+        u.out = d_out + (size_t)b * max_n;
+        u.logits = d_logits ? d_logits + (size_t)b * max_n * g.Q : nullptr;
+        u.ring = h->d_ring + (size_t)b * ring_floats;
+        u.n_pad = (int)n_pad; u.n0 = (int)n0; u.n_samples = (int)h_n_samples[b]; u.d_is_f32 = d_is_f32; u.F = F;
+    }
+    QPN_HIP(hipMemcpyAsync(h->d_utts, utts.data(), B * sizeof(UttDesc), hipMemcpyHostToDevice, stream));
+    QPN_HIP(hipStreamSynchronize(stream));   // utts is a host temporary
+    QPN_HIP(hipMemsetAsync(h->d_ring, 0, ring_floats * B * sizeof(float), stream));
+    QPN_HIP(hipMemsetAsync(h->d_status, 0, 64, stream));
+    hipLaunchKernelGGL(k_known, dim3((unsigned)((n0 + 255) / 256), B), dim3(256), 0, stream, d_x, n_x, (int)n_pad, g.Q, h->d_known);
+    hipLaunchKernelGGL(k_aux_project, dim3((unsigned)F, B), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_h, F,
+                       h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.L, h->d_pproj);
+    p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
+    p.status = h->d_status; p.mode = mode; p.seed = seed;
+    if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024)
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
+    QPN_HIP(hipEventRecord(h->ev0, stream));
+    hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), (size_t)p.lds_floats * sizeof(float), stream, p);
+    QPN_HIP(hipGetLastError());
+    QPN_HIP(hipEventRecord(h->ev1, stream));
+    h->pending = true;
+    return QPN_OK;
+}
+
+extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
+    int rc = need_device(h); if (rc) return rc;
+    if (!h->pending) { qpn_set_error("no decode in flight"); return QPN_ESTATE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    QPN_HIP(hipStreamSynchronize(stream));
+    h->pending = false;
+    int status = 0;
+    QPN_HIP(hipMemcpy(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    QPN_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (status & 1) { qpn_set_error("pitch-dependent tap left its ring buffer (dilated factor <= 0.5 or > maxd)"); return QPN_ERANGE; }
+    return QPN_OK;
+}
+
+extern "C" int qpn_decode(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+                          const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+                          const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+                          const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream) {
+    int rc = qpn_decode_enqueue(h, B, n_x, F, Td, d_x, d_h, d_dfac, d_is_f32, h_n_samples, maxd, mode, seed, d_teacher, d_out, d_logits, stream);
+    if (rc) return rc;
+    return qpn_decode_finish(h, stream);
+}
+
+extern "C" float qpn_last_decode_kernel_ms(qpn_handle* h) { return h ? h->last_ms : 0.0f; }
+
+// ---------------------------------------------------------------- dilated index builders
+__global__ void k_didx_train(const float* __restrict__ d, int64_t L, int dilation, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; const int b = blockIdx.y;
+    if (i < L) {
+        float dil = -d[(size_t)b * L + i] * (float)dilation;
+        float s = __fadd_rn(dil, (float)(i - L));
+        out[(size_t)b * L + i] = (int64_t)rintf(s);
+    }
+}
+__global__ void k_didx_gen32(const float* __restrict__ d, int64_t n, int dilation, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int64_t)rintf(-d[i] * (float)dilation);
+}
+__global__ void k_didx_gen64(const double* __restrict__ d, int64_t n, int dilation, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)rint(-d[i] * (double)dilation);
+}
+static int dev_ok() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { qpn_set_error("no HIP device: libqpnet_hip has no CPU fallback"); return QPN_ENODEV; }
+    return QPN_OK;
+}
+extern "C" int qpn_dilated_index_train(const float* d_d, int B, int64_t L, int dilation, int64_t* d_out, void* stream) {
+    int rc = dev_ok(); if (rc) return rc;
+    if (!d_d || !d_out || B < 1 || L < 1) { qpn_set_error("bad arguments"); return QPN_EINVAL; }
+    hipLaunchKernelGGL(k_didx_train, dim3((unsigned)((L + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, d_d, L, dilation, d_out);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}
+extern "C" int qpn_dilated_index_gen_f32(const float* d_d, int64_t n, int dilation, int64_t* d_out, void* stream) {
+    int rc = dev_ok(); if (rc) return rc;
+    if (!d_d || !d_out || n < 1) { qpn_set_error("bad arguments"); return QPN_EINVAL; }
+    hipLaunchKernelGGL(k_didx_gen32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_d, n, dilation, d_out);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}
+extern "C" int qpn_dilated_index_gen_f64(const double* d_d, int64_t n, int dilation, int32_t* d_out, void* stream) {
+    int rc = dev_ok(); if (rc) return rc;
+    if (!d_d || !d_out || n < 1) { qpn_set_error("bad arguments"); return QPN_EINVAL; }
+    hipLaunchKernelGGL(k_didx_gen64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_d, n, dilation, d_out);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}

@@ -1,0 +1,94 @@
+// qpn_common.h -- internal definitions shared by the HIP translation units of libqpnet_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/qpnet_hip.h"
+
+#define QPN_MAX_LAYERS 48
+#define QPN_NW 16                 // waves per decode workgroup
+#define QPN_NT (QPN_NW * 64)
+
+// ---------------------------------------------------------------- error plumbing
+void qpn_set_error(const char* fmt, ...);
+#define QPN_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            qpn_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? QPN_ENOMEM : QPN_ENODEV;                    \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------- geometry
+struct LayerGeom {
+    int adaptive;      // 0 fixed, 1 pitch-adaptive
+    int dilation;      // 2^k
+    // flat offsets (floats) into the state_dict-ordered parameter vector
+    // fixed:    convS/convT = (C,C,2) weights (tap0 older), biasS/biasT
+    // adaptive: convC/convP per half
+    int64_t wS, bS, wT, bT;            // fixed: dil*_sigmoid/tanh .conv.weight/.bias ; adaptive: convC
+    int64_t wSP, bSP, wTP, bTP;        // adaptive only: convP
+    int64_t auxS, auxSb, auxT, auxTb;  // (C,A,1), (C)
+    int64_t skip, skipb, res, resb;    // (S,C,1),(S),(C,C,1),(C)
+};
+
+struct Geom {
+    qpn_config cfg;
+    int C, S, Q, A, U, LF, LA, L;
+    int Cp, Sp, Ap;            // K paddings (16 * power of two)
+    int recF, recA;
+    int64_t causal_w, causal_b, up_w, up_b, post1_w, post1_b, post2_w, post2_b;
+    int64_t n_params;
+    LayerGeom layers[QPN_MAX_LAYERS];
+};
+
+int qpn_build_geom(const qpn_config* cfg, Geom* g);
+static inline int qpn_pad_k(int K) { int R = 1; while (16 * R < K) R *= 2; return 16 * R; }
+
+// ---------------------------------------------------------------- decode program
+enum {
+    OP_NOP = 0, OP_PAST, OP_Z, OP_RES, OP_SKIP, OP_POST1, OP_POST2, OP_CAUSAL, OP_ARGMAX, OP_STAGE
+};
+#define TF_BARRIER 0x100      // workgroup barrier before this task
+#define TF_DRAIN   0x200      // ... and drain this wave's global stores first
+#define TF_LAST    0x400      // OP_SKIP of the last layer: also emit relu(skip total)
+#define TF_HASW    0x800      // task consumes a weight tile (prefetchable)
+
+struct Task {          // 32 bytes, wave-uniform, read through the scalar cache
+    int op;            // opcode | flags | (log2 R << 16)
+    int woff4;         // float4 offset of the weight tile in the packed buffer
+    int xoff;          // LDS float offset of the input vector
+    int row0;          // first row of the tile (in the matrix' packed row order)
+    int a, b, c, d;    // op specific
+};
+
+struct RingDesc { int base; int len; int mult; int adaptive; };   // base: float offset in the utterance's ring block
+
+struct UttDesc {
+    const float* pproj;     // [F][L][2C] per-frame aux projections
+    const void* dfac;       // dilated factors row (double or float)
+    const int* known;       // [n0] padded known prefix (sample ids)
+    const int64_t* teacher; // optional [n_samples]
+    int64_t* out;           // [n_samples]
+    float* logits;          // optional [n_samples][Q]
+    float* ring;            // ring block of this utterance (zeroed before launch)
+    int n_pad, n0, n_samples, d_is_f32;
+    int64_t F;
+};
+
+struct DecodeParams {
+    const float4* wpk;
+    const float* flat;
+    const float* qb;        // [L][2C]
+    const Task* tasks;
+    const UttDesc* utts;
+    int* status;
+    int n_slots;
+    int C, Cp, S, Q, L, U, mode;
+    int64_t causal_w, causal_b, up_w;
+    int o_xbuf, o_xp, o_pd, o_auxv, o_g, o_skf, o_ska, o_y1, o_y2, o_lg, o_samp, lds_floats;
+    unsigned long long seed;
+    RingDesc rings[QPN_MAX_LAYERS];
+};

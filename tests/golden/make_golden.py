@@ -26,6 +26,8 @@ import qpnet as ref  # noqa: E402  (the reference module)
 
 from qpnet_amd import synth  # noqa: E402
 from qpnet_amd.config import TINY, PAPER, QPNetConfig  # noqa: E402
+sys.path.insert(0, HERE)
+from cases import DECODE_CASES, FORWARD_CASES, TRAIN_CASES  # noqa: E402
 
 torch.set_num_threads(8)
 torch.set_grad_enabled(False)
@@ -70,17 +72,6 @@ def gen_kat():
     print("kat.npz written")
 
 
-DECODE_CASES = [
-    # name, cfg, weight seed, [(feat seed, n_frames, f0_factor)], extra_memory
-    ("tiny_b1", TINY, 11, [(21, 10, 1.0)], False),
-    ("tiny_b3", TINY, 11, [(22, 7, 1.0), (23, 12, 1.0), (24, 7, 1.0)], False),
-    ("tiny_f0half", TINY, 12, [(25, 12, 0.5)], False),
-    ("tiny_f0x15_f32", TINY, 12, [(26, 12, 1.5)], True),
-    ("paper_b1", PAPER, 13, [(31, 50, 1.0)], False),
-    ("paper_f0half", PAPER, 13, [(32, 30, 0.5)], False),
-    ("paper_f0x15", PAPER, 13, [(33, 30, 1.5)], False),
-    ("paper_b2", PAPER, 14, [(34, 20, 1.0), (35, 26, 1.0)], False),
-]
 
 
 def gen_decode():
@@ -108,11 +99,6 @@ def gen_decode():
     print("decode.npz written")
 
 
-FORWARD_CASES = [
-    # name, cfg, weight seed, data seed, batch_length, max_length
-    ("tiny", TINY, 11, 41, 600, 30000),
-    ("paper", PAPER, 13, 42, 1500, 30000),
-]
 
 
 def gen_forward():
@@ -133,11 +119,6 @@ def gen_forward():
     print("forward.npz written")
 
 
-TRAIN_CASES = [
-    # name, cfg, weight seed, data seed, batch_length, n_steps
-    ("tiny", TINY, 11, 51, 800, 4),
-    ("paper", PAPER, 13, 52, 1200, 3),
-]
 
 
 def gen_train():
@@ -160,12 +141,12 @@ def gen_train():
             opt.zero_grad()
             loss.backward()
             if step == 0:
-                g = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+                g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in m.parameters()]).numpy()
                 if g.size > 60000:   # keep the fixture small: per-tensor L2 norms + a strided sample
                     out[name + "_grad0_sample"] = g[::97].astype(np.float32)
                 else:
                     out[name + "_grad0"] = g.astype(np.float32)
-                out[name + "_grad0_norms"] = np.array([p.grad.norm().item() for p in m.parameters()])
+                out[name + "_grad0_norms"] = np.array([0.0 if p.grad is None else p.grad.norm().item() for p in m.parameters()])
             opt.step()
             losses.append(loss.item())
         w = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).numpy()

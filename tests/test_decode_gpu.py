@@ -1,0 +1,66 @@
+"""GPU parity: the HIP persistent decode kernel vs (a) the reference's own greedy streams
+(golden fixtures made by importing the reference) and (b) the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from cases import DECODE_CASES
+from qpnet_amd import synth
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", DECODE_CASES, ids=[c[0] for c in DECODE_CASES])
+def test_decode_matches_reference_streams(case, cuda, golden_dir, oracle):
+    import torch
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    d_arg = torch.from_numpy(bd).float().to(cuda) if extra else bd
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, d_arg,
+                                 mode="argmax", extra_memory=extra)
+    assert nlist == list(g[name + "_nleft"])           # list consumed like the reference
+    onl = list(ns)
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, onl, bd.astype(np.float32) if extra else bd)
+    assert len(outs) == len(utts)
+    for i, s in enumerate(outs):
+        ref = g["%s_out%d" % (name, i)].astype(np.int64)
+        assert s.dtype == np.int64 and s.shape == ref.shape
+        np.testing.assert_array_equal(s, o_outs[i], err_msg="HIP vs oracle, row %d" % i)
+        np.testing.assert_array_equal(s, ref, err_msg="HIP vs reference stream, row %d" % i)
+
+
+def test_stream_logits_bitwise_vs_oracle(cuda, oracle):
+    """Teacher-forced per-step logits of the HIP kernel are BIT-identical to the oracle's."""
+    import torch
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 77)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, d, n = synth.decode_inputs(cfg, 6, 5, 1.0)
+    rs = np.random.RandomState(9)
+    teacher = rs.randint(0, 256, size=n).astype(np.int64)
+    out, logits = m._stream_logits(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda),
+                                   d[None], torch.from_numpy(teacher[None]), n)
+    r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True)
+    lg = logits[0].cpu().numpy()
+    assert np.array_equal(lg.view(np.uint32), r["logits"].view(np.uint32)), \
+        "max abs diff %g" % np.abs(lg - r["logits"]).max()
+    np.testing.assert_array_equal(out[0].cpu().numpy(), r["samples"])
+
+
+def test_decode_range_error(cuda):
+    """A dilated factor above maxd must be reported (reference asserts, qpnet.py:294,417)."""
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd import _lib
+    flat = synth.make_weights(TINY, 3)
+    m = util.build_model(TINY, flat, cuda)
+    x, h, d, n = synth.decode_inputs(TINY, 4, 5, 1.0)
+    d = d.copy(); d[200:] = 0.2        # rounds to a tap distance of 0 -> out of contract
+    with pytest.raises(_lib.QpnError) as e:
+        m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode="argmax")
+    assert e.value.code == -4
