@@ -48,6 +48,9 @@ def lib():
             raise ImportError(
                 "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). qpnet_amd has no CPU/PyTorch fallback." % LIB_PATH)
+        # torch ships its own libamdhip64; load it FIRST so this library binds to the same HIP
+        # runtime instance (two runtimes in one process do not see each other's device state).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)

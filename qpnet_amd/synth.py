@@ -110,3 +110,17 @@ def train_inputs(cfg: QPNetConfig, batch_length: int, seed: int = 1, max_length:
         xs.append(x_[:-1]); ts.append(x_[1:]); hs.append(h_.T.copy()); ds.append(d[:x_bs][:-1]); bs.append(bl)
     assert len(set(bs)) == 1, "all rows of a batch must share batch_length (qpnet.py:253)"
     return (np.stack(xs), np.stack(hs), np.stack(ts), np.stack(ds), np.array(bs, dtype=np.int64))
+
+
+def decode_batch(cfg: QPNetConfig, utts):
+    """A decode batch prepared the way ``decode_generator`` does (reference bin/qpnet_decode.py:152-209).
+    utts: [(feature seed, n_frames, f0_factor)].  Returns x (B,1) int64, h (B,A,Fmax) f32 zero padded,
+    d (B,Tmax) f64 zero padded, n_samples list."""
+    xs, hs, ds, ns = [], [], [], []
+    for (fs, nf, fac) in utts:
+        x, h, d, n = decode_inputs(cfg, nf, fs, fac)
+        xs.append(x); hs.append(h.T); ds.append(d[:, None]); ns.append(n)
+    bx = np.stack(xs)
+    bh = np.ascontiguousarray(harness.pad_list(hs).transpose(0, 2, 1)).astype(np.float32)
+    bd = harness.pad_list(ds).squeeze(-1)
+    return bx, bh, bd, ns
