@@ -132,6 +132,19 @@ def decode(cfg, flat_w, h, d, x, n_samples, maxd=None, teacher=None, d_is_f32=Fa
     return {"samples": out, "margin": margin, "logits": logits}
 
 
+def forward(cfg, flat_w, x, h, d, batch_length):
+    """QPNet.forward for ONE batch row (qpnet.py:239-312) restated as teacher-forced streaming:
+    x (T,) int64, h (n_aux, F), d (T,) float32 -> logits (batch_length, Q) for the last positions.
+    Uses the training index expression (qpnet.py:592-604)."""
+    x = np.asarray(x, dtype=np.int64); T = x.size; BL = int(batch_length)
+    d32 = np.asarray(d, dtype=np.float32)
+    maxd = int(np.ceil(d32).max())
+    n_x = T - BL + 1
+    teacher = np.concatenate([x[n_x:], [0]])
+    r = decode(cfg, flat_w, h, d32.astype(np.float64), x[:n_x], BL, maxd=maxd, teacher=teacher, d_is_f32=2, want_logits=True)
+    return r["logits"]
+
+
 def batch_fast_generate(cfg, flat_w, x, h, n_samples_list, dilated_factors, mode="argmax"):
     """Batch semantics of QPNet.batch_fast_generate (qpnet.py:314-559): rows are independent,
     padding uses the batch-level ceil(max d); results are returned in completion order

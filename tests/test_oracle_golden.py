@@ -1,0 +1,90 @@
+"""CPU: the oracle (oracle/qpnet_oracle.c) against the fixtures produced by importing the
+reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from cases import DECODE_CASES, FORWARD_CASES
+from qpnet_amd import synth
+import util
+
+
+def test_mulaw_kat(oracle, golden_dir):
+    g = np.load(golden_dir + "/kat.npz")
+    np.testing.assert_array_equal(oracle.encode_mu_law(g["mulaw_x"]), g["mulaw_enc"])
+    np.testing.assert_allclose(oracle.decode_mu_law(np.arange(256)), g["mulaw_dec"], rtol=1e-14, atol=0)
+    # SURVEY §8a a1/a2 known answers
+    np.testing.assert_array_equal(oracle.encode_mu_law(np.array([-1, -.5, 0, .5, 1.0])), [0, 16, 128, 239, 255])
+    np.testing.assert_allclose(oracle.decode_mu_law(np.array([0, 128, 255])), [-1.02207017, 0.0, 0.97840458], atol=1e-8)
+
+
+def test_mulaw_product_matches_reference(golden_dir):
+    from qpnet_amd.qpnet import encode_mu_law, decode_mu_law
+    g = np.load(golden_dir + "/kat.npz")
+    np.testing.assert_array_equal(encode_mu_law(g["mulaw_x"], 256), g["mulaw_enc"])
+    np.testing.assert_array_equal(decode_mu_law(np.arange(256), 256), g["mulaw_dec"])
+
+
+@pytest.mark.parametrize("tag", ["h", "1", "x"])
+def test_dilated_index_kat(oracle, golden_dir, tag):
+    g = np.load(golden_dir + "/kat.npz")
+    d64 = g["didx_d64_" + tag]
+    d32 = d64.astype(np.float32)
+    for k in range(4):
+        np.testing.assert_array_equal(oracle.dilated_index_train(d32, 2 ** k), g["didx_train_f32_%s_%d" % (tag, k)])
+        np.testing.assert_array_equal(oracle.dilated_index_train(d64, 2 ** k), g["didx_train_f64_%s_%d" % (tag, k)])
+        np.testing.assert_array_equal(oracle.dilated_index_gen(d32, 2 ** k), g["didx_gen_f32_%s_%d" % (tag, k)])
+        np.testing.assert_array_equal(oracle.dilated_index_gen(d64, 2 ** k), g["didx_gen_f64_%s_%d" % (tag, k)])
+
+
+def test_dilated_index_long(oracle, golden_dir):
+    g = np.load(golden_dir + "/kat.npz")
+    np.testing.assert_array_equal(oracle.dilated_index_train(g["didx_long_d32"], 8), g["didx_long_train_f32_3"])
+
+
+@pytest.mark.parametrize("case", DECODE_CASES, ids=[c[0] for c in DECODE_CASES])
+def test_oracle_decode_equals_reference_streams(case, oracle, golden_dir):
+    """bit-exact mu-law indices for greedy decode, incl. B>1 completion order, f0 x0.5 / x1.5,
+    float32 (extra_memory) and float64 index paths."""
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode.npz")
+    flat = synth.make_weights(cfg, wseed)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = oracle.batch_fast_generate(cfg, flat, bx, bh, nlist, bd.astype(np.float32) if extra else bd)
+    assert nlist == list(g[name + "_nleft"])
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64))
+
+
+@pytest.mark.parametrize("case", FORWARD_CASES, ids=[c[0] for c in FORWARD_CASES])
+def test_oracle_forward_equals_reference_logits(case, oracle, golden_dir):
+    """QPNet.forward (teacher forced) == streaming oracle on the same samples (SURVEY §4 identity),
+    logits within fp32 reassociation error and CE loss within 1e-4 (north_star tolerance)."""
+    name, cfg, wseed, dseed, bl, ml = case
+    g = np.load(golden_dir + "/forward.npz")
+    flat = synth.make_weights(cfg, wseed)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
+    BL = int(b[0])
+    assert BL == int(g[name + "_bl"])
+    lg = oracle.forward(cfg, flat, x[0], h[0], d[0], BL)
+    ref = g[name + "_logits"][0]
+    np.testing.assert_allclose(lg, ref, atol=5e-6, rtol=0)
+    assert (lg.argmax(1) == ref.argmax(1)).all()
+    lse = np.log(np.exp(lg.astype(np.float64)).sum(1))
+    loss = (lse - lg[np.arange(BL), t[0, -BL:]]).mean()
+    assert abs(loss - float(g[name + "_loss"])) < 1e-4
+
+
+def test_qexp_qgate_accuracy(oracle):
+    """the spec's exp / gate are within a few ulp of libm (so the fixed-order spec is a faithful fp32
+    evaluation of sigmoid*tanh, reference qpnet.py:634-635)."""
+    L = oracle.lib()
+    xs = np.linspace(-20, 20, 4001).astype(np.float32)
+    e = np.array([L.qpo_qexp(float(x)) for x in xs], dtype=np.float64)
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(e - ref) / ref) < 3e-7
+    rs = np.random.RandomState(0)
+    a, b = rs.uniform(-8, 8, 2000).astype(np.float32), rs.uniform(-8, 8, 2000).astype(np.float32)
+    gq = np.array([L.qpo_qgate(float(u), float(v)) for u, v in zip(a, b)])
+    gr = 1 / (1 + np.exp(-a.astype(np.float64))) * np.tanh(b.astype(np.float64))
+    assert np.max(np.abs(gq - gr)) < 3e-7
