@@ -100,6 +100,38 @@ int qpn_decode_finish(qpn_handle* h, void* stream);
  * measured with HIP events on the launch stream (bench.py roofline). */
 float qpn_last_decode_kernel_ms(qpn_handle* h);
 
+/*
+ * QPNet.forward (reference src/nets/qpnet.py:239-312), teacher forced, fused fp32-MFMA kernels.
+ *   d_flat   flat fp32 parameters (state_dict order), read at call time (training updates them)
+ *   d_x      (B x T) int64 samples         d_h  (B x n_aux x F) fp32 frame-rate features
+ *   d_dfac   (B x Td) fp32 dilated factors BL   batch_length (same for every row, qpnet.py:253)
+ *   maxd     int(max(ceil(dilated_factors))) over the whole tensor (qpnet.py:255)
+ *   d_logits (B x BL x n_quantize) fp32 out.  Activations needed by backward stay in the
+ *   handle's workspace until the next qpn_train_forward.  Asynchronous on `stream`.
+ */
+int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                      const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits, void* stream);
+
+/* autograd of the above (reference: loss.backward(), src/bin/qpnet_train.py:529-530):
+ * d_dlogits (B x BL x n_quantize) -> d_flatgrad (n_params, overwritten), same layout as d_flat. */
+int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, void* stream);
+
+/* Synchronise and report the device-side status of the last training call (QPN_ERANGE when a
+ * pitch-dependent tap left its layer input: reference assert qpnet.py:294). */
+int qpn_train_status(qpn_handle* h, void* stream);
+
+/* torch.nn.CrossEntropyLoss() (mean) on the logits above and, optionally, its gradient
+ * (reference src/bin/qpnet_train.py:430,526-528).  d_targets is the (B x tgt_stride) int64 target
+ * tensor whose LAST BL columns are used (batch_t[:, -batch_length:]).  h_loss (optional, host)
+ * receives the loss (synchronises); d_dlogits (optional) receives dL/dlogits. */
+int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,
+                float* d_dlogits, double* h_loss, void* stream);
+
+/* torch.optim.Adam step (reference src/bin/qpnet_train.py:426-429,531), fp32, in place:
+ * d_flat, d_m, d_v (n floats each) updated from d_grad; `step` is the 1-based step count. */
+int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
+                  int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
 /* _dilated_index (src/nets/qpnet.py:592-604, tensor path) and _generate_dilated_index
  * (src/nets/qpnet.py:613-618): d (B x L) float32 -> int64 (B x L), NOT replicated over
  * channels (the reference's .repeat over n_ch is redundant). */

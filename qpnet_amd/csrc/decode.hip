@@ -15,6 +15,7 @@
 // Arithmetic is the fixed-order fp32 "QPNet-f32" spec of DESIGN.md §3, so results are
 // bit-identical to the CPU oracle; compile with -ffp-contract=off.
 #include "qpn_common.h"
+#include "qpn_handle.h"
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -87,7 +88,6 @@ __global__ void k_pack_gather(const float* __restrict__ flat, const int* __restr
     if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
 }
 
-struct BiasDesc { int64_t auxb[2], convb[2], convPb[2]; int adaptive; int pad; };
 
 // Qb[l][row] = ((b_up * dot(Va[row,:], 1) + ba) + b_conv) [+ b_convP]   
 // one workgroup of 64*k lanes per layer; aux tiles packed natural-row, R = Ap/16.
@@ -390,25 +390,7 @@ extern "C" int64_t qpn_param_count(const qpn_config* cfg) {
     Geom g; if (qpn_build_geom(cfg, &g) != QPN_OK) return -1; return g.n_params;
 }
 
-struct qpn_handle {
-    Geom g;
-    int device;
-    // decode program
-    std::vector<int> h_map;          // gather map of the packed tile buffer
-    std::vector<Task> h_tasks;
-    int n_slots;
-    int aux_woff4, aux_tiles, logRa;
-    DecodeParams dp;                 // template (pointers filled per call)
-    int* d_map; float* d_wpk; Task* d_tasks; float* d_qb; BiasDesc* d_bd; int* d_status;
-    const float* d_flat; bool have_weights;
-    // per-call workspaces (grow only)
-    float* d_pproj; size_t pproj_cap;
-    float* d_ring; size_t ring_cap;
-    int* d_known; size_t known_cap;
-    UttDesc* d_utts; size_t utts_cap;
-    hipEvent_t ev0, ev1; float last_ms;
-    bool pending;
-};
+
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -541,7 +523,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     h->d_map = nullptr; h->d_wpk = nullptr; h->d_tasks = nullptr; h->d_qb = nullptr; h->d_bd = nullptr; h->d_status = nullptr;
     h->d_flat = nullptr; h->have_weights = false;
     h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
-    h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1;
+    h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
     rc = build_program(h);
     if (rc != QPN_OK) { delete h; return rc; }
     int ndev = 0;
@@ -559,6 +541,7 @@ extern "C" void qpn_destroy(qpn_handle* h) {
     if (h->device >= 0) {
         void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_pproj, h->d_ring, h->d_known, h->d_utts};
         for (void* b : bufs) if (b) (void)hipFree(b);
+        qpn_train_destroy(h->train);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
     }

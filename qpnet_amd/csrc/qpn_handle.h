@@ -1,0 +1,28 @@
+// qpn_handle.h -- the library handle (shared by decode.hip and train_host.hip)
+#pragma once
+#include "qpn_common.h"
+
+struct BiasDesc { int64_t auxb[2], convb[2], convPb[2]; int adaptive; int pad; };
+struct TrainState;
+void qpn_train_destroy(TrainState* t);
+
+struct qpn_handle {
+    Geom g;
+    int device;
+    // decode program
+    std::vector<int> h_map;          // gather map of the packed tile buffer
+    std::vector<Task> h_tasks;
+    int n_slots;
+    int aux_woff4, aux_tiles, logRa;
+    DecodeParams dp;                 // template (pointers filled per call)
+    int* d_map; float* d_wpk; Task* d_tasks; float* d_qb; BiasDesc* d_bd; int* d_status;
+    const float* d_flat; bool have_weights;
+    // per-call workspaces (grow only)
+    float* d_pproj; size_t pproj_cap;
+    float* d_ring; size_t ring_cap;
+    int* d_known; size_t known_cap;
+    UttDesc* d_utts; size_t utts_cap;
+    hipEvent_t ev0, ev1; float last_ms;
+    bool pending;
+    struct TrainState* train;        // lazily created by the training entry points (train_host.hip)
+};

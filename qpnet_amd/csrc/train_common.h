@@ -1,0 +1,99 @@
+// train_common.h -- shared pieces of the MFMA training kernels (forward / backward).
+//
+// All activations are TIME-MAJOR [n][channels] fp32 (one 256-byte row per time step for C=64):
+// the pitch-dependent gather then moves whole contiguous rows, and every contraction is a
+// GEMM with M = time.  Contractions run on the fp32 matrix cores: v_mfma_f32_16x16x4_f32
+// (exact fp32, 256 FLOP/clk/CU), A operand from an LDS tile, B operand (weights) from a
+// fragment-ordered copy that a gather kernel refreshes from the flat parameter vector
+// every step (weights change every step; 0.5 M floats).
+#pragma once
+#include "qpn_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TR_TM 64           // time rows per workgroup tile
+#define TR_MAXL QPN_MAX_LAYERS
+
+// leading dimension for an LDS A-tile read "row = lane&15, k = lane>>4" with ds_read_b32:
+// ld == 2 (mod 32) makes the 32-lane groups conflict free (MI355X_MICROARCH.md §LDS).
+__host__ __device__ static inline int tr_lda(int K) { return ((K + 29) / 32) * 32 + 2; }
+// leading dimension for transposed reads "k-row = lane>>4, col = lane&15": ld == 16 (mod 32)
+__host__ __device__ static inline int tr_ldt(int N) { return ((N + 15) / 32) * 32 + 16; }
+
+struct TrLayer {
+    int adaptive, dilation;
+    int s_in, s_out;          // first valid local row of the layer input / output
+    int tap_off;              // offset (ints) of this layer's tap table in the TAP buffer, or -1 (fixed)
+    // fragment-ordered weight blocks (float4 offsets into the packed training weights)
+    int w1_f4, wr_f4;         // fwd: [Ktp x 2C], [C x C]
+    int w1t_f4, wrt_f4;       // bwd: [2C x Ktp] (dA = dZ.W1), [C x C] (dg = dXout.Wr)
+    int bias1, biasr;         // float offsets into the packed bias block
+};
+
+struct TrainParams {
+    int C, S, Q, A, Ap, L, U;
+    int B, T, F, Td, BL, N1, N0, maxd;
+    int Kt, Ktp;              // 2C + Ap, padded to 16
+    int LC;                   // L * C (skip contraction depth)
+    // global buffers
+    const float* flat;        // parameters (state_dict order)
+    const float4* wp;         // fragment-ordered weights
+    const float* bp;          // packed biases
+    const int64_t* x; const float* h; const float* d;
+    float* X;                 // [L+1][B][N1][C]
+    float* SG; float* TH;     // [L][B][N1][C]
+    float* HUP;               // [B][N1][Ap]
+    int* TAP;                 // [LA][B][N1]
+    float* S0; float* Y0;     // [B][BL][S] pre-relu skip sum / post1
+    float* logits;            // [B][BL][Q]
+    int* status;
+    // post-net packed blocks
+    int ws_f4, p1_f4, p2_f4;          // fwd: [LC x S], [S x S], [S x Q]
+    int wst_f4, p1t_f4, p2t_f4;       // bwd: [S x LC], [S x S], [Q x S]
+    int bias_s, bias_p1, bias_p2;     // packed bias offsets (bias_s = sum over layers of skip biases)
+    int64_t causal_w, causal_b, up_w, up_b;
+    TrLayer layers[TR_MAXL];
+};
+
+struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
+    const float* dlogits; float* gflat;
+    float* DXA[2]; float* DXB[2];     // [B][N1][C] grads w.r.t. a layer input: own-position part / scattered pitch-tap part
+    float* DZ;                        // [B][N1][2C] gate pre-activation grads of the current layer
+    float* DS0; float* DY0;           // [B][BL][S]
+    float* DGS;                       // [B][BL][L*C]
+    float* DHUP;                      // [B][N1][Ap]
+    float* slab;                      // [NCH][gstage] split-time partial weight grads
+    const int* gsrc;                  // [n_params] gather map flat-grad <- slab space (-1: owned by a special kernel)
+    const int* gsrc2;                 // second source (adaptive conv biases share one gradient), -1 if none
+    int nch, gstage;
+    int64_t n_params;
+    // slab offsets (floats) of every weight-grad block
+    int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
+    int g_p1, g_bp1, g_p2, g_bp2;
+};
+
+// ---- one wave: acc[mt][j] += A_lds[16*mt.., :K] * Bfrag[:, nt_j]   (K multiple of 16)
+// A_lds row-major with leading dim lda (floats); Bp fragment order: [(ks4*NT + nt)*64 + lane] float4,
+// element e of the float4 = B[4*(4*ks4+e) + (lane>>4)][16*nt + (lane&15)].
+template <int MT, int NJ>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
+                                          const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
+    const int arow = lane & 15, ak = lane >> 4;
+    for (int ks4 = 0; ks4 < K / 16; ++ks4) {
+        float4 b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = Bp[((size_t)ks4 * NT + nts[j]) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float* ap = A_lds + (size_t)(16 * mt + arow) * lda + 16 * ks4 + ak;
+            const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j].x, acc[mt][j], 0, 0, 0);
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j].y, acc[mt][j], 0, 0, 0);
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[j].z, acc[mt][j], 0, 0, 0);
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[j].w, acc[mt][j], 0, 0, 0);
+            }
+        }
+    }
+}

@@ -1,0 +1,307 @@
+// train_fwd.hip -- teacher-forced forward of QPNet on gfx950 (MI355X): QPNet.forward
+// (reference src/nets/qpnet.py:239-312) as fused fp32-MFMA kernels.
+//
+//   k_train_prep : OneHot+CausalConv1d as a 2-row table lookup (qpnet.py:60-79,110-132), the
+//                  ConvTranspose2d upsampling of h (qpnet.py:134-158) and the pitch-dependent
+//                  tap table _dilated_index (qpnet.py:592-604) -- no (B,T,256) one-hot, no
+//                  C-fold replicated int64 index tensor.
+//   k_layer_fwd  : one gated residual block (qpnet.py:626-640 / 657-670) per launch:
+//                  gather(prev, pitch tap) -> [x_cur | x_past | aux] . W1 on MFMA -> sigmoid*tanh
+//                  in registers -> res 1x1 on MFMA + residual.  The skip 1x1 is NOT done here:
+//   k_post_fwd   : sum_l Ws_l g_l (one K = L*C contraction over the saved gates, last
+//                  batch_length rows only, qpnet.py:283,306,309) -> relu -> 1x1 -> relu -> 1x1
+//                  (_postprocess, qpnet.py:566-571), all on MFMA, logits written time-major
+//                  (B, BL, Q) exactly as the reference returns them.
+#include "train_common.h"
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+__global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per time row
+    const int lane = threadIdx.x & 63;
+    if (n >= p.N1) return;
+    const int C = p.C, Q = p.Q;
+    // causal conv on one-hot input == two table rows (tap 0 = older sample)
+    const int64_t xo = (int64_t)p.T - p.N0 + n;
+    int64_t s0 = p.x[(size_t)b * p.T + xo] % Q, s1 = p.x[(size_t)b * p.T + xo + 1] % Q;
+    if (s0 < 0) s0 += Q;
+    if (s1 < 0) s1 += Q;
+    float* X0 = p.X + ((size_t)b * p.N1 + n) * C;
+    for (int c = lane; c < C; c += 64) {
+        float v = p.flat[p.causal_w + ((size_t)c * Q + s0) * 2] + p.flat[p.causal_w + ((size_t)c * Q + s1) * 2 + 1];
+        X0[c] = v + p.flat[p.causal_b + c];
+    }
+    // upsampled aux features, aligned at the END of h_up (negative hindex, qpnet.py:269-276)
+    float* hu = p.HUP + ((size_t)b * p.N1 + n) * p.Ap;
+    if (lane < p.Ap) {
+        float v = 0.0f;
+        if (lane < p.A) {
+            if (p.U > 0) {
+                const int64_t q = (int64_t)p.F * p.U - p.N1 + n;
+                const int64_t f = q / p.U; const int j = (int)(q - f * p.U);
+                v = p.h[((size_t)b * p.A + lane) * p.F + f] * p.flat[p.up_w + j] + p.flat[p.up_b];
+            } else {
+                v = p.h[((size_t)b * p.A + lane) * p.F + (p.F - p.N1 + n)];
+            }
+        }
+        hu[lane] = v;
+    }
+    // pitch-dependent taps: N1 + rint(float32(-d*dil) + float32(idx)), idx = n - N1 (qpnet.py:595-600)
+    if (lane < p.L) {
+        const TrLayer ly = p.layers[lane];
+        if (ly.adaptive) {
+            const float dv = p.d[(size_t)b * p.Td + (p.Td - p.N1 + n)];
+            const float dil = -dv * (float)ly.dilation;
+            const float s = __fadd_rn(dil, (float)(n - p.N1));
+            int tap = p.N1 + (int)rintf(s);
+            if (n >= ly.s_out && (tap < ly.s_in || tap > n)) { atomicOr(p.status, 1); }   // reference assert (qpnet.py:294)
+            tap = tap < 0 ? 0 : (tap >= p.N1 ? p.N1 - 1 : tap);
+            p.TAP[ly.tap_off + (size_t)b * p.N1 + n] = tap;
+        }
+    }
+}
+
+// dynamic LDS: As[64][lda(Ktp)] | Gs[64][lda(C)]
+__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
+    extern __shared__ float sm[];
+    const TrLayer ly = p.layers[l];
+    const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
+    const int lda = tr_lda(Ktp), ldg = tr_lda(C);
+    float* As = sm; float* Gs = sm + 64 * lda;
+    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TR_TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
+    const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
+    const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
+    // ---- stage [x_cur | x_past | aux | 0] rows into LDS (float2 granularity: lda is even, not /4)
+    const int K2 = Ktp / 2;
+    for (int idx = tid; idx < TR_TM * K2; idx += 256) {
+        const int r = idx / K2, k = (idx - r * K2) * 2;
+        const int n = n0 + r;
+        float2 v = make_float2(0.f, 0.f);
+        if (n < p.N1) {
+            if (k < C) v = *(const float2*)(Xin + (size_t)n * C + k);
+            else if (k < 2 * C) { const int tp = taps ? taps[n] : n - ly.dilation; v = *(const float2*)(Xin + (size_t)tp * C + (k - C)); }
+            else if (k < 2 * C + Ap) v = *(const float2*)(hup + (size_t)n * Ap + (k - 2 * C));
+        }
+        *(float2*)(As + (size_t)r * lda + k) = v;
+    }
+    __syncthreads();
+    const float4* W1 = p.wp + ly.w1_f4;
+    const float* bias1 = p.bp + ly.bias1;
+    float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
+    float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
+    const int NCG = C / 16;
+    for (int cg = wave; cg < NCG; cg += 4) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        const int nts[2] = {cg, NCG + cg};
+        wave_gemm<4, 2>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
+        const int c = 16 * cg + (lane & 15);
+        const float bs = bias1[c], bt = bias1[C + c];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * mt + 4 * (lane >> 4) + i;
+                const float sg = sigmoidf_(acc[mt][0][i] + bs);
+                const float th = tanhf(acc[mt][1][i] + bt);
+                Gs[(size_t)r * ldg + c] = sg * th;
+                if (n0 + r < p.N1) { SG[(size_t)(n0 + r) * C + c] = sg; TH[(size_t)(n0 + r) * C + c] = th; }
+            }
+    }
+    if (last) return;               // the last block's residual output is never used (qpnet.py:306-309)
+    __syncthreads();
+    const float4* Wr = p.wp + ly.wr_f4;
+    const float* br = p.bp + ly.biasr;
+    float* Xout = p.X + ((size_t)((l + 1) * p.B + b) * p.N1) * C;
+    for (int nt = wave; nt < NCG; nt += 4) {
+        f32x4 acc[4][1];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
+        const int nts[1] = {nt};
+        wave_gemm<4, 1>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
+        const int c = 16 * nt + (lane & 15);
+        const float bb = br[c];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * mt + 4 * (lane >> 4) + i;
+                if (n0 + r < p.N1) Xout[(size_t)(n0 + r) * C + c] = (acc[mt][0][i] + bb) + As[(size_t)r * lda + c];
+            }
+    }
+}
+
+// dynamic LDS: St[64][lda(S)] | Yt[64][lda(S)]  (the two G_l staging buffers alias Yt)
+__global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
+    extern __shared__ float sm[];
+    const int C = p.C, S = p.S, Q = p.Q, L = p.L;
+    const int lds = tr_lda(S), ldg = tr_lda(C);
+    float* St = sm; float* Yt = sm + 64 * lds;
+    float* Gb[2] = {Yt, Yt + 64 * ldg};
+    const int b = blockIdx.y, t0 = blockIdx.x * TR_TM;      // rows of the last-BL window
+    const int nbase = p.N1 - p.BL + t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NTS = S / 16, NTQ = Q / 16, NCG = C / 16;
+    // ---------- skip sum: K = L*C over the saved gates
+    const int npairs = (NTS + 1) / 2;
+    for (int pb = 0; pb < npairs; pb += 8) {                // pair batch (one batch when S <= 256)
+        const int np = pb + wave;
+        const bool active = np < npairs;
+        const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        for (int l = 0; l < L; ++l) {
+            float* G = Gb[l & 1];
+            const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
+            const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
+            for (int idx = tid; idx < TR_TM * (C / 2); idx += 512) {
+                const int r = idx / (C / 2), k = (idx - r * (C / 2)) * 2;
+                float2 g = make_float2(0.f, 0.f);
+                if (t0 + r < p.BL) {
+                    const float2 a = *(const float2*)(SG + (size_t)(nbase + r) * C + k);
+                    const float2 t = *(const float2*)(TH + (size_t)(nbase + r) * C + k);
+                    g = make_float2(a.x * t.x, a.y * t.y);
+                }
+                *(float2*)(G + (size_t)r * ldg + k) = g;
+            }
+            __syncthreads();
+            if (active) {
+                const int nts[2] = {nt0, nt1};
+                wave_gemm<4, 2>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = j ? nt1 : nt0;
+                if (j && nt1 == nt0) break;
+                const int c = 16 * nt + (lane & 15);
+                const float bs = p.bp[p.bias_s + c];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * mt + 4 * (lane >> 4) + i;
+                        const float v = acc[mt][j][i] + bs;
+                        if (t0 + r < p.BL) p.S0[((size_t)b * p.BL + t0 + r) * S + c] = v;
+                        St[(size_t)r * lds + c] = v > 0.f ? v : 0.f;
+                    }
+            }
+        }
+        __syncthreads();   // also protects the G buffers (alias of Yt) before the next batch / phase
+    }
+    // ---------- post 1x1 #1: y0 = W1 relu(s0) + b1
+    for (int pb = 0; pb < npairs; pb += 8) {
+        const int np = pb + wave;
+        if (np < npairs) {
+            const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            const int nts[2] = {nt0, nt1};
+            wave_gemm<4, 2>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = j ? nt1 : nt0;
+                if (j && nt1 == nt0) break;
+                const int c = 16 * nt + (lane & 15);
+                const float bb = p.bp[p.bias_p1 + c];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * mt + 4 * (lane >> 4) + i;
+                        const float v = acc[mt][j][i] + bb;
+                        if (t0 + r < p.BL) p.Y0[((size_t)b * p.BL + t0 + r) * S + c] = v;
+                        Yt[(size_t)r * lds + c] = v > 0.f ? v : 0.f;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    // ---------- post 1x1 #2: logits = W2 relu(y0) + b2
+    const int qpairs = (NTQ + 1) / 2;
+    for (int pb = 0; pb < qpairs; pb += 8) {
+        const int np = pb + wave;
+        if (np < qpairs) {
+            const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTQ) ? 2 * np + 1 : 2 * np;
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            const int nts[2] = {nt0, nt1};
+            wave_gemm<4, 2>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = j ? nt1 : nt0;
+                if (j && nt1 == nt0) break;
+                const int c = 16 * nt + (lane & 15);
+                const float bb = p.bp[p.bias_p2 + c];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * mt + 4 * (lane >> 4) + i;
+                        if (t0 + r < p.BL) p.logits[((size_t)b * p.BL + t0 + r) * Q + c] = acc[mt][j][i] + bb;
+                    }
+            }
+        }
+    }
+}
+
+// mean cross entropy + its gradient, one wave per row (reference qpnet_train.py:430,526-528)
+__global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t tgt_stride,
+                                            int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* lg = logits + (size_t)row * Q;
+    const int64_t b = row / BL, t = row - b * BL;
+    int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
+    float m = -INFINITY;
+    for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    float se = 0.f;
+    for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
+    for (int s = 32; s >= 1; s >>= 1) se += __shfl_xor(se, s);
+    const float lse = logf(se) + m;
+    const float inv = 1.0f / (float)rows;
+    if (dlogits) for (int q = lane; q < Q; q += 64) {
+        float pr = expf(lg[q] - lse);
+        dlogits[(size_t)row * Q + q] = (pr - (q == tg ? 1.0f : 0.0f)) * inv;
+    }
+    if (lane == 0) atomicAdd(loss, (double)(lse - lg[tg]) / (double)rows);
+}
+
+// ------------------------------------------------------------------ host launchers (called from train_host.hip)
+int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
+    const int C = p.C, S = p.S;
+    hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
+    const size_t lds_layer = (size_t)64 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
+    const size_t lds_post = (size_t)64 * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
+    if (lds_layer > 160 * 1024 || lds_post > 160 * 1024) {
+        qpn_set_error("training kernels: tiles do not fit the 160 KiB LDS for n_resch=%d n_skipch=%d (n_resch <= 128 supported)", C, S);
+        return QPN_EINVAL;
+    }
+    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
+    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
+    for (int l = 0; l < p.L; ++l) {
+        const int rows = p.N1 - p.layers[l].s_out;
+        hipLaunchKernelGGL(k_layer_fwd, dim3((rows + TR_TM - 1) / TR_TM, p.B), dim3(256), lds_layer, stream, p, l, l == p.L - 1 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_post_fwd, dim3((p.BL + TR_TM - 1) / TR_TM, p.B), dim3(512), lds_post, stream, p);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}
+
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream) {
+    const int64_t rows = (int64_t)B * BL;
+    QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
+    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}

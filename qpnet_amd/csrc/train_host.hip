@@ -1,0 +1,260 @@
+// train_host.hip -- host orchestration of the training step behind the C ABI:
+//   qpn_train_forward / qpn_train_backward  (QPNet.forward + autograd, reference qpnet.py:239-312)
+//   qpn_ce_loss                              (CrossEntropyLoss mean, reference qpnet_train.py:430,526-528)
+//   qpn_adam_step                            (torch.optim.Adam, reference qpnet_train.py:426-429,531)
+#include "train_common.h"
+#include "qpn_handle.h"
+#include <algorithm>
+#include <string.h>
+
+int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
+
+
+struct TrainState {
+    std::vector<int> h_wmap;                  // gather map of the fragment-ordered weights
+    std::vector<int> h_bstart, h_blist;       // CSR of the packed biases
+    std::vector<int> h_gsrc, h_gsrc2;
+    int* d_wmap; float* d_wp; int* d_bstart; int* d_blist; float* d_bp; int n_bias;
+    int* d_gsrc; int* d_gsrc2;
+    TrainParams tp;                           // template with block offsets filled in
+    TrainBwd bw;
+    // workspaces (grow only)
+    float* d_ws; size_t ws_cap;               // one arena, carved per call
+    int* d_tap; size_t tap_cap;
+    int* d_status; double* d_loss;
+    bool fwd_valid;
+};
+
+__global__ void k_gather_f(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
+}
+__global__ void k_bias_pack(const float* __restrict__ flat, const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float a = 0.f; for (int j = start[i]; j < start[i + 1]; ++j) a += flat[list[j]]; out[i] = a; }
+}
+
+// B[k][n] (K x N, both multiples of 16) -> fragment order; returns float4 offset
+template <class F>
+static int frag_pack(std::vector<int>& map, int K, int N, F src) {
+    const int NT = N / 16, off4 = (int)(map.size() / 4);
+    map.resize(map.size() + (size_t)K * N);
+    int* m = map.data() + (size_t)off4 * 4;
+    for (int ks4 = 0; ks4 < K / 16; ++ks4)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    int k = 16 * ks4 + 4 * e + (lane >> 4), n = 16 * nt + (lane & 15);
+                    m[(((size_t)ks4 * NT + nt) * 64 + lane) * 4 + e] = (int)src(k, n);
+                }
+    return off4;
+}
+
+static int train_init(qpn_handle* h) {
+    if (h->train) return QPN_OK;
+    const Geom& g = h->g;
+    const int C = g.C, S = g.S, Q = g.Q, A = g.A, L = g.L;
+    if (C % 16 || S % 16 || Q % 16) { qpn_set_error("training kernels need n_resch, n_skipch, n_quantize multiples of 16"); return QPN_EINVAL; }
+    TrainState* t = new TrainState();
+    memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
+    t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
+    t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
+    TrainParams& p = t->tp;
+    const int Ap = (A + 3) / 4 * 4;               // aux columns padded to the MFMA k-step
+    p.C = C; p.S = S; p.Q = Q; p.A = A; p.Ap = Ap; p.L = L; p.U = g.U;
+    p.Kt = 2 * C + Ap; p.Ktp = (p.Kt + 15) / 16 * 16; p.LC = L * C;
+    p.causal_w = g.causal_w; p.causal_b = g.causal_b; p.up_w = g.up_w; p.up_b = g.up_b;
+    std::vector<int>& map = t->h_wmap;
+    std::vector<std::vector<int>> biases;      // packed bias i <- list of flat indices
+    auto add_bias = [&](int n, auto f) { int off = (int)biases.size(); for (int i = 0; i < n; ++i) biases.push_back(f(i)); return off; };
+    const int Ktp = p.Ktp;
+    int n_adapt = 0;
+    for (int l = 0; l < L; ++l) {
+        const LayerGeom y = g.layers[l];
+        TrLayer& ly = p.layers[l];
+        ly.adaptive = y.adaptive; ly.dilation = y.dilation;
+        ly.tap_off = y.adaptive ? n_adapt++ : -1;     // scaled by B*N1 per call
+        auto w1src = [&](int k, int n) -> int64_t {   // B[k][n] of z = [x_cur | x_past | aux] . W1
+            const int half = n / C, r = n % C;
+            if (k < C) return y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
+            if (k < 2 * C) { const int kk = k - C; return y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2; }
+            if (k < 2 * C + A) return (half ? y.auxT : y.auxS) + (int64_t)r * A + (k - 2 * C);
+            return -1;
+        };
+        ly.w1_f4 = frag_pack(map, Ktp, 2 * C, w1src);
+        ly.w1t_f4 = frag_pack(map, 2 * C, Ktp, [&](int k, int n) { return w1src(n, k); });
+        ly.wr_f4 = frag_pack(map, C, C, [&](int k, int n) { return y.res + (int64_t)n * C + k; });
+        ly.wrt_f4 = frag_pack(map, C, C, [&](int k, int n) { return y.res + (int64_t)k * C + n; });
+        ly.bias1 = add_bias(2 * C, [&](int n) {
+            const int half = n / C, r = n % C;
+            std::vector<int> v{(int)((half ? y.bT : y.bS) + r), (int)((half ? y.auxTb : y.auxSb) + r)};
+            if (y.adaptive) v.push_back((int)((half ? y.bTP : y.bSP) + r));
+            return v; });
+        ly.biasr = add_bias(C, [&](int n) { return std::vector<int>{(int)(y.resb + n)}; });
+    }
+    p.ws_f4 = frag_pack(map, L * C, S, [&](int k, int n) { return g.layers[k / C].skip + (int64_t)n * C + (k % C); });
+    p.wst_f4 = frag_pack(map, S, L * C, [&](int k, int n) { return g.layers[n / C].skip + (int64_t)k * C + (n % C); });
+    p.p1_f4 = frag_pack(map, S, S, [&](int k, int n) { return g.post1_w + (int64_t)n * S + k; });
+    p.p1t_f4 = frag_pack(map, S, S, [&](int k, int n) { return g.post1_w + (int64_t)k * S + n; });
+    p.p2_f4 = frag_pack(map, S, Q, [&](int k, int n) { return g.post2_w + (int64_t)n * S + k; });
+    p.p2t_f4 = frag_pack(map, Q, S, [&](int k, int n) { return g.post2_w + (int64_t)k * S + n; });
+    p.bias_s = add_bias(S, [&](int n) { std::vector<int> v; for (int l = 0; l < L; ++l) v.push_back((int)(g.layers[l].skipb + n)); return v; });
+    p.bias_p1 = add_bias(S, [&](int n) { return std::vector<int>{(int)(g.post1_b + n)}; });
+    p.bias_p2 = add_bias(Q, [&](int n) { return std::vector<int>{(int)(g.post2_b + n)}; });
+    t->n_bias = (int)biases.size();
+    t->h_bstart.assign(1, 0);
+    for (auto& v : biases) { for (int x : v) t->h_blist.push_back(x); t->h_bstart.push_back((int)t->h_blist.size()); }
+
+    // ---- weight-grad staging space ("slab") and the flat-grad gather map
+    TrainBwd& bw = t->bw;
+    int go = 0;
+    auto gtake = [&](int n) { int r = go; go += (n + 63) & ~63; return r; };
+    std::vector<int>& gs = t->h_gsrc; std::vector<int>& gs2 = t->h_gsrc2;
+    gs.assign(g.n_params, -1); gs2.assign(g.n_params, -1);
+    for (int l = 0; l < L; ++l) {
+        const LayerGeom y = g.layers[l];
+        bw.g_w1[l] = gtake(2 * C * Ktp);   // dW1[n][k] (n = z row, k = A-tile column), row-major [2C][Ktp]
+        bw.g_b1[l] = gtake(2 * C);
+        bw.g_wr[l] = gtake(C * C);         // dWr[o][c]
+        bw.g_br[l] = gtake(C);
+        bw.g_ws[l] = gtake(S * C);         // dWs_l[s][c]
+        for (int n = 0; n < 2 * C; ++n) {
+            const int half = n / C, r = n % C;
+            for (int k = 0; k < 2 * C + A; ++k) {
+                int64_t dst;
+                if (k < C) dst = y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
+                else if (k < 2 * C) { const int kk = k - C; dst = y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2; }
+                else dst = (half ? y.auxT : y.auxS) + (int64_t)r * A + (k - 2 * C);
+                gs[dst] = bw.g_w1[l] + n * Ktp + k;
+            }
+            gs[(half ? y.bT : y.bS) + r] = bw.g_b1[l] + n;
+            gs[(half ? y.auxTb : y.auxSb) + r] = bw.g_b1[l] + n;
+            if (y.adaptive) gs[(half ? y.bTP : y.bSP) + r] = bw.g_b1[l] + n;
+        }
+        for (int o = 0; o < C; ++o) { for (int c = 0; c < C; ++c) gs[y.res + (int64_t)o * C + c] = bw.g_wr[l] + o * C + c; gs[y.resb + o] = bw.g_br[l] + o; }
+        for (int s = 0; s < S; ++s) for (int c = 0; c < C; ++c) gs[y.skip + (int64_t)s * C + c] = bw.g_ws[l] + s * C + c;
+    }
+    bw.g_bs = gtake(S);
+    for (int l = 0; l < L; ++l) for (int s = 0; s < S; ++s) gs[g.layers[l].skipb + s] = bw.g_bs + s;
+    bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
+    for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
+    for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
+    bw.gstage = go; bw.nch = 32; bw.n_params = g.n_params;
+    // causal table / bias and the upsampling kernel are written by dedicated kernels (gs stays -1)
+
+    const size_t nmap = map.size();
+    QPN_HIP(hipMalloc(&t->d_wmap, nmap * sizeof(int)));
+    QPN_HIP(hipMalloc(&t->d_wp, nmap * sizeof(float)));
+    QPN_HIP(hipMalloc(&t->d_bstart, t->h_bstart.size() * sizeof(int)));
+    QPN_HIP(hipMalloc(&t->d_blist, t->h_blist.size() * sizeof(int)));
+    QPN_HIP(hipMalloc(&t->d_bp, (size_t)t->n_bias * sizeof(float)));
+    QPN_HIP(hipMalloc(&t->d_gsrc, (size_t)g.n_params * sizeof(int)));
+    QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
+    QPN_HIP(hipMalloc(&t->d_status, 64));
+    QPN_HIP(hipMalloc(&t->d_loss, 64));
+    QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
+    QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
+    QPN_HIP(hipMemcpy(t->d_gsrc, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
+    QPN_HIP(hipMemcpy(t->d_gsrc2, gs2.data(), gs2.size() * sizeof(int), hipMemcpyHostToDevice));
+    h->train = t;
+    return QPN_OK;
+}
+
+void qpn_train_destroy(TrainState* t) {
+    if (!t) return;
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    delete t;
+}
+
+static int need_dev(qpn_handle* h) {
+    if (!h) { qpn_set_error("null handle"); return QPN_EINVAL; }
+    if (h->device < 0) { qpn_set_error("no HIP device: libqpnet_hip has no CPU fallback"); return QPN_ENODEV; }
+    return QPN_OK;
+}
+
+extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                                 const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    rc = train_init(h); if (rc) return rc;
+    TrainState* t = h->train;
+    hipStream_t stream = (hipStream_t)stream_;
+    const Geom& g = h->g;
+    if (!d_flat || !d_x || !d_h || !d_dfac || !d_logits || B < 1 || BL < 1 || maxd < 1) { qpn_set_error("bad train_forward arguments"); return QPN_EINVAL; }
+    const int64_t N0 = (int64_t)g.recA * maxd + g.recF + 1 + BL;           // qpnet.py:254-262
+    if (N0 > T || N0 - 1 > Td || N0 - 1 > (g.U > 0 ? F * g.U : F)) {
+        qpn_set_error("chunk too short: need receptive field (%lld) + batch_length (%d) = %lld samples, have x:%lld d:%lld h_up:%lld",
+                      (long long)(N0 - BL), BL, (long long)N0, (long long)T, (long long)Td, (long long)(g.U > 0 ? F * g.U : F));
+        return QPN_EINVAL;
+    }
+    TrainParams& p = t->tp;
+    p.B = B; p.T = (int)T; p.F = (int)F; p.Td = (int)Td; p.BL = BL; p.N0 = (int)N0; p.N1 = (int)N0 - 1; p.maxd = maxd;
+    const int C = g.C, S = g.S, L = g.L, N1 = p.N1;
+    int s = 0, nA = 0;
+    for (int l = 0; l < L; ++l) {
+        TrLayer& ly = p.layers[l];
+        ly.s_in = s; s += ly.adaptive ? ly.dilation * maxd : ly.dilation; ly.s_out = s;
+        if (ly.adaptive) ly.tap_off = (nA++) * B * N1;
+    }
+    // ---- carve the arena
+    const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
+    TrainBwd& bw = t->bw;
+    const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
+    size_t need = nX + 2 * nG + nH + 2 * nS + 4 * nDX + nDZ + 2 * nS + nDGS + nH + nSlab + 1024;
+    if (need > t->ws_cap) {
+        if (t->d_ws) (void)hipFree(t->d_ws);
+        t->d_ws = nullptr; t->ws_cap = 0;
+        hipError_t e = hipMalloc(&t->d_ws, need * sizeof(float));
+        if (e != hipSuccess) { qpn_set_error("hipMalloc(%zu MiB) for the training workspace failed", need * 4 >> 20); return QPN_ENOMEM; }
+        t->ws_cap = need;
+    }
+    const size_t ntap = (size_t)std::max(nA, 1) * B * N1;
+    if (ntap > t->tap_cap) {
+        if (t->d_tap) (void)hipFree(t->d_tap);
+        t->d_tap = nullptr; t->tap_cap = 0;
+        QPN_HIP(hipMalloc(&t->d_tap, ntap * sizeof(int)));
+        t->tap_cap = ntap;
+    }
+    float* w = t->d_ws;
+    auto carve = [&](size_t n) { float* r = w; w += (n + 63) & ~(size_t)63; return r; };
+    p.X = carve(nX); p.SG = carve(nG); p.TH = carve(nG); p.HUP = carve(nH); p.S0 = carve(nS); p.Y0 = carve(nS);
+    bw.DXA[0] = carve(nDX); bw.DXA[1] = carve(nDX); bw.DXB[0] = carve(nDX); bw.DXB[1] = carve(nDX);
+    bw.DZ = carve(nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
+    p.TAP = t->d_tap; p.status = t->d_status;
+    p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
+    // ---- refresh the fragment-ordered weights / packed biases from the current parameters
+    const size_t nmap = t->h_wmap.size();
+    hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
+    hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
+    QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
+    rc = qpn_launch_fwd(p, stream); if (rc) return rc;
+    t->fwd_valid = true;
+    return QPN_OK;
+}
+
+extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train) { qpn_set_error("no training call yet"); return QPN_ESTATE; }
+    QPN_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    int st = 0;
+    QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
+    return QPN_OK;
+}
+
+extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,
+                           float* d_dlogits, double* h_loss, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    rc = train_init(h); if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_logits || !d_targets || B < 1 || BL < 1 || tgt_stride < BL) { qpn_set_error("bad ce_loss arguments"); return QPN_EINVAL; }
+    rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, stream); if (rc) return rc;
+    if (h_loss) {
+        QPN_HIP(hipMemcpyAsync(h_loss, h->train->d_loss, sizeof(double), hipMemcpyDeviceToHost, stream));
+        QPN_HIP(hipStreamSynchronize(stream));
+    }
+    return QPN_OK;
+}
