@@ -12,7 +12,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TR_TM 64           // time rows per workgroup tile
-#define TR_MAXL QPN_MAX_LAYERS
+#define TR_MAXL 32          // layers supported by the training kernels (kernel-argument budget)
 
 // leading dimension for an LDS A-tile read "row = lane&15, k = lane>>4" with ds_read_b32:
 // ld == 2 (mod 32) makes the 32-lane groups conflict free (MI355X_MICROARCH.md §LDS).

@@ -10,6 +10,7 @@
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream);
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, hipStream_t stream);
 
 
 struct TrainState {
@@ -56,6 +57,7 @@ static int train_init(qpn_handle* h) {
     if (h->train) return QPN_OK;
     const Geom& g = h->g;
     const int C = g.C, S = g.S, Q = g.Q, A = g.A, L = g.L;
+    if (L > TR_MAXL) { qpn_set_error("training kernels support up to %d residual layers", TR_MAXL); return QPN_EINVAL; }
     if (C % 16 || S % 16 || Q % 16) { qpn_set_error("training kernels need n_resch, n_skipch, n_quantize multiples of 16"); return QPN_EINVAL; }
     TrainState* t = new TrainState();
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
@@ -257,4 +259,21 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
         QPN_HIP(hipStreamSynchronize(stream));
     }
     return QPN_OK;
+}
+
+extern "C" int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train || !h->train->fwd_valid) { qpn_set_error("qpn_train_backward needs a preceding qpn_train_forward"); return QPN_ESTATE; }
+    if (!d_dlogits || !d_flatgrad) { qpn_set_error("bad train_backward arguments"); return QPN_EINVAL; }
+    TrainState* t = h->train;
+    TrainBwd& bw = t->bw;
+    bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
+    return qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
+}
+
+extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
+                             int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
+    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream_);
 }

@@ -34,3 +34,79 @@ def test_forward_logits_vs_reference(case, cuda, golden_dir):
     lse = np.log(np.exp(lg[0].astype(np.float64)).sum(1))
     loss = (lse - lg[0][np.arange(BL), t[0, -BL:]]).mean()
     assert abs(loss - float(g[name + "_loss"])) < 1e-4          # north_star tolerance
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_autograd_grads_vs_reference(case, cuda, golden_dir):
+    """loss.backward() through the HIP backward == the reference's autograd grads (fixture)
+    and == the numpy oracle's hand-derived grads, per parameter tensor."""
+    import torch
+    from oracle import train_oracle as TO
+    name, cfg, wseed, dseed, bl, nsteps = case
+    g = np.load(golden_dir + "/train.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda).train()
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    BL = int(b[0])
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    assert abs(loss.item() - g[name + "_losses"][0]) < 1e-4
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    # oracle grads on the same inputs
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    _, dl = TO.ce_loss(lg, t[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        a, r = grad[o:o + n], og[o:o + n]
+        assert np.abs(a - r).max() <= 2e-5 * scale + 1e-4 * np.abs(r).max(), "grad mismatch in " + k
+    if name + "_grad0" in g:
+        ref = g[name + "_grad0"]; mine = grad
+    else:
+        ref = g[name + "_grad0_sample"]; mine = grad[::97]
+    assert np.abs(mine - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_fused_train_steps_vs_reference(case, cuda, golden_dir):
+    """forward + CE + backward + Adam entirely behind the C ABI: loss per step within 1e-4 of the
+    reference run with the same seed (north_star), final weights match."""
+    import torch
+    from qpnet_amd.train import FusedTrainer
+    name, cfg, wseed, dseed, bl, nsteps = case
+    g = np.load(golden_dir + "/train.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        losses.append(tr.step(xt, ht, tt, dt, bt))
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    w = m.flat_parameters().cpu().numpy()
+    np.testing.assert_allclose(w[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
+def test_torch_adam_on_views_matches(cuda, golden_dir):
+    """the drop-in path the reference trainer uses: torch.optim.Adam over model.parameters()
+    (which are views of the flat buffer) + our autograd.Function."""
+    import torch
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES[0]
+    g = np.load(golden_dir + "/train.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=0.0)
+    crit = torch.nn.CrossEntropyLoss()
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        BL = int(b[0])
+        loss = crit(m(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
