@@ -132,21 +132,140 @@ def run_decode(args, rank, local, world):
     return out
 
 
+PG_NAMES = ["prep+pack", "k_layer_fwd", "k_post_fwd", "k_ce", "k_post_bwd", "k_wgrad", "k_layer_bwd", "grad_tail", "k_adam"]
+
+
+def train_flops(cfg, N1, BL, starts_out):
+    """Algorithmic FLOPs (2 x MACs, padding excluded) of one training step per kernel group
+    (per-row MACs x exact per-layer row counts)."""
+    C, S, Q, A = cfg.n_resch, cfg.n_skipch, cfg.n_quantize, cfg.n_aux
+    L = len(starts_out)
+    Kt = 2 * C + A
+    rows = [N1 - s for s in starts_out]
+    lf = sum(r * (Kt * 2 * C + (C * C if i < L - 1 else 0)) for i, r in enumerate(rows))
+    pf = BL * (L * C * S + S * S + S * Q)
+    pb = BL * (Q * S + S * S + S * L * C)
+    wg = BL * (Q * S + S * S + L * S * C) + sum(r * (2 * C * Kt + (C * C if i < L - 1 else 0)) for i, r in enumerate(rows))
+    lb = sum(r * ((C * C if i < L - 1 else 0) + 2 * C * Kt) for i, r in enumerate(rows))
+    g = [0.0] * len(PG_NAMES)
+    g[1], g[2], g[4], g[5], g[6] = 2.0 * lf, 2.0 * pf, 2.0 * pb, 2.0 * wg, 2.0 * lb
+    return g
+
+
+def cpu_baseline_train(cfg, flat, batch):
+    """numpy float32 port of the training step (oracle/train_oracle.py, pinned to the reference's
+    autograd) timed on this box's host cores: ONE full-size step (bounded sample)."""
+    from oracle import train_oracle as TO
+    x, h, t, d, b = batch
+    w = flat.copy()
+    opt = TO.Adam(w.size)
+    t0 = time.time()
+    TO.train_step(cfg, w, opt, x, h, t, d, b)
+    dt = time.time() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "one full-size step (forward+CE+backward+Adam, chunk of %d samples) of the numpy float32 oracle" % x.shape[1]}
+
+
+def run_train(args, rank, local, world):
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from qpnet_amd import synth, harness, _lib
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.qpnet import QPNet
+    from qpnet_amd.train import FusedTrainer
+    dev = torch.device("cuda", local)
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = QPNet(**cfg.kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
+    m = m.to(dev).train()
+    tr = FusedTrainer(m, lr=1e-4, world_size=world)
+    # utterance-sharded synthetic chunks: rank r consumes chunks r, r+world, ... (SURVEY §8e)
+    nchunks = 4
+    host_batches = [synth.train_inputs(cfg, 20000, 5000 + 17 * (rank + world * i), 30000, f0_lo=55.0, f0_hi=300.0) for i in range(nchunks)]
+    batches = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in hb] for hb in host_batches]
+
+    def step(i, want_loss=False):
+        x, h, t, d, b = batches[i % nchunks]
+        return tr.step(x, h, t, d, b, want_loss=want_loss)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    # per-kernel-group device time of one more (untimed) step -> roofline of the dominant group
+    L_, hd = m._native(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ms = (C.c_float * len(PG_NAMES))()
+    nprof = 3
+    _lib.check(L_.qpn_train_profile_begin(hd, stream))
+    for i in range(nprof):
+        step(i)
+    _lib.check(L_.qpn_train_profile_end(hd, ms, len(PG_NAMES), stream))
+    ms = [v / nprof for v in ms]
+    x0, h0, t0_, d0, b0 = host_batches[0]
+    BL = int(b0[0]); maxd = int(np.ceil(d0).max())
+    N1 = cfg.receptive_field(maxd) + BL - 1
+    starts, s_ = [], 0
+    for dil in cfg.dilationsF:
+        s_ += dil; starts.append(s_)
+    for dil in cfg.dilationsA:
+        s_ += dil * maxd; starts.append(s_)
+    fl = train_flops(cfg, N1, BL, starts)
+    dom = int(np.argmax(ms))
+    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
+    total_flops = sum(fl)
+    value = args.steps * world / dt
+    out = {
+        "metric": "train steps/sec (batch-1 chunk-steps of RF+20000 samples, aggregate over GPUs)",
+        "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "config[1]: paper-size SI-QPNet (C=64,S=256,4F+4A) training step, forward+CE+backward+Adam on one chunk "
+                               "of %d samples (RF %d + batch_length %d), batch 1 per GPU" % (x0.shape[1], N1 + 1 - BL, BL),
+                   "global_batch": world, "parallelism": "dp%d (utterance-sharded chunks, one flat-gradient all-reduce per step)" % world},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": PG_NAMES[dom],
+                     "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
+                     "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
+                     "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
+                     "note": "achieved = algorithmic FLOPs of the dominant kernel group (all its launches in one step) / its summed "
+                             "device time from HIP events on the launch stream; step_tflops = whole step"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_train(cfg, flat, host_batches[0])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", default="decode", choices=["decode", "train"])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", default="train", choices=["decode", "train"])
     ap.add_argument("--batch", type=int, default=20, help="utterances per GPU (reference decode_batch_size = 20, runQP.py:66)")
     ap.add_argument("--frames", type=int, default=2005, help="frames per utterance (2005 -> 10 s @22.05 kHz)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.mode == "train" else 3
+    if args.warmup is None:
+        args.warmup = 5 if args.mode == "train" else 1
     rank, local, world = dist_setup(args.gpus)
     if args.mode == "decode":
         out = run_decode(args, rank, local, world)
     else:
-        raise SystemExit("train mode: not built yet")
+        out = run_train(args, rank, local, world)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -132,6 +132,21 @@ int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, 
 int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
                   int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
+/* Per-kernel-group device timings of the training calls issued between begin and end (HIP events on
+ * `stream`; used by bench.py for the roofline).  h_ms[QPN_PG_*] receives milliseconds. */
+#define QPN_PG_PREP 0
+#define QPN_PG_LAYER_FWD 1
+#define QPN_PG_POST_FWD 2
+#define QPN_PG_CE 3
+#define QPN_PG_POST_BWD 4
+#define QPN_PG_WGRAD 5
+#define QPN_PG_LAYER_BWD 6
+#define QPN_PG_GRAD_TAIL 7
+#define QPN_PG_ADAM 8
+#define QPN_PG_COUNT 9
+int qpn_train_profile_begin(qpn_handle* h, void* stream);
+int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);
+
 /* _dilated_index (src/nets/qpnet.py:592-604, tensor path) and _generate_dilated_index
  * (src/nets/qpnet.py:613-618): d (B x L) float32 -> int64 (B x L), NOT replicated over
  * channels (the reference's .repeat over n_ch is redundant). */

@@ -39,6 +39,8 @@ SYMBOLS = [
     ("qpn_train_status", _i, [_vp, _vp]),
     ("qpn_ce_loss", _i, [_vp, _vp, _vp, _i64, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("qpn_adam_step", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    ("qpn_train_profile_begin", _i, [_vp, _vp]),
+    ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),
     ("qpn_dilated_index_train", _i, [_vp, _i, _i64, _i, _vp, _vp]),
     ("qpn_dilated_index_gen_f32", _i, [_vp, _i64, _i, _vp, _vp]),
     ("qpn_dilated_index_gen_f64", _i, [_vp, _i64, _i, _vp, _vp]),

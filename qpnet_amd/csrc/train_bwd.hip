@@ -391,6 +391,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     hipLaunchKernelGGL(k_post_bwd, dim3((BL + TR_TM - 1) / TR_TM, B), dim3(512), lds_post, stream, p, bw);
+    qpn_prof_mark(PG_POST_BWD, stream);
     WgDesc w; memset(&w, 0, sizeof(w));
     w.slab = bw.slab; w.gstage = bw.gstage; w.nb = B; w.C = C; w.Ap = p.Ap;
     // post 2: dW2[q][s] = sum dlogits[t][q] relu(Y0)[t][s]
@@ -406,6 +407,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         w.rowsB = N1; w.row0B = N1 - BL; w.R = BL;
         w.goff = bw.g_ws[l]; w.ldc = C; w.gbias = l == 0 ? bw.g_bs : -1; launch_wgrad(w, bw.nch, stream);
     }
+    qpn_prof_mark(PG_WGRAD, stream);
     int pp = 0;
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
@@ -415,6 +417,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         QPN_HIP(hipMemsetAsync(bw.DXB[pp ^ 1], 0, nDX * sizeof(float), stream));
         const int rows = N1 - ly.s_out;
         hipLaunchKernelGGL(k_layer_bwd, dim3((rows + TR_TM - 1) / TR_TM, B), dim3(256), lds_layer, stream, p, bw, l, last, pp);
+        qpn_prof_mark(PG_LAYER_BWD, stream);
         // dW1 = dZ^T [x_cur | x_past | aux]
         w.A = bw.DZ; w.A2 = nullptr; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1; w.row0A = ly.s_out;
         w.bmode = 3; w.B1 = p.X + (size_t)l * B * N1 * C; w.B2 = nullptr; w.hup = p.HUP; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap;
@@ -425,6 +428,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         w.bmode = 2; w.B1 = p.SG + (size_t)l * B * N1 * C; w.B2 = p.TH + (size_t)l * B * N1 * C; w.ldb = C; w.N = C; w.Nvalid = C;
         w.rowsB = N1; w.row0B = ly.s_out; w.R = last ? 0 : rows; w.tap = nullptr;
         w.goff = bw.g_wr[l]; w.ldc = C; w.gbias = bw.g_br[l]; launch_wgrad(w, bw.nch, stream);
+        qpn_prof_mark(PG_WGRAD, stream);
         pp ^= 1;
     }
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
@@ -440,6 +444,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, b2, rpw);
         if (p.U > 0) hipLaunchKernelGGL(k_up_bwd, dim3(nwg), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpw);
     }
+    qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }
@@ -447,6 +452,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, hipStream_t stream) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
+    qpn_prof_mark(PG_ADAM, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }

@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     const int C = p.C, S = p.S;
     hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
+    qpn_prof_mark(PG_PREP, stream);
     const size_t lds_layer = (size_t)64 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
     const size_t lds_post = (size_t)64 * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
     if (lds_layer > 160 * 1024 || lds_post > 160 * 1024) {
@@ -293,7 +294,9 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
         const int rows = p.N1 - p.layers[l].s_out;
         hipLaunchKernelGGL(k_layer_fwd, dim3((rows + TR_TM - 1) / TR_TM, p.B), dim3(256), lds_layer, stream, p, l, l == p.L - 1 ? 1 : 0);
     }
+    qpn_prof_mark(PG_LAYER_FWD, stream);
     hipLaunchKernelGGL(k_post_fwd, dim3((p.BL + TR_TM - 1) / TR_TM, p.B), dim3(512), lds_post, stream, p);
+    qpn_prof_mark(PG_POST_FWD, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }
@@ -302,6 +305,7 @@ int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, i
     const int64_t rows = (int64_t)B * BL;
     QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
     hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss);
+    qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }

@@ -28,6 +28,35 @@ struct TrainState {
     bool fwd_valid;
 };
 
+// ---- per-group timing
+struct Prof { bool on = false; std::vector<hipEvent_t> ev; std::vector<int> grp; size_t used = 0; };
+static thread_local Prof g_prof;
+void qpn_prof_mark(int group, hipStream_t stream) {
+    Prof& P = g_prof;
+    if (!P.on) return;
+    if (P.used == P.ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; P.ev.push_back(e); P.grp.push_back(0); }
+    P.grp[P.used] = group;
+    (void)hipEventRecord(P.ev[P.used++], stream);
+}
+extern "C" int qpn_train_profile_begin(qpn_handle* h, void* stream) {
+    (void)h; g_prof.on = true; g_prof.used = 0;
+    qpn_prof_mark(-1, (hipStream_t)stream);
+    return QPN_OK;
+}
+extern "C" int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream) {
+    (void)h;
+    Prof& P = g_prof;
+    QPN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < n; ++i) h_ms[i] = 0.f;
+    for (size_t i = 1; i < P.used; ++i) {
+        float ms = 0.f;
+        QPN_HIP(hipEventElapsedTime(&ms, P.ev[i - 1], P.ev[i]));
+        if (P.grp[i] >= 0 && P.grp[i] < n) h_ms[P.grp[i]] += ms;
+    }
+    P.on = false;
+    return QPN_OK;
+}
+
 __global__ void k_gather_f(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
@@ -232,6 +261,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
     hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
     QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
+    qpn_prof_mark(PG_PREP, stream);
     rc = qpn_launch_fwd(p, stream); if (rc) return rc;
     t->fwd_valid = true;
     return QPN_OK;
