@@ -6,8 +6,8 @@
 //                  x_cur part (+ residual) is stored at its own row; the x_past part is the backward of
 //                  the pitch-dependent gather = scatter-add to row tap[n] (float atomics only for the
 //                  adaptive blocks; fixed blocks have a unique writer per row)
-//   k_wgrad      : every weight gradient is a time-contraction dW[m][n] = sum_t A[t][m] B[t][n]; split over
-//                  `nch` time chunks into partial slabs (deterministic), bias grads = column sums of A
+//   k_wgrad2     : every weight gradient is a time-contraction dW[m][n] = sum_t A[t][m] B[t][n]; one launch per
+//                  weight family over (time chunk, layer), partial slabs (deterministic), bias grads = colsum(A)
 //   k_causal_bwd : the one-hot causal conv's weight grad is a histogram over sample classes -> LDS table
 //   k_up_bwd     : gradient of the (1,1,1,U) upsampling kernel and its bias
 //   k_reduce_grad: slabs -> flat gradient in state_dict order;  k_adam: torch.optim.Adam update.
@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TR_TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)b * p.N1;
-    const float* DAin = bw.DXA[pp] + rb * C; const float* DBin = bw.DXB[pp] + rb * C;
-    float* DAout = bw.DXA[pp ^ 1] + rb * C; float* DBout = bw.DXB[pp ^ 1] + rb * C;
+    (void)pp;
+    const size_t nDX = (size_t)p.B * p.N1 * C;     // grads wrt X[j] live at DXA/DXB[0] + j*nDX
+    const float* DAin = bw.DXA[0] + (size_t)(l + 1) * nDX + rb * C; const float* DBin = bw.DXB[0] + (size_t)(l + 1) * nDX + rb * C;
+    float* DAout = bw.DXA[0] + (size_t)l * nDX + rb * C; float* DBout = bw.DXB[0] + (size_t)l * nDX + rb * C;
     const int NCG = C / 16;
     // ---- dXout tile
     for (int idx = tid; idx < TR_TM * (C / 2); idx += 256) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
     const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
-    float* DZg = bw.DZ + rb * 2 * C;
+    float* DZg = bw.DZ + ((size_t)l * p.B * p.N1 + rb) * 2 * C;
     const int win0 = p.N1 - p.BL;
     for (int nt = wave; nt < NCG; nt += 4) {
         f32x4 acc[4][1];
@@ -207,85 +209,137 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     }
 }
 
-// ------------------------------------------------------------------------------------------ weight gradients
-struct WgDesc {
-    // A operand: A[row][m] (+ A2), M columns
-    const float* A; const float* A2; int lda, M;
-    int rowsA, row0A;            // array rows per batch item / first row of the window
-    // B operand
-    int bmode;                   // 0 plain, 1 relu, 2 product B1*B2, 3 [X[n] | X[tap[n]] | HUP[n] | 0]
-    const float* B1; const float* B2; int ldb, N, Nvalid;
-    int rowsB, row0B;
-    const int* tap; int tap_rows; int dil; int C, Ap; const float* hup;
-    int R, nb;                   // window rows per batch item, batch items
-    float* slab; int gstage, goff, ldc, gbias;   // gbias < 0: no column sums
+// ------------------------------------------------------------------------------------------ weight gradients, v2
+// One launch covers every layer (blockIdx.y) and every time chunk (blockIdx.x).  A workgroup (4 waves)
+// computes the WHOLE output block dW[M][N] of its layer for its chunk of rows: wave w owns m-tiles
+// {w, w+4, ...} x all n-tiles, operands staged once per 32 rows with 16-byte loads (no re-reads across
+// output tiles), partial result written to its slab.  dW = A^T B with
+//   A[row][m]  : plain array, or the sum of two arrays (grad wrt a layer output = own-row + scattered part)
+//   B[row][n]  : plain | relu(array) | product of two arrays (gate = sigma*tanh) | [x_cur | x_past | aux | 0]
+struct Wg2 {
+    const float* A; const float* A2; size_t A_lstride; int lda, M;        // per-layer stride (floats)
+    int rowsA;                                                              // rows per batch item in A's array
+    int bmode; const float* B1; const float* B2; size_t B_lstride; int ldb, N, Nvalid;
+    int rowsB;
+    const float* hup; const int* tap; int C, Ap;
+    int nb, nlayers;
+    float* slab; int gstage;
+    int row0A[TR_MAXL], row0B[TR_MAXL], R[TR_MAXL];                         // window per layer
+    int goff[TR_MAXL], gbias[TR_MAXL], tap_off[TR_MAXL], dil[TR_MAXL];
+    int ldc, ncol_groups;                                                   // post: N split into column groups (blockIdx.z)
 };
 
-__global__ __launch_bounds__(256) void k_wgrad(WgDesc w, int nch) {
-    __shared__ float At[64 * 80];
-    __shared__ float Bt[64 * 80];
-    const int ldt = 80;
-    const int ntn = (w.N + 63) / 64;
-    const int m0 = (blockIdx.x / ntn) * 64, nn0 = (blockIdx.x % ntn) * 64;
-    const int ch = blockIdx.y;
+template <int MPW, int NTMAX>
+__global__ __launch_bounds__(256) void k_wgrad2(Wg2 w, int nch) {
+    extern __shared__ float sm[];
+    constexpr int RS = 32;
+    const int y = blockIdx.y, ch = blockIdx.x, zg = blockIdx.z;
+    const int Mp = (w.M + 15) & ~15, Ng = w.N / w.ncol_groups, Np = (Ng + 15) & ~15;
+    const int ldA = tr_ldt(Mp), ldB = tr_ldt(Np);
+    float* As = sm; float* Bs = sm + RS * ldA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t total = (int64_t)w.R * w.nb;
-    const int64_t per = (total + nch - 1) / nch;
+    const int MT = Mp / 16, NT = Np / 16;
+    const int ncol0 = zg * Ng;
+    const int64_t total = (int64_t)w.R[y] * w.nb;
+    const int64_t per = ((total + nch - 1) / nch + RS - 1) / RS * RS;
     const int64_t r_begin = per * ch, r_end = r_begin + per < total ? r_begin + per : total;
-    f32x4 acc[4];
+    const float* A = w.A + (size_t)y * w.A_lstride; const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
+    const float* B1 = w.B1 + (size_t)y * w.B_lstride; const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
+    const int* tap = (w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
+    const int Rl = w.R[y];
+    f32x4 acc[MPW][NTMAX];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+    for (int a = 0; a < MPW; ++a)
+#pragma unroll
+        for (int b = 0; b < NTMAX; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
     float csum = 0.f;
-    for (int64_t rs = r_begin; rs < r_end; rs += 64) {
-        // stage 64 rows x 64 columns of A and B
-        for (int idx = tid; idx < 64 * 64; idx += 256) {
-            const int r = idx >> 6, c = idx & 63;
+    const int A4 = Mp / 4, B4 = Np / 4;
+    for (int64_t rs = r_begin; rs < r_end; rs += RS) {
+        for (int idx = tid; idx < RS * A4; idx += 256) {
+            const int r = idx / A4, c = (idx - r * A4) * 4;
             const int64_t rr = rs + r;
-            float a = 0.f, bv = 0.f;
-            if (rr < r_end) {
-                const int b = (int)(rr / w.R), i = (int)(rr - (int64_t)b * w.R);
-                if (m0 + c < w.M) {
-                    const size_t o = ((size_t)b * w.rowsA + w.row0A + i) * w.lda + m0 + c;
-                    a = w.A[o]; if (w.A2) a += w.A2[o];
-                }
-                const int n = nn0 + c;
-                if (n < w.Nvalid) {
-                    const size_t row = (size_t)b * w.rowsB + w.row0B + i;
-                    if (w.bmode == 0) bv = w.B1[row * w.ldb + n];
-                    else if (w.bmode == 1) { bv = w.B1[row * w.ldb + n]; bv = bv > 0.f ? bv : 0.f; }
-                    else if (w.bmode == 2) bv = w.B1[row * w.ldb + n] * w.B2[row * w.ldb + n];
-                    else {
-                        const int nloc = w.row0B + i;
-                        if (n < w.C) bv = w.B1[row * w.C + n];
-                        else if (n < 2 * w.C) {
-                            const int tp = w.tap ? w.tap[(size_t)b * w.tap_rows + nloc] : nloc - w.dil;
-                            bv = w.B1[((size_t)b * w.rowsB + tp) * w.C + (n - w.C)];
-                        } else bv = w.hup[row * w.Ap + (n - 2 * w.C)];
-                    }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rr < r_end && c < w.M) {
+                const int b = (int)(rr / Rl), i = (int)(rr - (int64_t)b * Rl);
+                const size_t o = ((size_t)b * w.rowsA + w.row0A[y] + i) * w.lda + c;
+                v = *(const float4*)(A + o);
+                if (A2) { const float4 u = *(const float4*)(A2 + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+            }
+            *(float4*)(As + (size_t)r * ldA + c) = v;
+        }
+        for (int idx = tid; idx < RS * B4; idx += 256) {
+            const int r = idx / B4, c = (idx - r * B4) * 4;
+            const int64_t rr = rs + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = ncol0 + c;
+            if (rr < r_end && c < Ng && n < w.Nvalid) {
+                const int b = (int)(rr / Rl), i = (int)(rr - (int64_t)b * Rl);
+                const int nloc = w.row0B[y] + i;
+                const size_t row = (size_t)b * w.rowsB + nloc;
+                if (w.bmode == 0) v = *(const float4*)(B1 + row * w.ldb + n);
+                else if (w.bmode == 1) { v = *(const float4*)(B1 + row * w.ldb + n); v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (w.bmode == 2) { const float4 s = *(const float4*)(B1 + row * w.ldb + n), t = *(const float4*)(B2 + row * w.ldb + n); v = make_float4(s.x * t.x, s.y * t.y, s.z * t.z, s.w * t.w); }
+                else {
+                    if (n < w.C) v = *(const float4*)(B1 + row * w.C + n);
+                    else if (n < 2 * w.C) { const int tp = tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - w.dil[y]; v = *(const float4*)(B1 + ((size_t)b * w.rowsB + tp) * w.C + (n - w.C)); }
+                    else v = *(const float4*)(w.hup + row * w.Ap + (n - 2 * w.C));
                 }
             }
-            At[r * ldt + c] = a; Bt[r * ldt + c] = bv;
+            *(float4*)(Bs + (size_t)r * ldB + c) = v;
         }
         __syncthreads();
-        if (w.gbias >= 0 && nn0 == 0 && tid < 64) { float s = 0.f; for (int r = 0; r < 64; ++r) s += At[r * ldt + tid]; csum += s; }
+        if (w.gbias[y] >= 0 && zg == 0 && tid < w.M) { float s = 0.f; for (int r = 0; r < RS; ++r) s += As[r * ldA + tid]; csum += s; }
         const int g = lane >> 4, cl = lane & 15;
-#pragma unroll 4
-        for (int ks = 0; ks < 16; ++ks) {
-            const float a = At[(4 * ks + g) * ldt + 16 * wave + cl];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bt[(4 * ks + g) * ldt + 16 * j + cl], acc[j], 0, 0, 0);
+        for (int ks = 0; ks < RS / 4; ++ks) {
+            float bfr[NTMAX];
+#pragma unroll
+            for (int nt = 0; nt < NTMAX; ++nt) bfr[nt] = nt < NT ? Bs[(4 * ks + g) * ldB + 16 * nt + cl] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const int mt = wave + 4 * mi;
+                if (mt < MT) {
+                    const float a = As[(4 * ks + g) * ldA + 16 * mt + cl];
+#pragma unroll
+                    for (int nt = 0; nt < NTMAX; ++nt)
+                        if (nt < NT) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[nt], acc[mi][nt], 0, 0, 0);
+                }
+            }
         }
         __syncthreads();
     }
     float* out = w.slab + (size_t)ch * w.gstage;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int mt = wave + 4 * mi;
+        if (mt >= MT) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 16 * wave + 4 * (lane >> 4) + i, n = nn0 + 16 * j + (lane & 15);
-            if (m < w.M && n < w.N) out[w.goff + (size_t)m * w.ldc + n] = acc[j][i];
+        for (int nt = 0; nt < NTMAX; ++nt) {
+            if (nt >= NT) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * mt + 4 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
+                if (m < w.M && n < Ng) out[w.goff[y] + (size_t)m * w.ldc + ncol0 + n] = acc[mi][nt][i];
+            }
         }
-    if (w.gbias >= 0 && nn0 == 0 && tid < 64 && m0 + tid < w.M) out[w.gbias + m0 + tid] = csum;
+    }
+    if (w.gbias[y] >= 0 && zg == 0 && tid < w.M) out[w.gbias[y] + tid] = csum;
+}
+
+template <int MPW, int NTMAX>
+static int launch_wgrad2(const Wg2& w, int nch, hipStream_t stream) {
+    const int Mp = (w.M + 15) & ~15, Np = ((w.N / w.ncol_groups) + 15) & ~15;
+    if (Mp / 16 > 4 * MPW || Np / 16 > NTMAX) return -1;
+    const size_t lds = (size_t)32 * (tr_ldt(Mp) + tr_ldt(Np)) * sizeof(float);
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_wgrad2<MPW, NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wgrad2<MPW, NTMAX>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    return 0;
+}
+static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
+    if (launch_wgrad2<1, 4>(w, nch, stream) == 0) return true;
+    if (launch_wgrad2<4, 4>(w, nch, stream) == 0) return true;
+    if (launch_wgrad2<2, 12>(w, nch, stream) == 0) return true;
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------ small backward kernels
@@ -376,11 +430,6 @@ __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-static void launch_wgrad(const WgDesc& w, int nch, hipStream_t stream) {
-    const int ntm = (w.M + 63) / 64, ntn = (w.N + 63) / 64;
-    hipLaunchKernelGGL(k_wgrad, dim3(ntm * ntn, nch), dim3(256), 0, stream, w, nch);
-}
-
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
@@ -390,58 +439,67 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
+    // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
+    QPN_HIP(hipMemsetAsync(bw.DXA[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
+    QPN_HIP(hipMemsetAsync(bw.DXB[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
     hipLaunchKernelGGL(k_post_bwd, dim3((BL + TR_TM - 1) / TR_TM, B), dim3(512), lds_post, stream, p, bw);
     qpn_prof_mark(PG_POST_BWD, stream);
-    WgDesc w; memset(&w, 0, sizeof(w));
-    w.slab = bw.slab; w.gstage = bw.gstage; w.nb = B; w.C = C; w.Ap = p.Ap;
-    // post 2: dW2[q][s] = sum dlogits[t][q] relu(Y0)[t][s]
-    w.A = bw.dlogits; w.A2 = nullptr; w.lda = Q; w.M = Q; w.rowsA = BL; w.row0A = 0;
-    w.bmode = 1; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.rowsB = BL; w.row0B = 0; w.R = BL;
-    w.goff = bw.g_p2; w.ldc = S; w.gbias = bw.g_bp2; launch_wgrad(w, bw.nch, stream);
-    // post 1: dW1[o][s] = sum dY0[t][o] relu(S0)[t][s]
-    w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff = bw.g_p1; w.gbias = bw.g_bp1; launch_wgrad(w, bw.nch, stream);
-    // skip: dWs_l[s][c] = sum dS0[t][s] g_l[t][c]; skip bias grads (shared by all layers) = colsum(dS0)
-    for (int l = 0; l < L; ++l) {
-        w.A = bw.DS0; w.lda = S; w.M = S; w.rowsA = BL; w.row0A = 0;
-        w.bmode = 2; w.B1 = p.SG + (size_t)l * B * N1 * C; w.B2 = p.TH + (size_t)l * B * N1 * C; w.ldb = C; w.N = C; w.Nvalid = C;
-        w.rowsB = N1; w.row0B = N1 - BL; w.R = BL;
-        w.goff = bw.g_ws[l]; w.ldc = C; w.gbias = l == 0 ? bw.g_bs : -1; launch_wgrad(w, bw.nch, stream);
-    }
-    qpn_prof_mark(PG_WGRAD, stream);
-    int pp = 0;
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
-        const int last = l == L - 1;
-        // outputs of this layer's backward go to parity pp^1: zero them (scatter target / rows without a writer)
-        QPN_HIP(hipMemsetAsync(bw.DXA[pp ^ 1], 0, nDX * sizeof(float), stream));
-        QPN_HIP(hipMemsetAsync(bw.DXB[pp ^ 1], 0, nDX * sizeof(float), stream));
         const int rows = N1 - ly.s_out;
-        hipLaunchKernelGGL(k_layer_bwd, dim3((rows + TR_TM - 1) / TR_TM, B), dim3(256), lds_layer, stream, p, bw, l, last, pp);
-        qpn_prof_mark(PG_LAYER_BWD, stream);
-        // dW1 = dZ^T [x_cur | x_past | aux]
-        w.A = bw.DZ; w.A2 = nullptr; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1; w.row0A = ly.s_out;
-        w.bmode = 3; w.B1 = p.X + (size_t)l * B * N1 * C; w.B2 = nullptr; w.hup = p.HUP; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap;
-        w.rowsB = N1; w.row0B = ly.s_out; w.R = rows; w.tap = ly.adaptive ? p.TAP + ly.tap_off : nullptr; w.tap_rows = N1; w.dil = ly.dilation;
-        w.goff = bw.g_w1[l]; w.ldc = p.Ktp; w.gbias = bw.g_b1[l]; launch_wgrad(w, bw.nch, stream);
-        // dWr = dXout^T g   (zero for the last layer: its residual output is unused)
-        w.A = bw.DXA[pp]; w.A2 = bw.DXB[pp]; w.lda = C; w.M = C; w.rowsA = N1; w.row0A = ly.s_out;
-        w.bmode = 2; w.B1 = p.SG + (size_t)l * B * N1 * C; w.B2 = p.TH + (size_t)l * B * N1 * C; w.ldb = C; w.N = C; w.Nvalid = C;
-        w.rowsB = N1; w.row0B = ly.s_out; w.R = last ? 0 : rows; w.tap = nullptr;
-        w.goff = bw.g_wr[l]; w.ldc = C; w.gbias = bw.g_br[l]; launch_wgrad(w, bw.nch, stream);
-        qpn_prof_mark(PG_WGRAD, stream);
-        pp ^= 1;
+        hipLaunchKernelGGL(k_layer_bwd, dim3((rows + TR_TM - 1) / TR_TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
     }
+    qpn_prof_mark(PG_LAYER_BWD, stream);
+    // ---- weight gradients: 4 launches over (time chunk, layer)
+    const int nch = bw.nch;
+    Wg2 w; memset(&w, 0, sizeof(w));
+    w.slab = bw.slab; w.gstage = bw.gstage; w.nb = B; w.C = C; w.Ap = p.Ap; w.hup = p.HUP; w.tap = p.TAP; w.ncol_groups = 1;
+    bool ok = true;
+    {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
+        w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
+        w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
+        w.nlayers = L; w.ldc = p.Ktp;
+        for (int l = 0; l < L; ++l) {
+            const TrLayer& ly = p.layers[l];
+            w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
+            w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
+        }
+        ok = ok && wgrad2_any(w, nch, stream);
+    }
+    {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
+        w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
+        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+        for (int l = 0; l < L; ++l) {
+            w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1;
+        }
+        ok = ok && wgrad2_any(w, nch, stream);
+    }
+    {   // dWs_l = dS0^T g_l over the last BL rows; the shared skip-bias grad = colsum(dS0) (layer 0's block only)
+        w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
+        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+        for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; }
+        ok = ok && wgrad2_any(w, nch, stream);
+    }
+    {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
+        w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
+        w.row0A[0] = w.row0B[0] = 0; w.R[0] = BL; w.tap_off[0] = -1;
+        w.ncol_groups = S % 64 == 0 ? S / 64 : 1;
+        w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
+        ok = ok && wgrad2_any(w, nch, stream);
+        w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
+        ok = ok && wgrad2_any(w, nch, stream);
+    }
+    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 64, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
+    qpn_prof_mark(PG_WGRAD, stream);
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat);
     {
-        // grads w.r.t. the causal output sit in parity `pp`; k_causal_bwd reads parity 0 -> pass a shifted view
-        TrainBwd b2 = bw; b2.DXA[0] = bw.DXA[pp]; b2.DXB[0] = bw.DXB[pp];
         const int64_t total = (int64_t)B * N1;
         const int nwg = 64, rpw = (int)((total + nwg - 1) / nwg);
         const int CB = C < 64 ? C : 64;
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, b2, rpw);
+        hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
         if (p.U > 0) hipLaunchKernelGGL(k_up_bwd, dim3(nwg), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpw);
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);

@@ -253,28 +253,35 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     }
 }
 
-// mean cross entropy + its gradient, one wave per row (reference qpnet_train.py:430,526-528)
+// mean cross entropy + its gradient, one wave per row, 16 rows per wave (reference qpnet_train.py:430,526-528)
 __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t tgt_stride,
                                             int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const float* lg = logits + (size_t)row * Q;
-    const int64_t b = row / BL, t = row - b * BL;
-    int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
-    float m = -INFINITY;
-    for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
-    float se = 0.f;
-    for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
-    for (int s = 32; s >= 1; s >>= 1) se += __shfl_xor(se, s);
-    const float lse = logf(se) + m;
+    __shared__ double part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)rows;
-    if (dlogits) for (int q = lane; q < Q; q += 64) {
-        float pr = expf(lg[q] - lse);
-        dlogits[(size_t)row * Q + q] = (pr - (q == tg ? 1.0f : 0.0f)) * inv;
+    double lsum = 0.0;
+    for (int it = 0; it < 16; ++it) {
+        const int64_t row = ((int64_t)blockIdx.x * 16 + it) * 4 + wave;
+        if (row >= rows) break;
+        const float* lg = logits + (size_t)row * Q;
+        const int64_t b = row / BL, t = row - b * BL;
+        const int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
+        float m = -INFINITY;
+        for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
+        for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+        float se = 0.f;
+        for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
+        for (int s = 32; s >= 1; s >>= 1) se += __shfl_xor(se, s);
+        const float lse = logf(se) + m;
+        if (dlogits) for (int q = lane; q < Q; q += 64) {
+            const float pr = expf(lg[q] - lse);
+            dlogits[(size_t)row * Q + q] = (pr - (q == tg ? 1.0f : 0.0f)) * inv;
+        }
+        lsum += (double)(lse - lg[tg]);
     }
-    if (lane == 0) atomicAdd(loss, (double)(lse - lg[tg]) / (double)rows);
+    if (lane == 0) part[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (double)rows);
 }
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
@@ -304,7 +311,7 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream) {
     const int64_t rows = (int64_t)B * BL;
     QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
-    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss);
+    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss);
     qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

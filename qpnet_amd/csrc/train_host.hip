@@ -234,7 +234,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
     TrainBwd& bw = t->bw;
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
-    size_t need = nX + 2 * nG + nH + 2 * nS + 4 * nDX + nDZ + 2 * nS + nDGS + nH + nSlab + 1024;
+    size_t need = nX + 2 * nG + nH + 2 * nS + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + 4096;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -252,8 +252,8 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     float* w = t->d_ws;
     auto carve = [&](size_t n) { float* r = w; w += (n + 63) & ~(size_t)63; return r; };
     p.X = carve(nX); p.SG = carve(nG); p.TH = carve(nG); p.HUP = carve(nH); p.S0 = carve(nS); p.Y0 = carve(nS);
-    bw.DXA[0] = carve(nDX); bw.DXA[1] = carve(nDX); bw.DXB[0] = carve(nDX); bw.DXB[1] = carve(nDX);
-    bw.DZ = carve(nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
+    bw.DXA[0] = carve((size_t)(L + 1) * nDX); bw.DXB[0] = carve((size_t)(L + 1) * nDX); bw.DXA[1] = bw.DXB[1] = nullptr;   // DXB directly follows DXA (one memset)
+    bw.DZ = carve((size_t)L * nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
     p.TAP = t->d_tap; p.status = t->d_status;
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
