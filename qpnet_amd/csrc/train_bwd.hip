@@ -229,67 +229,111 @@ struct Wg2 {
     int ldc, ncol_groups;                                                   // post: N split into column groups (blockIdx.z)
 };
 
-template <int MPW, int NTMAX>
+struct Wg2L {            // per-workgroup scalars hoisted out of the kernel-argument arrays
+    const float* A; const float* A2; const float* B1; const float* B2; const float* hup; const int* tap;
+    int lda, ldb, M, Ng, Nvalid, rowsA, rowsB, row0A, row0B, C, Ap, dil, nb, ncol0, rend;
+    unsigned uR;
+};
+
+template <int BMODE, int NA, int NB>
+__device__ __forceinline__ void wg_fetch(const Wg2L& q, int rs, float4 (&ra)[NA], float4 (&ra2)[NA], float4 (&rb)[NB], float4 (&rb2)[NB],
+                                         bool a_act, int a_row0, int a_rstep, int a_col, bool b_act, int b_row0, int b_rstep, int b_col) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int r = a_row0 + k * a_rstep, rr = rs + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), v2 = v;
+        if (a_act && r < 32 && rr < q.rend && a_col < q.M) {
+            const unsigned b = q.nb > 1 ? (unsigned)rr / q.uR : 0u; const int i = rr - (int)(b * q.uR);
+            const size_t o = ((size_t)b * q.rowsA + q.row0A + i) * q.lda + a_col;
+            v = *(const float4*)(q.A + o);
+            if (q.A2) v2 = *(const float4*)(q.A2 + o);
+        }
+        ra[k] = v; ra2[k] = v2;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int r = b_row0 + k * b_rstep, rr = rs + r;
+        const int n = q.ncol0 + b_col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), v2 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (b_act && r < 32 && rr < q.rend && b_col < q.Ng && n < q.Nvalid) {
+            const unsigned b = q.nb > 1 ? (unsigned)rr / q.uR : 0u; const int i = rr - (int)(b * q.uR);
+            const int nloc = q.row0B + i;
+            const size_t row = (size_t)b * q.rowsB + nloc;
+            if (BMODE <= 1) v = *(const float4*)(q.B1 + row * q.ldb + n);
+            else if (BMODE == 2) { v = *(const float4*)(q.B1 + row * q.ldb + n); v2 = *(const float4*)(q.B2 + row * q.ldb + n); }
+            else {
+                if (n < q.C) v = *(const float4*)(q.B1 + row * q.C + n);
+                else if (n < 2 * q.C) { const int tp = q.tap ? q.tap[(size_t)b * q.rowsB + nloc] : nloc - q.dil; v = *(const float4*)(q.B1 + ((size_t)b * q.rowsB + tp) * q.C + (n - q.C)); }
+                else v = *(const float4*)(q.hup + row * q.Ap + (n - 2 * q.C));
+            }
+        }
+        rb[k] = v; rb2[k] = v2;
+    }
+}
+
+template <int BMODE, int MPW, int NTMAX>
 __global__ __launch_bounds__(256) void k_wgrad2(Wg2 w, int nch) {
     extern __shared__ float sm[];
     constexpr int RS = 32;
+    constexpr int NA = 2 * MPW;              // staging passes of A: 32 rows / (256 / (Mp/4)) with Mp <= 64*MPW
+    constexpr int NB = (NTMAX + 1) / 2 + 1;  // staging passes of B: ceil(32 / floor(256 / (Np/4))), Np <= 16*NTMAX
     const int y = blockIdx.y, ch = blockIdx.x, zg = blockIdx.z;
     const int Mp = (w.M + 15) & ~15, Ng = w.N / w.ncol_groups, Np = (Ng + 15) & ~15;
     const int ldA = tr_ldt(Mp), ldB = tr_ldt(Np);
     float* As = sm; float* Bs = sm + RS * ldA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int MT = Mp / 16, NT = Np / 16;
-    const int ncol0 = zg * Ng;
-    const int64_t total = (int64_t)w.R[y] * w.nb;
-    const int64_t per = ((total + nch - 1) / nch + RS - 1) / RS * RS;
-    const int64_t r_begin = per * ch, r_end = r_begin + per < total ? r_begin + per : total;
-    const float* A = w.A + (size_t)y * w.A_lstride; const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
-    const float* B1 = w.B1 + (size_t)y * w.B_lstride; const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
-    const int* tap = (w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
     const int Rl = w.R[y];
+    const int64_t total = (int64_t)Rl * w.nb;
+    const int64_t per = ((total + nch - 1) / nch + RS - 1) / RS * RS;
+    const int rbeg = (int)(per * ch), rend = (int)(per * ch + per < total ? per * ch + per : total);
+    Wg2L q;
+    q.A = w.A + (size_t)y * w.A_lstride; q.A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
+    q.B1 = w.B1 + (size_t)y * w.B_lstride; q.B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
+    q.hup = w.hup; q.tap = (w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
+    q.lda = w.lda; q.ldb = w.ldb; q.M = w.M; q.Ng = Ng; q.Nvalid = w.Nvalid; q.rowsA = w.rowsA; q.rowsB = w.rowsB;
+    q.row0A = w.row0A[y]; q.row0B = w.row0B[y]; q.C = w.C; q.Ap = w.Ap; q.dil = w.dil[y]; q.nb = w.nb; q.ncol0 = zg * Ng; q.rend = rend;
+    q.uR = (unsigned)(Rl > 0 ? Rl : 1);
+    const int gbias = zg == 0 ? w.gbias[y] : -1, goff = w.goff[y];
+    const int A4 = Mp / 4, B4 = Np / 4;
+    const int a_col = (tid % A4) * 4, a_row0 = tid / A4, a_rstep = 256 / A4;
+    const int b_rstep = 256 / B4 > 0 ? 256 / B4 : 1;
+    const int b_col = (tid % B4) * 4, b_row0 = tid / B4;
+    const bool a_act = tid < a_rstep * A4, b_act = tid < b_rstep * B4;
     f32x4 acc[MPW][NTMAX];
 #pragma unroll
     for (int a = 0; a < MPW; ++a)
 #pragma unroll
         for (int b = 0; b < NTMAX; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
     float csum = 0.f;
-    const int A4 = Mp / 4, B4 = Np / 4;
-    for (int64_t rs = r_begin; rs < r_end; rs += RS) {
-        for (int idx = tid; idx < RS * A4; idx += 256) {
-            const int r = idx / A4, c = (idx - r * A4) * 4;
-            const int64_t rr = rs + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rr < r_end && c < w.M) {
-                const int b = (int)(rr / Rl), i = (int)(rr - (int64_t)b * Rl);
-                const size_t o = ((size_t)b * w.rowsA + w.row0A[y] + i) * w.lda + c;
-                v = *(const float4*)(A + o);
-                if (A2) { const float4 u = *(const float4*)(A2 + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
+    if (rbeg < rend) wg_fetch<BMODE, NA, NB>(q, rbeg, ra, ra2, rb, rb2, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+    const int g = lane >> 4, cl = lane & 15;
+    for (int rs = rbeg; rs < rend; rs += RS) {
+        // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int r = a_row0 + k * a_rstep;
+            if (a_act && r < RS) {
+                float4 v = ra[k];
+                v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w;
+                *(float4*)(As + (size_t)r * ldA + a_col) = v;
             }
-            *(float4*)(As + (size_t)r * ldA + c) = v;
         }
-        for (int idx = tid; idx < RS * B4; idx += 256) {
-            const int r = idx / B4, c = (idx - r * B4) * 4;
-            const int64_t rr = rs + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int n = ncol0 + c;
-            if (rr < r_end && c < Ng && n < w.Nvalid) {
-                const int b = (int)(rr / Rl), i = (int)(rr - (int64_t)b * Rl);
-                const int nloc = w.row0B[y] + i;
-                const size_t row = (size_t)b * w.rowsB + nloc;
-                if (w.bmode == 0) v = *(const float4*)(B1 + row * w.ldb + n);
-                else if (w.bmode == 1) { v = *(const float4*)(B1 + row * w.ldb + n); v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (w.bmode == 2) { const float4 s = *(const float4*)(B1 + row * w.ldb + n), t = *(const float4*)(B2 + row * w.ldb + n); v = make_float4(s.x * t.x, s.y * t.y, s.z * t.z, s.w * t.w); }
-                else {
-                    if (n < w.C) v = *(const float4*)(B1 + row * w.C + n);
-                    else if (n < 2 * w.C) { const int tp = tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - w.dil[y]; v = *(const float4*)(B1 + ((size_t)b * w.rowsB + tp) * w.C + (n - w.C)); }
-                    else v = *(const float4*)(w.hup + row * w.Ap + (n - 2 * w.C));
-                }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int r = b_row0 + k * b_rstep;
+            if (b_act && r < RS) {
+                float4 v = rb[k];
+                if (BMODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (BMODE == 2) { v.x *= rb2[k].x; v.y *= rb2[k].y; v.z *= rb2[k].z; v.w *= rb2[k].w; }
+                *(float4*)(Bs + (size_t)r * ldB + b_col) = v;
             }
-            *(float4*)(Bs + (size_t)r * ldB + c) = v;
         }
         __syncthreads();
-        if (w.gbias[y] >= 0 && zg == 0 && tid < w.M) { float s = 0.f; for (int r = 0; r < RS; ++r) s += As[r * ldA + tid]; csum += s; }
-        const int g = lane >> 4, cl = lane & 15;
+        // next stage's rows fly while the matrix cores work on this one
+        if (rs + RS < rend) wg_fetch<BMODE, NA, NB>(q, rs + RS, ra, ra2, rb, rb2, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+        if (gbias >= 0 && tid < q.M) { float s = 0.f; for (int r = 0; r < RS; ++r) s += As[r * ldA + tid]; csum += s; }
 #pragma unroll
         for (int ks = 0; ks < RS / 4; ++ks) {
             float bfr[NTMAX];
@@ -319,27 +363,36 @@ __global__ __launch_bounds__(256) void k_wgrad2(Wg2 w, int nch) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = 16 * mt + 4 * (lane >> 4) + i, n = 16 * nt + (lane & 15);
-                if (m < w.M && n < Ng) out[w.goff[y] + (size_t)m * w.ldc + ncol0 + n] = acc[mi][nt][i];
+                if (m < q.M && n < Ng) out[goff + (size_t)m * w.ldc + q.ncol0 + n] = acc[mi][nt][i];
             }
         }
     }
-    if (w.gbias[y] >= 0 && zg == 0 && tid < w.M) out[w.gbias[y] + tid] = csum;
+    if (gbias >= 0 && tid < q.M) out[gbias + tid] = csum;
 }
 
-template <int MPW, int NTMAX>
+template <int BMODE, int MPW, int NTMAX>
 static int launch_wgrad2(const Wg2& w, int nch, hipStream_t stream) {
     const int Mp = (w.M + 15) & ~15, Np = ((w.N / w.ncol_groups) + 15) & ~15;
     if (Mp / 16 > 4 * MPW || Np / 16 > NTMAX) return -1;
     const size_t lds = (size_t)32 * (tr_ldt(Mp) + tr_ldt(Np)) * sizeof(float);
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_wgrad2<MPW, NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_wgrad2<MPW, NTMAX>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad2<BMODE, MPW, NTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wgrad2<BMODE, MPW, NTMAX>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
     return 0;
 }
-static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
-    if (launch_wgrad2<1, 4>(w, nch, stream) == 0) return true;
-    if (launch_wgrad2<4, 4>(w, nch, stream) == 0) return true;
-    if (launch_wgrad2<2, 12>(w, nch, stream) == 0) return true;
+template <int BMODE>
+static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
+    if (launch_wgrad2<BMODE, 1, 4>(w, nch, stream) == 0) return true;
+    if (launch_wgrad2<BMODE, 4, 4>(w, nch, stream) == 0) return true;
+    if (launch_wgrad2<BMODE, 2, 12>(w, nch, stream) == 0) return true;
     return false;
+}
+static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
+    switch (w.bmode) {
+    case 1: return wgrad2_mode<1>(w, nch, stream);
+    case 2: return wgrad2_mode<2>(w, nch, stream);
+    case 3: return wgrad2_mode<3>(w, nch, stream);
+    default: return wgrad2_mode<0>(w, nch, stream);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ small backward kernels
@@ -495,7 +548,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat);
     {
         const int64_t total = (int64_t)B * N1;
-        const int nwg = 64, rpw = (int)((total + nwg - 1) / nwg);
+        const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
         const int CB = C < 64 ? C : 64;
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
