@@ -172,7 +172,7 @@ static int train_init(qpn_handle* h) {
     bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
     for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
     for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
-    bw.gstage = go; bw.nch = 32; bw.n_params = g.n_params;
+    bw.gstage = go; bw.nch = 64; bw.n_params = g.n_params;
     // causal table / bias and the upsampling kernel are written by dedicated kernels (gs stays -1)
 
     const size_t nmap = map.size();
