@@ -60,8 +60,27 @@ __device__ __forceinline__ float chunk16(const float4 (&w)[4], const float4 (&x)
     }
     return acc;
 }
-// stride-halving tree over the R lanes of a row group (R = 1 << logR, lanes contiguous)
+// stride-halving tree over the R lanes of a row group (R = 1 << logR, lanes contiguous).
+// The spec order is "p_i += p_{i+s} for s = R/2 .. 1"; fp add is commutative, so every lane of the
+// group ends with the same bits whether the partner is reached by xor, rotation or quad permute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float tree_reduce(float acc, int logR) {
+    if (logR == 2) {                       // K = 64: two quad permutes, no LDS crossbar
+        acc = acc + dpp_f<0x4E>(acc);      // quad_perm [2,3,0,1]  (stride 2)
+        acc = acc + dpp_f<0xB1>(acc);      // quad_perm [1,0,3,2]  (stride 1)
+        return acc;
+    }
+    if (logR == 4) {                       // K = 256: row rotations by 8 and 4, then the quad permutes
+        acc = acc + dpp_f<0x128>(acc);     // row_ror:8
+        acc = acc + dpp_f<0x124>(acc);     // row_ror:4
+        acc = acc + dpp_f<0x4E>(acc);
+        acc = acc + dpp_f<0xB1>(acc);
+        return acc;
+    }
+    if (logR == 1) return acc + dpp_f<0xB1>(acc);
     for (int s = (1 << logR) >> 1; s >= 1; s >>= 1) acc = acc + __shfl_xor(acc, s);
     return acc;
 }
@@ -161,8 +180,30 @@ __global__ void k_known(const int64_t* __restrict__ x, int n_x, int n_pad, int Q
 }
 
 // ================================================================== the persistent decode kernel
+// File-scope LDS symbol: device functions index it directly, so the compiler keeps address space 3
+// (a generic float* would turn every LDS access into a FLAT op that also waits on the global-load queue).
+extern __shared__ float4 qpn_lds[];
+#define SM ((float*)qpn_lds)
+#define SMI ((int*)qpn_lds)
+struct UttView {            // per-utterance pointers derived from kernel-argument bases (global address space)
+    const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
+    int n_pad, n0, n_samples, d_is_f32;
+};
+__device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDesc& d) {
+    UttView u;
+    u.pproj = p.pproj + d.pproj;
+    u.dfac = d.d_is_f32 ? (const void*)((const float*)p.dfac + d.dfac) : (const void*)((const double*)p.dfac + d.dfac);
+    u.known = p.known + d.known;
+    u.teacher = d.teacher >= 0 ? p.teacher + d.teacher : nullptr;
+    u.out = p.out + d.out;
+    u.logits = d.logits >= 0 ? p.logits + d.logits : nullptr;
+    u.ring = p.ring + d.ring;
+    u.n_pad = d.n_pad; u.n0 = d.n0; u.n_samples = d.n_samples; u.d_is_f32 = d.d_is_f32;
+    return u;
+}
+
 // pitch-dependent tap distance of ring `r` at (padded) time t  (qpnet.py:613-624)
-__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttDesc& u, int64_t ut) {
+__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int64_t ut) {
     if (!r.adaptive) return r.mult;
     if (ut < 0) return r.mult;                       // d := 1.0 in the left padding (qpnet.py:361-364)
     if (u.d_is_f32) {
@@ -173,152 +214,204 @@ __device__ __forceinline__ int tap_offset(const RingDesc& r, const UttDesc& u, i
     return -(int)rint(-d * (double)r.mult);
 }
 
-// Stage everything step t1 needs that does not depend on the sample picked at step t1-1:
-// the gathered past rows of every layer (LDS xp) and the aux terms a[t1] (LDS auxv).
-__device__ __forceinline__ void stage_step(const DecodeParams& p, const UttDesc& u, float* sm, int64_t t1,
-                                           int tid, int nthreads, int* status) {
-    const int L = p.L, C = p.C, C2 = 2 * p.C;
+// aux terms a[t1] of every layer -> LDS (needs only the frame-rate projections)
+__device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& u, int64_t t1, int tid, int nthreads) {
+    float* sm = SM;
+    const int n = p.L * 2 * p.C;
     const int64_t ut = t1 - u.n_pad;
     int64_t f; int j;
     if (ut < 0) { f = 0; j = 0; }                    // replicate pad of the upsampled h (qpnet.py:359)
     else if (p.U > 0) { f = ut / p.U; j = (int)(ut - f * p.U); }
     else { f = ut; j = 0; }
     const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f;
-    const float* pf = u.pproj + (size_t)f * L * C2;
-    for (int i = tid; i < L * C2; i += nthreads) sm[p.o_auxv + i] = __builtin_fmaf(wj, pf[i], p.qb[i]);
+    const float* pf = u.pproj + (size_t)f * n;
+    for (int i = tid; i < n; i += nthreads) sm[p.o_auxv + i] = __builtin_fmaf(wj, pf[i], p.qb[i]);
+}
+// gathered past rows x_l[t2 - off_l(t2)] of every layer -> LDS xp; sel[l] = 1 when off == 1 (the row is
+// produced during step t2-1 itself and is read from xbuf instead)
+__device__ __forceinline__ void stage_taps(const DecodeParams& p, const UttView& u, int64_t t2, int tid, int nthreads, int* status) {
+    const int L = p.L, C = p.C;
+    float* sm = SM; int* smi = SMI;
+    const int64_t ut = t2 - u.n_pad;
     for (int i = tid; i < L * C; i += nthreads) {
         const int l = i / C, c = i - l * C;
         const RingDesc r = p.rings[l];
         int off = tap_offset(r, u, ut);
         if (off < 1 || off >= r.len) { if (c == 0) atomicOr(status, 1); off = off < 1 ? 1 : r.len - 1; }
-        int64_t tp = t1 - off;                        // time of the past tap; < 0 -> zeros
-        int slot = (int)(((tp % r.len) + r.len) % r.len);
-        sm[p.o_xp + l * p.Cp + c] = ld_agent(u.ring + r.base + (size_t)slot * C + c);
+        if (c == 0) smi[p.o_sel + l] = off == 1;
+        if (off > 1) {
+            const int64_t tp = t2 - off;              // time of the past tap; < 0 -> zeros (ring is zero-filled)
+            const int slot = (int)(((tp % r.len) + r.len) % r.len);
+            sm[p.o_xp + l * p.Cp + c] = ld_agent(u.ring + r.base + (size_t)slot * C + c);
+        }
+    }
+}
+// causal conv on the one-hot input = two table rows (qpnet.py:110-132): input of layer 0 at time t1
+__device__ __forceinline__ void causal_rows(const DecodeParams& p, const UttView& u, int s_prev, int s_cur, int64_t t1, int lane) {
+    float* sm = SM;
+    const RingDesc r0 = p.rings[0];
+    for (int ch = lane; ch < p.C; ch += 64) {
+        float v = p.flat[p.causal_w + ((size_t)ch * p.Q + s_prev) * 2] + p.flat[p.causal_w + ((size_t)ch * p.Q + s_cur) * 2 + 1];
+        v = v + p.flat[p.causal_b + ch];
+        sm[p.o_xbuf + ch] = v;
+        st_agent(u.ring + r0.base + (size_t)(t1 % r0.len) * p.C + ch, v);
     }
 }
 
+struct Ctx {
+    const DecodeParams* p; const UttView* u;
+    int lane, wave; int64_t Ttot;
+};
+
+// one slot of the per-step program for this wave; `w` holds the slot's weight tile and is refilled with
+// the tile of slot+3 as soon as it has been consumed (three tiles in flight per wave).
+__device__ __forceinline__ void run_slot(const Ctx& c, int slot, int64_t t, float4 (&w)[4]) {
+    const DecodeParams& p = *c.p; const UttView& u = *c.u;
+    float* sm = SM; int* smi = SMI;
+    const int lane = c.lane;
+    const int4* tl = (const int4*)(smi + p.o_tasks + (slot * QPN_NW + c.wave) * 8);
+    const int4 q0 = tl[0], q1 = tl[1];
+    const int opf = __builtin_amdgcn_readfirstlane(q0.x);
+    int xoff = __builtin_amdgcn_readfirstlane(q0.z);
+    const int row0 = __builtin_amdgcn_readfirstlane(q0.w);
+    const int ta = __builtin_amdgcn_readfirstlane(q1.x), tb = __builtin_amdgcn_readfirstlane(q1.y);
+    const int tc = __builtin_amdgcn_readfirstlane(q1.z), td = __builtin_amdgcn_readfirstlane(q1.w);
+    // descriptor of the task three slots ahead (same register set)
+    int ns = slot + 3; if (ns >= p.n_slots) ns -= p.n_slots;
+    const int2 nq = *(const int2*)(smi + p.o_tasks + (ns * QPN_NW + c.wave) * 8);
+    const int nopf = __builtin_amdgcn_readfirstlane(nq.x), nwoff = __builtin_amdgcn_readfirstlane(nq.y);
+    if (opf & TF_BARRIER) {
+        if (opf & TF_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wg_barrier();
+    }
+    const int op = opf & 0xff;
+    const int C = p.C, Q = p.Q;
+    if (opf & TF_HASW) {
+        const int logR = (opf >> 16) & 0xf;
+        const int R = 1 << logR, q = lane & (R - 1);
+        if (op == OP_PAST && smi[p.o_sel + tc]) xoff = tb;        // tap distance 1: the row is this step's layer input
+        float4 x[4];
+        const float4* xv = (const float4*)(sm + xoff + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = xv[j];
+        float acc = chunk16(w, x);
+        if (nopf & TF_HASW) load_tile(w, p.wpk, nwoff, lane);
+        acc = tree_reduce(acc, logR);
+        const int row = row0 + (lane >> logR);
+        const bool lead = q == 0;
+        const int par = (int)(t & 1) * p.L * 2 * C;
+        switch (op) {
+        case OP_PAST:      // a = layer*2C: past-tap dot of the NEXT step -> pd[(t+1)&1]
+            if (lead) sm[p.o_pd + (p.L * 2 * C - par) + ta + row] = acc;
+            break;
+        case OP_Z: {       // rows interleaved (sigmoid_c, tanh_c); a = layer*2C, c = g
+            const int ch = row >> 1, half = row & 1, nat = half * C + ch;
+            const float z = (acc + sm[p.o_pd + par + ta + nat]) + sm[p.o_auxv + ta + nat];
+            float zo;
+            if (logR == 2) zo = dpp_f<0x104>(z);            // row_shl:4 -> lane i reads lane i+4 (the tanh group)
+            else if (logR == 1) zo = dpp_f<0x102>(z);
+            else if (logR == 3) zo = dpp_f<0x108>(z);
+            else if (logR == 0) zo = dpp_f<0x101>(z);
+            else zo = __shfl_xor(z, R);
+            if (lead && !half) sm[tc + ch] = qgate(z, zo);
+            break;
+        }
+        case OP_RES:       // a = x in (LDS), b = bias (LDS), c = x out (LDS), d = ring index of the consumer or -1
+            if (lead) {
+                const float v = (acc + sm[tb + row]) + sm[ta + row];
+                sm[tc + row] = v;
+                if (td >= 0) {
+                    const RingDesc r = p.rings[td];
+                    st_agent(u.ring + r.base + (size_t)(t % r.len) * C + row, v);
+                }
+            }
+            break;
+        case OP_SKIP:      // a = accumulator (LDS), b = bias (LDS), c = other accumulator, d = y1
+            if (lead) {
+                const float v = sm[ta + row] + (acc + sm[tb + row]);
+                sm[ta + row] = v;
+                if (opf & TF_LAST) {
+                    const float tot = tc >= 0 ? sm[tc + row] + v : v;     // sumF + sumA (qpnet.py:505)
+                    sm[td + row] = tot > 0.0f ? tot : 0.0f;
+                }
+            }
+            break;
+        case OP_POST1:     // b = bias, c = y2
+            if (lead) { const float v = acc + sm[tb + row]; sm[tc + row] = v > 0.0f ? v : 0.0f; }
+            break;
+        case OP_POST2:     // b = bias, c = logits
+            if (lead) sm[tc + row] = acc + sm[tb + row];
+            break;
+        default: break;
+        }
+        return;
+    }
+    if (op == OP_ARGMAX) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
+        for (int s = 32; s >= 1; s >>= 1) {
+            const float ov = __shfl_xor(bv, s); const int oi = __shfl_xor(bi, s);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const int64_t i = t - (u.n0 - 1);
+        if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
+        int next;
+        if (i >= 0) {
+            next = bi;
+            if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
+            if (lane == 0) u.out[i] = bi;
+        } else next = u.known[t + 1];
+        const int cur = smi[p.o_samp + 1];
+        if (t + 2 < c.Ttot) causal_rows(p, u, cur, next, t + 1, lane);     // layer-0 input of the next step
+        if (lane == 0) { smi[p.o_samp] = cur; smi[p.o_samp + 1] = next; }
+    } else if (op == OP_STAGE) {    // a = first wave of the staging group, b = waves in it
+        const int stid = (c.wave - ta) * 64 + lane, nst = tb * 64;
+        for (int i = stid; i < p.S; i += nst) { sm[p.o_skf + i] = 0.0f; sm[p.o_ska + i] = 0.0f; }
+        if (t + 2 < c.Ttot) stage_aux(p, u, t + 1, stid, nst);
+        if (t + 3 < c.Ttot) stage_taps(p, u, t + 2, stid, nst, p.status);
+    }
+    if (nopf & TF_HASW) load_tile(w, p.wpk, nwoff, lane);
+}
+
 __global__ __launch_bounds__(QPN_NT) void k_decode(DecodeParams p) {
-    extern __shared__ float4 smem4[];
-    float* sm = (float*)smem4;
-    int* smi = (int*)smem4;
-    const UttDesc u = p.utts[blockIdx.x];
+    float* sm = SM;
+    int* smi = SMI;
+    const UttView u = make_view(p, p.utts[blockIdx.x]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int C = p.C, Q = p.Q;
-
-    for (int i = tid; i < p.lds_floats; i += QPN_NT) sm[i] = 0.0f;
-    __syncthreads();
-    if (tid == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.n0 > 1 ? u.known[1] : 0; }
-    const int64_t Ttot = (int64_t)u.n0 + u.n_samples;
-    if (Ttot < 3) { /* nothing to predict unless n_samples >= 1 and n0 >= 2 (n_pad >= 1 always) */ }
-    stage_step(p, u, sm, 1, tid, QPN_NT, p.status);
-    __syncthreads();
-
-    const Task* __restrict__ tasks = p.tasks + wave;
-    float4 w[4], wn[4];
+    for (int i = tid; i < p.state_floats; i += QPN_NT) sm[i] = 0.0f;
+    for (int i = tid; i < p.n_bias; i += QPN_NT) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
     {
-        const Task t0 = tasks[0];
-        if (t0.op & TF_HASW) load_tile(w, p.wpk, t0.woff4, lane);
+        const int* src = (const int*)p.tasks;
+        for (int i = tid; i < p.n_slots * QPN_NW * 8; i += QPN_NT) smi[p.o_tasks + i] = src[i];
+    }
+    __syncthreads();
+    const int64_t Ttot = (int64_t)u.n0 + u.n_samples;
+    if (Ttot < 3) return;                                   // nothing to predict
+    // state for the first step (t = 1): layer-0 input, aux terms; taps of step 2; pd of step 1 is all-zero
+    if (wave == 0) {
+        causal_rows(p, u, u.known[0], u.known[1], 1, lane);
+        if (lane == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.known[1]; }
+    }
+    stage_aux(p, u, 1, tid, QPN_NT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (Ttot > 3) stage_taps(p, u, 2, tid, QPN_NT, p.status);
+    __syncthreads();
+
+    Ctx c; c.p = &p; c.u = &u; c.lane = lane; c.wave = wave; c.Ttot = Ttot;
+    float4 w0[4], w1[4], w2[4];
+    {
+        const int* tk = smi + p.o_tasks + wave * 8;
+        if (tk[0] & TF_HASW) load_tile(w0, p.wpk, tk[1], lane);
+        if (tk[QPN_NW * 8] & TF_HASW) load_tile(w1, p.wpk, tk[QPN_NW * 8 + 1], lane);
+        if (tk[2 * QPN_NW * 8] & TF_HASW) load_tile(w2, p.wpk, tk[2 * QPN_NW * 8 + 1], lane);
     }
     for (int64_t t = 1; t + 1 < Ttot; ++t) {
-        for (int slot = 0; slot < p.n_slots; ++slot) {
-            const Task tk = tasks[slot * QPN_NW];
-            {   // prefetch the next task's weight tile (wraps into the next step)
-                int ns = slot + 1 == p.n_slots ? 0 : slot + 1;
-                const Task tn = tasks[ns * QPN_NW];
-                if (tn.op & TF_HASW) load_tile(wn, p.wpk, tn.woff4, lane);
-            }
-            if (tk.op & TF_BARRIER) {
-                if (tk.op & TF_DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wg_barrier();
-            }
-            const int op = tk.op & 0xff;
-            const int logR = (tk.op >> 16) & 0xf;
-            if (tk.op & TF_HASW) {
-                const int R = 1 << logR, q = lane & (R - 1);
-                float4 x[4];
-                const float4* xv = (const float4*)(sm + tk.xoff + 16 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = xv[j];
-                float acc = tree_reduce(chunk16(w, x), logR);
-                const int row = tk.row0 + (lane >> logR);
-                const bool lead = q == 0;
-                switch (op) {
-                case OP_PAST:      // a = LDS offset of this layer's past-dot vector (natural rows)
-                    if (lead) sm[tk.a + row] = acc;
-                    break;
-                case OP_Z: {       // rows interleaved (sigmoid_c, tanh_c); a = pd, b = auxv, c = g
-                    const int ch = row >> 1, half = row & 1, nat = half * C + ch;
-                    float z = (acc + sm[tk.a + nat]) + sm[tk.b + nat];
-                    float zo = __shfl_xor(z, R);
-                    if (lead && !half) sm[tk.c + ch] = qgate(z, zo);
-                    break;
-                }
-                case OP_RES:       // a = x in (LDS), b = bias (flat), c = x out (LDS), d = ring index of the consumer or -1
-                    if (lead) {
-                        float v = (acc + p.flat[tk.b + row]) + sm[tk.a + row];
-                        sm[tk.c + row] = v;
-                        if (tk.d >= 0) {
-                            const RingDesc r = p.rings[tk.d];
-                            st_agent(u.ring + r.base + (size_t)(t % r.len) * C + row, v);
-                        }
-                    }
-                    break;
-                case OP_SKIP:      // a = accumulator (LDS), b = bias (flat), c = other accumulator, d = y1
-                    if (lead) {
-                        float v = sm[tk.a + row] + (acc + p.flat[tk.b + row]);
-                        sm[tk.a + row] = v;
-                        if (tk.op & TF_LAST) {
-                            // total = sumF + sumA (qpnet.py:505); a is the A accumulator unless the net has no A layers
-                            float tot = tk.c >= 0 ? sm[tk.c + row] + v : v;
-                            sm[tk.d + row] = tot > 0.0f ? tot : 0.0f;
-                        }
-                    }
-                    break;
-                case OP_POST1:     // b = bias, c = y2
-                    if (lead) { float v = acc + p.flat[tk.b + row]; sm[tk.c + row] = v > 0.0f ? v : 0.0f; }
-                    break;
-                case OP_POST2:     // b = bias, c = logits
-                    if (lead) sm[tk.c + row] = acc + p.flat[tk.b + row];
-                    break;
-                default: break;
-                }
-            } else if (op == OP_CAUSAL) {   // a = channel block; also clears the skip accumulators
-                const int ch = tk.a * 64 + lane;
-                if (ch < C) {
-                    const int a0 = smi[p.o_samp], a1 = smi[p.o_samp + 1];
-                    float v = p.flat[p.causal_w + ((size_t)ch * Q + a0) * 2] + p.flat[p.causal_w + ((size_t)ch * Q + a1) * 2 + 1];
-                    v = v + p.flat[p.causal_b + ch];
-                    sm[p.o_xbuf + ch] = v;
-                    const RingDesc r = p.rings[0];
-                    st_agent(u.ring + r.base + (size_t)(t % r.len) * C + ch, v);
-                }
-                for (int i = tk.a * 64 + lane; i < p.S; i += tk.b * 64) { sm[p.o_skf + i] = 0.0f; sm[p.o_ska + i] = 0.0f; }
-            } else if (op == OP_ARGMAX) {
-                float bv = -INFINITY; int bi = 0x7fffffff;
-                for (int i = lane; i < Q; i += 64) { float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
-                for (int s = 32; s >= 1; s >>= 1) {
-                    float ov = __shfl_xor(bv, s); int oi = __shfl_xor(bi, s);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                }
-                const int64_t i = t - (u.n0 - 1);
-                if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
-                if (lane == 0) {
-                    int next;
-                    if (i >= 0) {
-                        u.out[i] = bi;
-                        next = bi;
-                        if (u.teacher) { int64_t s = u.teacher[i] % Q; next = (int)(s < 0 ? s + Q : s); }
-                    } else next = u.known[t + 1];
-                    smi[p.o_samp] = smi[p.o_samp + 1];
-                    smi[p.o_samp + 1] = next;
-                }
-            } else if (op == OP_STAGE) {    // a = first wave of the staging group, b = waves in it
-                if (t + 2 < Ttot)   // the last step has no successor to stage for
-                    stage_step(p, u, sm, t + 1, (wave - tk.a) * 64 + lane, tk.b * 64, p.status);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = wn[j];
+        for (int slot = 0; slot < p.n_slots; slot += 3) {
+            run_slot(c, slot, t, w0);
+            run_slot(c, slot + 1, t, w1);
+            run_slot(c, slot + 2, t, w2);
         }
     }
 }
@@ -424,21 +517,28 @@ static int build_program(qpn_handle* h) {
         return QPN_EINVAL;
     }
     if (g.n_params >= (int64_t)1 << 31) { qpn_set_error("model too large for 32-bit gather map"); return QPN_EINVAL; }
-    // ---- LDS layout (float offsets, all multiples of 4)
+    // ---- LDS layout (float offsets, all multiples of 4): step state first (zeroed at start) ...
     DecodeParams& p = h->dp;
     memset(&p, 0, sizeof(p));
     int o = 0;
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
-    p.o_xbuf = take((L + 1) * g.Cp); p.o_xp = take(L * g.Cp); p.o_pd = take(L * 2 * C); p.o_auxv = take(L * 2 * C);
+    p.o_xbuf = take((L + 1) * g.Cp); p.o_xp = take(L * g.Cp); p.o_pd = take(2 * L * 2 * C); p.o_auxv = take(L * 2 * C);
     p.o_g = take(g.Cp); p.o_skf = take(S); p.o_ska = take(S); p.o_y1 = take(g.Sp); p.o_y2 = take(g.Sp); p.o_lg = take(Q);
-    p.o_samp = take(4); p.lds_floats = o;
-    if ((size_t)o * 4 > 160 * 1024) { qpn_set_error("decode state (%d KiB) exceeds the 160 KiB LDS of one CU", o * 4 / 1024); return QPN_EINVAL; }
+    p.o_samp = take(4); p.o_sel = take(L); p.state_floats = o;
+    // ... then the biases the epilogues add (so no global load sits behind the weight prefetch queue)
+    std::vector<int>& bsrc = h->h_bias_src; bsrc.clear();
+    auto bias_block = [&](int64_t flat_off, int n) { int r = p.o_bias + (int)bsrc.size(); for (int i = 0; i < n; ++i) bsrc.push_back((int)(flat_off + i)); return r; };
+    p.o_bias = o;
+    std::vector<int> lds_br(L), lds_bs(L);
+    for (int l = 0; l < L; ++l) { lds_br[l] = bias_block(g.layers[l].resb, C); lds_bs[l] = bias_block(g.layers[l].skipb, S); }
+    const int lds_b1 = bias_block(g.post1_b, S), lds_b2 = bias_block(g.post2_b, Q);
+    p.n_bias = (int)bsrc.size();
+    o += (p.n_bias + 3) & ~3;
     p.C = C; p.Cp = g.Cp; p.S = S; p.Q = Q; p.L = L; p.U = g.U;
     p.causal_w = g.causal_w; p.causal_b = g.causal_b; p.up_w = g.up_w;
 
     // ---- packed weight tiles + task list
     std::vector<int>& map = h->h_map; map.clear();
-    struct Pending { Task t; };
     std::vector<std::vector<Task>> phases;
     auto tile_tasks = [&](std::vector<Task>& ph, int op, int off4, int rows, int Kp, int xoff, int a, int b, int c, int d, int flags) {
         const int R = Kp / 16, rpt = 64 / R, tiles = rows / rpt;
@@ -447,13 +547,6 @@ static int build_program(qpn_handle* h) {
             k.a = a; k.b = b; k.c = c; k.d = d; ph.push_back(k);
         }
     };
-    // phase 0: causal lookup (+ clear skip sums) and every layer's past-tap dot
-    std::vector<Task> ph0;
-    {
-        int nblk = (C + 63) / 64;
-        for (int i = 0; i < nblk; ++i) { Task k; memset(&k, 0, sizeof(k)); k.op = OP_CAUSAL; k.a = i; k.b = nblk; ph0.push_back(k); }
-    }
-    std::vector<std::vector<Task>> zph(L), rph(L);
     for (int l = 0; l < L; ++l) {
         const LayerGeom y = g.layers[l];
         auto srcw = [&](int half, int r, int k, int past) -> int64_t {
@@ -465,19 +558,23 @@ static int build_program(qpn_handle* h) {
         int off_cur = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row & 1, row >> 1, k, 0); });
         int off_res = pack_matrix(map, C, C, g.Cp, [&](int row, int k) { return y.res + (int64_t)row * C + k; });
         int off_skip = pack_matrix(map, S, C, g.Cp, [&](int row, int k) { return y.skip + (int64_t)row * C + k; });
-        tile_tasks(ph0, OP_PAST, off_past, 2 * C, g.Cp, p.o_xp + l * g.Cp, p.o_pd + l * 2 * C, 0, 0, 0, 0);
-        tile_tasks(zph[l], OP_Z, off_cur, 2 * C, g.Cp, p.o_xbuf + l * g.Cp, p.o_pd + l * 2 * C, p.o_auxv + l * 2 * C, p.o_g, 0, 0);
-        tile_tasks(rph[l], OP_RES, off_res, C, g.Cp, p.o_g, p.o_xbuf + l * g.Cp, (int)y.resb, p.o_xbuf + (l + 1) * g.Cp, l + 1 < L ? l + 1 : -1, 0);
+        // Z phase: this step's pre-activations + the NEXT step's past-tap dots of the same layer (the
+        // past rows are known one step early, so these tiles fill the waves the z tiles leave idle)
+        std::vector<Task> zp, rp;
+        tile_tasks(zp, OP_Z, off_cur, 2 * C, g.Cp, p.o_xbuf + l * g.Cp, l * 2 * C, 0, p.o_g, 0, 0);
+        tile_tasks(zp, OP_PAST, off_past, 2 * C, g.Cp, p.o_xp + l * g.Cp, l * 2 * C, p.o_xbuf + l * g.Cp, l, 0, 0);
+        tile_tasks(rp, OP_RES, off_res, C, g.Cp, p.o_g, p.o_xbuf + l * g.Cp, lds_br[l], p.o_xbuf + (l + 1) * g.Cp, l + 1 < L ? l + 1 : -1, 0);
         const bool last = l == L - 1;
         int acc = y.adaptive ? p.o_ska : p.o_skf;
         int other = last ? (y.adaptive ? (g.LF > 0 ? p.o_skf : -1) : -1) : 0;
-        tile_tasks(rph[l], OP_SKIP, off_skip, S, g.Cp, p.o_g, acc, (int)y.skipb, other, p.o_y1, last ? TF_LAST : 0);
+        tile_tasks(rp, OP_SKIP, off_skip, S, g.Cp, p.o_g, acc, lds_bs[l], other, p.o_y1, last ? TF_LAST : 0);
+        phases.push_back(zp); phases.push_back(rp);
     }
     int off_p1 = pack_matrix(map, S, S, g.Sp, [&](int row, int k) { return g.post1_w + (int64_t)row * S + k; });
     int off_p2 = pack_matrix(map, Q, S, g.Sp, [&](int row, int k) { return g.post2_w + (int64_t)row * S + k; });
     std::vector<Task> p1, p2, pa;
-    tile_tasks(p1, OP_POST1, off_p1, S, g.Sp, p.o_y1, 0, (int)g.post1_b, p.o_y2, 0, 0);
-    tile_tasks(p2, OP_POST2, off_p2, Q, g.Sp, p.o_y2, 0, (int)g.post2_b, p.o_lg, 0, 0);
+    tile_tasks(p1, OP_POST1, off_p1, S, g.Sp, p.o_y1, 0, lds_b1, p.o_y2, 0, 0);
+    tile_tasks(p2, OP_POST2, off_p2, Q, g.Sp, p.o_y2, 0, lds_b2, p.o_lg, 0, 0);
     { Task k; memset(&k, 0, sizeof(k)); k.op = OP_ARGMAX; pa.push_back(k);
       for (int w = 1; w < QPN_NW; ++w) { Task s; memset(&s, 0, sizeof(s)); s.op = OP_STAGE; s.a = 1; s.b = QPN_NW - 1; pa.push_back(s); } }
     // aux matrices (natural rows) for the frame-rate projection kernels
@@ -488,8 +585,6 @@ static int build_program(qpn_handle* h) {
         int off = pack_matrix(map, 2 * C, A, g.Ap, [&](int row, int k) { return (row / C ? y.auxT : y.auxS) + (int64_t)(row % C) * A + k; });
         if (l == 0) h->aux_woff4 = off;
     }
-    phases.push_back(ph0);
-    for (int l = 0; l < L; ++l) { phases.push_back(zph[l]); phases.push_back(rph[l]); }
     phases.push_back(p1); phases.push_back(p2); phases.push_back(pa);
     // lay the phases out as slots x waves; the ARGMAX/STAGE phase keeps its fixed wave assignment
     h->h_tasks.clear();
@@ -509,8 +604,16 @@ static int build_program(qpn_handle* h) {
             }
         slot += ns;
     }
+    while (slot % 3) {      // the kernel unrolls the slot loop by 3 (three weight tiles in flight per wave)
+        h->h_tasks.resize((size_t)(slot + 1) * QPN_NW);
+        for (int w = 0; w < QPN_NW; ++w) { Task k; memset(&k, 0, sizeof(k)); h->h_tasks[(size_t)slot * QPN_NW + w] = k; }
+        ++slot;
+    }
     h->n_slots = slot;
     p.n_slots = slot;
+    p.o_tasks = o; o += slot * QPN_NW * 8;
+    p.lds_floats = o;
+    if ((size_t)o * 4 > 160 * 1024) { qpn_set_error("decode state (%d KiB) exceeds the 160 KiB LDS of one CU", o * 4 / 1024); return QPN_EINVAL; }
     return QPN_OK;
 }
 
@@ -520,7 +623,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     qpn_handle* h = new qpn_handle();
     int rc = qpn_build_geom(cfg, &h->g);
     if (rc != QPN_OK) { delete h; return rc; }
-    h->d_map = nullptr; h->d_wpk = nullptr; h->d_tasks = nullptr; h->d_qb = nullptr; h->d_bd = nullptr; h->d_status = nullptr;
+    h->d_map = nullptr; h->d_wpk = nullptr; h->d_tasks = nullptr; h->d_qb = nullptr; h->d_bd = nullptr; h->d_status = nullptr; h->d_bias_src = nullptr;
     h->d_flat = nullptr; h->have_weights = false;
     h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
     h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
@@ -539,7 +642,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
 extern "C" void qpn_destroy(qpn_handle* h) {
     if (!h) return;
     if (h->device >= 0) {
-        void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_pproj, h->d_ring, h->d_known, h->d_utts};
+        void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_bias_src, h->d_pproj, h->d_ring, h->d_known, h->d_utts};
         for (void* b : bufs) if (b) (void)hipFree(b);
         qpn_train_destroy(h->train);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -567,6 +670,8 @@ extern "C" int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, voi
         QPN_HIP(hipMalloc(&h->d_qb, (size_t)g.L * 2 * g.C * sizeof(float)));
         QPN_HIP(hipMalloc(&h->d_bd, (size_t)g.L * sizeof(BiasDesc)));
         QPN_HIP(hipMalloc(&h->d_status, 64));
+        QPN_HIP(hipMalloc(&h->d_bias_src, h->h_bias_src.size() * sizeof(int)));
+        QPN_HIP(hipMemcpy(h->d_bias_src, h->h_bias_src.data(), h->h_bias_src.size() * sizeof(int), hipMemcpyHostToDevice));
         QPN_HIP(hipMemcpy(h->d_map, h->h_map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
         QPN_HIP(hipMemcpy(h->d_tasks, h->h_tasks.data(), h->h_tasks.size() * sizeof(Task), hipMemcpyHostToDevice));
         std::vector<BiasDesc> bd(g.L);
@@ -641,16 +746,15 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     rc = grow(&h->d_known, &h->known_cap, (size_t)B * n0); if (rc) return rc;
     rc = grow(&h->d_utts, &h->utts_cap, (size_t)B); if (rc) return rc;
     std::vector<UttDesc> utts(B);
-    const size_t dsz = d_is_f32 ? 4 : 8;
     for (int b = 0; b < B; ++b) {
         UttDesc& u = utts[b];
-        u.pproj = h->d_pproj + (size_t)b * F * g.L * 2 * g.C;
-        u.dfac = (const char*)d_dfac + (size_t)b * Td * dsz;
-        u.known = h->d_known + (size_t)b * n0;
-        u.teacher = d_teacher ? d_teacher + (size_t)b * max_n : nullptr;
-        u.out = d_out + (size_t)b * max_n;
-        u.logits = d_logits ? d_logits + (size_t)b * max_n * g.Q : nullptr;
-        u.ring = h->d_ring + (size_t)b * ring_floats;
+        u.pproj = (int64_t)b * F * g.L * 2 * g.C;
+        u.dfac = (int64_t)b * Td;
+        u.known = (int64_t)b * n0;
+        u.teacher = d_teacher ? (int64_t)b * max_n : -1;
+        u.out = (int64_t)b * max_n;
+        u.logits = d_logits ? (int64_t)b * max_n * g.Q : -1;
+        u.ring = (int64_t)b * ring_floats;
         u.n_pad = (int)n_pad; u.n0 = (int)n0; u.n_samples = (int)h_n_samples[b]; u.d_is_f32 = d_is_f32; u.F = F;
     }
     QPN_HIP(hipMemcpyAsync(h->d_utts, utts.data(), B * sizeof(UttDesc), hipMemcpyHostToDevice, stream));
@@ -661,7 +765,8 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     hipLaunchKernelGGL(k_aux_project, dim3((unsigned)F, B), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_h, F,
                        h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.L, h->d_pproj);
     p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
-    p.status = h->d_status; p.mode = mode; p.seed = seed;
+    p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
+    p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024)
         QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
     QPN_HIP(hipEventRecord(h->ev0, stream));

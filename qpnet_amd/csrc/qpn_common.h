@@ -56,7 +56,7 @@ enum {
 #define TF_LAST    0x400      // OP_SKIP of the last layer: also emit relu(skip total)
 #define TF_HASW    0x800      // task consumes a weight tile (prefetchable)
 
-struct Task {          // 32 bytes, wave-uniform, read through the scalar cache
+struct Task {          // 32 bytes, wave-uniform; the table is copied to LDS at kernel start
     int op;            // opcode | flags | (log2 R << 16)
     int woff4;         // float4 offset of the weight tile in the packed buffer
     int xoff;          // LDS float offset of the input vector
@@ -66,14 +66,15 @@ struct Task {          // 32 bytes, wave-uniform, read through the scalar cache
 
 struct RingDesc { int base; int len; int mult; int adaptive; };   // base: float offset in the utterance's ring block
 
-struct UttDesc {
-    const float* pproj;     // [F][L][2C] per-frame aux projections
-    const void* dfac;       // dilated factors row (double or float)
-    const int* known;       // [n0] padded known prefix (sample ids)
-    const int64_t* teacher; // optional [n_samples]
-    int64_t* out;           // [n_samples]
-    float* logits;          // optional [n_samples][Q]
-    float* ring;            // ring block of this utterance (zeroed before launch)
+struct UttDesc {            // offsets into the base pointers of DecodeParams (kernel-argument pointers keep
+                            // the GLOBAL address space; pointers loaded from memory would become FLAT accesses)
+    int64_t pproj;          // floats: [F][L][2C] per-frame aux projections
+    int64_t dfac;           // elements: dilated factors row (double or float)
+    int64_t known;          // ints: [n0] padded known prefix (sample ids)
+    int64_t teacher;        // int64s: optional [n_samples], -1 = none
+    int64_t out;            // int64s: [n_samples]
+    int64_t logits;         // floats: optional [n_samples][Q], -1 = none
+    int64_t ring;           // floats: ring block of this utterance (zeroed before launch)
     int n_pad, n0, n_samples, d_is_f32;
     int64_t F;
 };
@@ -84,11 +85,14 @@ struct DecodeParams {
     const float* qb;        // [L][2C]
     const Task* tasks;
     const UttDesc* utts;
+    const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
     int* status;
     int n_slots;
     int C, Cp, S, Q, L, U, mode;
     int64_t causal_w, causal_b, up_w;
-    int o_xbuf, o_xp, o_pd, o_auxv, o_g, o_skf, o_ska, o_y1, o_y2, o_lg, o_samp, lds_floats;
+    int o_xbuf, o_xp, o_pd, o_auxv, o_g, o_skf, o_ska, o_y1, o_y2, o_lg, o_samp, o_sel, state_floats;
+    int o_bias, n_bias, o_tasks, lds_floats;
+    const int* bias_src;    // [n_bias] flat indices of the biases mirrored in LDS
     unsigned long long seed;
     RingDesc rings[QPN_MAX_LAYERS];
 };
