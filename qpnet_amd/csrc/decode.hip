@@ -18,6 +18,7 @@
 #include "qpn_handle.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDes
 }
 
 // pitch-dependent tap distance of ring `r` at (padded) time t  (qpnet.py:613-624)
-__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int64_t ut) {
+__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int ut) {
     if (!r.adaptive) return r.mult;
     if (ut < 0) return r.mult;                       // d := 1.0 in the left padding (qpnet.py:361-364)
     if (u.d_is_f32) {
@@ -218,10 +219,10 @@ __device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, i
 __device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& u, int64_t t1, int tid, int nthreads) {
     float* sm = SM;
     const int n = p.L * 2 * p.C;
-    const int64_t ut = t1 - u.n_pad;
-    int64_t f; int j;
+    const int ut = (int)t1 - u.n_pad;                // 32-bit: n0 + n_samples < 2^31 is checked on the host
+    int f, j;
     if (ut < 0) { f = 0; j = 0; }                    // replicate pad of the upsampled h (qpnet.py:359)
-    else if (p.U > 0) { f = ut / p.U; j = (int)(ut - f * p.U); }
+    else if (p.U > 0) { f = (int)((unsigned)ut / (unsigned)p.U); j = ut - f * p.U; }
     else { f = ut; j = 0; }
     const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f;
     const float* pf = u.pproj + (size_t)f * n;
@@ -232,7 +233,7 @@ __device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& 
 __device__ __forceinline__ void stage_taps(const DecodeParams& p, const UttView& u, int64_t t2, int tid, int nthreads, int* status) {
     const int L = p.L, C = p.C;
     float* sm = SM; int* smi = SMI;
-    const int64_t ut = t2 - u.n_pad;
+    const int ut = (int)t2 - u.n_pad;
     for (int i = tid; i < L * C; i += nthreads) {
         const int l = i / C, c = i - l * C;
         const RingDesc r = p.rings[l];
@@ -240,8 +241,8 @@ __device__ __forceinline__ void stage_taps(const DecodeParams& p, const UttView&
         if (off < 1 || off >= r.len) { if (c == 0) atomicOr(status, 1); off = off < 1 ? 1 : r.len - 1; }
         if (c == 0) smi[p.o_sel + l] = off == 1;
         if (off > 1) {
-            const int64_t tp = t2 - off;              // time of the past tap; < 0 -> zeros (ring is zero-filled)
-            const int slot = (int)(((tp % r.len) + r.len) % r.len);
+            const int tp = (int)t2 - off;             // time of the past tap; < 0 -> a never-written (zero) slot
+            const int slot = tp >= 0 ? (int)((unsigned)tp % (unsigned)r.len) : tp + r.len;
             sm[p.o_xp + l * p.Cp + c] = ld_agent(u.ring + r.base + (size_t)slot * C + c);
         }
     }
@@ -254,7 +255,7 @@ __device__ __forceinline__ void causal_rows(const DecodeParams& p, const UttView
         float v = p.flat[p.causal_w + ((size_t)ch * p.Q + s_prev) * 2] + p.flat[p.causal_w + ((size_t)ch * p.Q + s_cur) * 2 + 1];
         v = v + p.flat[p.causal_b + ch];
         sm[p.o_xbuf + ch] = v;
-        st_agent(u.ring + r0.base + (size_t)(t1 % r0.len) * p.C + ch, v);
+        st_agent(u.ring + r0.base + (size_t)((unsigned)t1 % (unsigned)r0.len) * p.C + ch, v);
     }
 }
 
@@ -416,6 +417,234 @@ __global__ __launch_bounds__(QPN_NT) void k_decode(DecodeParams p) {
     }
 }
 
+
+// ================================================================== specialised straight-line decode kernel
+// Same algorithm, state and bit-exact arithmetic as k_decode, but for geometries whose per-layer tiles fit one
+// round of 16 waves (2*NZ <= 16: n_resch <= 64) the per-step program is compiled as straight-line code with a
+// STATIC tile assignment instead of being interpreted from the task table: ~45 instructions per tile instead of
+// ~170, addresses and LDS offsets folded, reductions chosen at compile time.  (In-kernel stamps showed the
+// interpreter spends ~1500 cycles of pure instruction issue per slot; the memory system was idle half the time.)
+//   Z phase (per layer)  waves [0,NZ): this step's z tiles + gate      waves [NZ,2NZ): next step's past-tap dots
+//   R phase              waves [0,NRES): residual 1x1 (-> next layer)  the others: skip 1x1 rows, the NSKD tiles
+//                        that do not fit are deferred to the tail (their dots are parked and summed in layer order)
+//   tail                 deferred skip dots -> skip total/relu -> post 1x1 #1 -> post 1x1 #2 -> argmax/causal/staging
+// Each wave requests its next layer's two tiles one full layer ahead (plain loads, counted waits by hipcc).
+template <int V> struct ILog2 { static constexpr int v = 1 + ILog2<V / 2>::v; };
+template <> struct ILog2<1> { static constexpr int v = 0; };
+
+template <int LOGR>
+__device__ __forceinline__ float tree_reduce_c(float acc) {
+    if constexpr (LOGR == 5) { acc = acc + __shfl_xor(acc, 16); }
+    if constexpr (LOGR >= 4) { acc = acc + dpp_f<0x128>(acc); }
+    if constexpr (LOGR >= 3) { if constexpr (LOGR == 3) acc = acc + __shfl_xor(acc, 4); else acc = acc + dpp_f<0x124>(acc); }
+    if constexpr (LOGR >= 2) { acc = acc + dpp_f<0x4E>(acc); }
+    if constexpr (LOGR >= 1) { acc = acc + dpp_f<0xB1>(acc); }
+    return acc;
+}
+__device__ __forceinline__ void read_x(float4 (&x)[4], int xoff_plus_16q) {
+    const float4* xv = (const float4*)(SM + xoff_plus_16q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = xv[j];
+}
+
+template <int C, int S, int Q>
+__global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastParams f) {
+    constexpr int R = C / 16, LOGR = ILog2<R>::v, RPT = 64 / R;
+    constexpr int NZ = 2 * C / RPT, NRES = C / RPT, NSK = S / RPT;
+    constexpr int NSKI = NSK < QPN_NW - NRES ? NSK : QPN_NW - NRES, NSKD = NSK - NSKI;
+    constexpr int RS = S / 16, LOGRS = ILog2<RS>::v, RPTS = 64 / RS;
+    constexpr int NP1 = S / RPTS, NP2 = Q / RPTS;
+    static_assert(2 * NZ <= QPN_NW && NRES <= QPN_NW && R <= 8 && RS <= 32, "geometry not covered by the fast kernel");
+    static_assert(NSKD * RPT <= 64, "deferred skip rows exceed the parking area");
+    float* sm = SM; int* smi = SMI;
+    const UttView u = make_view(p, p.utts[blockIdx.x]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int L = p.L;
+    for (int i = tid; i < p.state_floats; i += QPN_NT) sm[i] = 0.0f;
+    for (int i = tid; i < p.n_bias; i += QPN_NT) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
+    __syncthreads();
+    const int Ttot = u.n0 + u.n_samples;
+    if (Ttot < 3) return;
+    if (wave == 0) {
+        causal_rows(p, u, u.known[0], u.known[1], 1, lane);
+        if (lane == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.known[1]; }
+    }
+    stage_aux(p, u, 1, tid, QPN_NT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (Ttot > 3) stage_taps(p, u, 2, tid, QPN_NT, p.status);
+    __syncthreads();
+
+    const int q0 = lane & (R - 1), grp0 = lane >> LOGR;
+    const int qs0 = lane & (RS - 1), grps0 = lane >> LOGRS;
+    const bool zrole = wave < NZ, prole = !zrole && wave < 2 * NZ;
+    const int ztile = zrole ? wave : wave - NZ;
+    const bool rrole = wave < NRES, srole = !rrole && wave - NRES < NSKI;
+    const int rtile = rrole ? wave : wave - NRES;
+    const float4* wl0 = p.wpk + lane;
+    const int C2 = 2 * C, LC2 = L * C2;
+    float4 wz[4], wr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wz[j] = wr[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (zrole || prole) { const float4* t = wl0 + (zrole ? f.w_cur[0] : f.w_past[0]) + ztile * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wz[j] = t[j * 64]; }
+    if (rrole || srole) { const float4* t = wl0 + (rrole ? f.w_res[0] : f.w_skip[0]) + rtile * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[j] = t[j * 64]; }
+
+    for (int t = 1; t + 1 < Ttot; ++t) {
+        // hipcc hoists every lane-constant address out of the step loop and then spills them (128-VGPR budget):
+        // an opaque zero re-derives the few bases per step instead, so nothing derived from them can be hoisted
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const float4* wl = wl0 + zero;
+        const int q = q0 + zero, grp = grp0 + zero, qs = qs0 + zero, grps = grps0 + zero;
+        const int par = (t & 1) * LC2;
+        for (int l = 0; l < L; ++l) {
+            const int ln = l + 1 < L ? l + 1 : 0;
+            wg_barrier();                                   // layer input x_l, pd[par], aux terms are in LDS
+            // ---- Z phase
+            if (zrole) {
+                float4 x[4]; read_x(x, p.o_xbuf + l * p.Cp + 16 * q);
+                const float acc = tree_reduce_c<LOGR>(chunk16(wz, x));
+                const int row = ztile * RPT + grp, ch = row >> 1, half = row & 1, nat = half * C + ch;
+                const float z = (acc + sm[p.o_pd + par + l * C2 + nat]) + sm[p.o_auxv + l * C2 + nat];
+                const float zo = dpp_f<0x100 + R>(z);       // row_shl:R -> the tanh group's pre-activation
+                if (q == 0 && !half) sm[p.o_gl + l * p.Cp + ch] = qgate(z, zo);
+            } else if (prole) {
+                const int xo = smi[p.o_sel + l] ? p.o_xbuf + l * p.Cp : p.o_xp + l * p.Cp;
+                float4 x[4]; read_x(x, xo + 16 * q);
+                const float acc = tree_reduce_c<LOGR>(chunk16(wz, x));
+                if (q == 0) sm[p.o_pd + (LC2 - par) + l * C2 + ztile * RPT + grp] = acc;    // next step's parity
+            }
+            // this wave's Z-phase tile of the next layer is requested as soon as the current one has been consumed
+            if (l + 1 < L && (zrole || prole)) { const float4* tp = wl + (zrole ? f.w_cur[ln] : f.w_past[ln]) + ztile * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wz[j] = tp[j * 64]; }
+            wg_barrier();                                   // gate vector g_l is in LDS
+            // ---- R phase
+            if (rrole) {
+                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
+                const float acc = tree_reduce_c<LOGR>(chunk16(wr, x));
+                const int row = rtile * RPT + grp;
+                if (q == 0) {
+                    const float v = (acc + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row];
+                    sm[p.o_xbuf + (l + 1) * p.Cp + row] = v;
+                    if (l + 1 < L) { const RingDesc r = p.rings[l + 1]; st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + row, v); }
+                }
+            } else if (srole) {
+                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
+                const float acc = tree_reduce_c<LOGR>(chunk16(wr, x));
+                const int row = rtile * RPT + grp;
+                if (q == 0) { const int a = (f.adaptive[l] ? p.o_ska : p.o_skf) + row; sm[a] = sm[a] + (acc + sm[f.b_skip[l] + row]); }
+            }
+            if (l + 1 < L && (rrole || srole)) { const float4* tp = wl + (rrole ? f.w_res[ln] : f.w_skip[ln]) + rtile * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wr[j] = tp[j * 64]; }
+        }
+        // ---- tail: deferred skip rows (dots parked per layer, summed in layer order below)
+        if constexpr (NSKD > 0) {
+            for (int d = wave; d < L * NSKD; d += QPN_NW) {
+                const int l = d / NSKD, k = d - l * NSKD;
+                float4 w[4]; const float4* tp = wl + f.w_skip[l] + (NSKI + k) * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = tp[j * 64];
+                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
+                const float acc = tree_reduce_c<LOGR>(chunk16(w, x));
+                if (q == 0) sm[p.o_sdef + l * 64 + k * RPT + grp] = acc + sm[f.b_skip[l] + (NSKI + k) * RPT + grp];
+            }
+        }
+        // first post-1 tile of this wave is requested before the barrier
+        float4 (&wa)[4] = wz; float4 (&wb)[4] = wr;       // the layer tile sets are idle during the tail
+        constexpr int T1 = (NP1 + QPN_NW - 1) / QPN_NW, T2 = (NP2 + QPN_NW - 1) / QPN_NW;
+        if (wave < NP1) { const float4* tp = wl + f.w_p1 + wave * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = tp[j * 64]; }
+        wg_barrier();
+        // skip total: rows handled in the R phases already hold their sums; deferred rows are summed now, in layer order
+        for (int row = tid; row < S; row += QPN_NT) {
+            float aF = sm[p.o_skf + row], aA = sm[p.o_ska + row];
+            if (NSKD > 0 && row >= NSKI * RPT) {
+                const int rl = row - NSKI * RPT;
+                for (int l = 0; l < L; ++l) { const float v = sm[p.o_sdef + l * 64 + rl]; if (f.adaptive[l]) aA = aA + v; else aF = aF + v; }
+            }
+            const float tot = aF + aA;                      // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
+            sm[p.o_y1 + row] = tot > 0.0f ? tot : 0.0f;
+        }
+        wg_barrier();
+#pragma unroll
+        for (int i = 0; i < T1; ++i) {
+            const int tile = wave + i * QPN_NW;
+            if (i + 1 < T1 && tile + QPN_NW < NP1) { const float4* tp = wl + f.w_p1 + (tile + QPN_NW) * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wb[j] = tp[j * 64]; }
+            if (tile < NP1) {
+                float4 x[4]; read_x(x, p.o_y1 + 16 * qs);
+                const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
+                const int row = tile * RPTS + grps;
+                if (qs == 0) { const float v = acc + sm[f.b_p1 + row]; sm[p.o_y2 + row] = v > 0.0f ? v : 0.0f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+        }
+        if (wave < NP2) { const float4* tp = wl + f.w_p2 + wave * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = tp[j * 64]; }
+        wg_barrier();
+#pragma unroll
+        for (int i = 0; i < T2; ++i) {
+            const int tile = wave + i * QPN_NW;
+            if (i + 1 < T2 && tile + QPN_NW < NP2) { const float4* tp = wl + f.w_p2 + (tile + QPN_NW) * 256;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wb[j] = tp[j * 64]; }
+            if (tile < NP2) {
+                float4 x[4]; read_x(x, p.o_y2 + 16 * qs);
+                const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
+                const int row = tile * RPTS + grps;
+                if (qs == 0) sm[p.o_lg + row] = acc + sm[f.b_p2 + row];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+        }
+        // ---- end of step: pick the sample, look up the next layer-0 input, stage aux terms / past rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's ring rows have left the CU
+        wg_barrier();
+        // layer-0 tiles of the next step fly while the sample is picked
+        if (zrole || prole) { const float4* tp = wl + (zrole ? f.w_cur[0] : f.w_past[0]) + ztile * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wz[j] = tp[j * 64]; }
+        if (rrole || srole) { const float4* tp = wl + (rrole ? f.w_res[0] : f.w_skip[0]) + rtile * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[j] = tp[j * 64]; }
+        if (wave == 0) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const int i = t - (u.n0 - 1);
+            if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
+            int next;
+            if (i >= 0) {
+                next = bi;
+                if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
+                if (lane == 0) u.out[i] = bi;
+            } else next = u.known[t + 1];
+            const int cur = smi[p.o_samp + 1];
+            if (t + 2 < Ttot) causal_rows(p, u, cur, next, t + 1, lane);
+            if (lane == 0) { smi[p.o_samp] = cur; smi[p.o_samp + 1] = next; }
+        } else {
+            const int stid = (wave - 1) * 64 + lane, nst = (QPN_NW - 1) * 64;
+            for (int i = stid; i < S; i += nst) { sm[p.o_skf + i] = 0.0f; sm[p.o_ska + i] = 0.0f; }
+            if (t + 2 < Ttot) stage_aux(p, u, t + 1, stid, nst);
+            if (t + 3 < Ttot) stage_taps(p, u, t + 2, stid, nst, p.status);
+        }
+    }
+}
+
 // ================================================================== host side
 static thread_local char g_err[512] = "";
 void qpn_set_error(const char* fmt, ...) {
@@ -524,7 +753,7 @@ static int build_program(qpn_handle* h) {
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     p.o_xbuf = take((L + 1) * g.Cp); p.o_xp = take(L * g.Cp); p.o_pd = take(2 * L * 2 * C); p.o_auxv = take(L * 2 * C);
     p.o_g = take(g.Cp); p.o_skf = take(S); p.o_ska = take(S); p.o_y1 = take(g.Sp); p.o_y2 = take(g.Sp); p.o_lg = take(Q);
-    p.o_samp = take(4); p.o_sel = take(L); p.state_floats = o;
+    p.o_samp = take(4); p.o_sel = take(L); p.o_gl = take(L * g.Cp); p.o_sdef = take(L * 64); p.state_floats = o;
     // ... then the biases the epilogues add (so no global load sits behind the weight prefetch queue)
     std::vector<int>& bsrc = h->h_bias_src; bsrc.clear();
     auto bias_block = [&](int64_t flat_off, int n) { int r = p.o_bias + (int)bsrc.size(); for (int i = 0; i < n; ++i) bsrc.push_back((int)(flat_off + i)); return r; };
@@ -561,6 +790,8 @@ static int build_program(qpn_handle* h) {
         // Z phase: this step's pre-activations + the NEXT step's past-tap dots of the same layer (the
         // past rows are known one step early, so these tiles fill the waves the z tiles leave idle)
         std::vector<Task> zp, rp;
+        h->fp.w_cur[l] = off_cur; h->fp.w_past[l] = off_past; h->fp.w_res[l] = off_res; h->fp.w_skip[l] = off_skip;
+        h->fp.b_res[l] = lds_br[l]; h->fp.b_skip[l] = lds_bs[l]; h->fp.adaptive[l] = y.adaptive;
         tile_tasks(zp, OP_Z, off_cur, 2 * C, g.Cp, p.o_xbuf + l * g.Cp, l * 2 * C, 0, p.o_g, 0, 0);
         tile_tasks(zp, OP_PAST, off_past, 2 * C, g.Cp, p.o_xp + l * g.Cp, l * 2 * C, p.o_xbuf + l * g.Cp, l, 0, 0);
         tile_tasks(rp, OP_RES, off_res, C, g.Cp, p.o_g, p.o_xbuf + l * g.Cp, lds_br[l], p.o_xbuf + (l + 1) * g.Cp, l + 1 < L ? l + 1 : -1, 0);
@@ -572,6 +803,7 @@ static int build_program(qpn_handle* h) {
     }
     int off_p1 = pack_matrix(map, S, S, g.Sp, [&](int row, int k) { return g.post1_w + (int64_t)row * S + k; });
     int off_p2 = pack_matrix(map, Q, S, g.Sp, [&](int row, int k) { return g.post2_w + (int64_t)row * S + k; });
+    h->fp.w_p1 = off_p1; h->fp.w_p2 = off_p2; h->fp.b_p1 = lds_b1; h->fp.b_p2 = lds_b2;
     std::vector<Task> p1, p2, pa;
     tile_tasks(p1, OP_POST1, off_p1, S, g.Sp, p.o_y1, 0, lds_b1, p.o_y2, 0, 0);
     tile_tasks(p2, OP_POST2, off_p2, Q, g.Sp, p.o_y2, 0, lds_b2, p.o_lg, 0, 0);
@@ -767,10 +999,20 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
     p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
-    if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024)
+    if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024) {
         QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
+    }
     QPN_HIP(hipEventRecord(h->ev0, stream));
-    hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), (size_t)p.lds_floats * sizeof(float), stream, p);
+    const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
+    const size_t lds_bytes = (size_t)p.lds_floats * sizeof(float);
+    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256)
+        hipLaunchKernelGGL((k_decode_fast<64, 256, 256>), dim3(B), dim3(QPN_NT), lds_bytes, stream, p, h->fp);
+    else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256)
+        hipLaunchKernelGGL((k_decode_fast<32, 32, 256>), dim3(B), dim3(QPN_NT), lds_bytes, stream, p, h->fp);
+    else
+        hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), lds_bytes, stream, p);
     QPN_HIP(hipGetLastError());
     QPN_HIP(hipEventRecord(h->ev1, stream));
     h->pending = true;

@@ -79,6 +79,14 @@ struct UttDesc {            // offsets into the base pointers of DecodeParams (k
     int64_t F;
 };
 
+// per-layer tile / bias locations for the specialised straight-line decode kernel (k_decode_fast)
+struct FastParams {
+    int w_cur[QPN_MAX_LAYERS], w_past[QPN_MAX_LAYERS], w_res[QPN_MAX_LAYERS], w_skip[QPN_MAX_LAYERS];   // float4 offsets
+    int b_res[QPN_MAX_LAYERS], b_skip[QPN_MAX_LAYERS];                                                   // LDS float offsets
+    int adaptive[QPN_MAX_LAYERS];
+    int w_p1, w_p2, b_p1, b_p2;
+};
+
 struct DecodeParams {
     const float4* wpk;
     const float* flat;
@@ -92,6 +100,7 @@ struct DecodeParams {
     int64_t causal_w, causal_b, up_w;
     int o_xbuf, o_xp, o_pd, o_auxv, o_g, o_skf, o_ska, o_y1, o_y2, o_lg, o_samp, o_sel, state_floats;
     int o_bias, n_bias, o_tasks, lds_floats;
+    int o_gl, o_sdef;       // specialised kernel: per-layer gate vectors [L][Cp], deferred skip dots [L][64]
     const int* bias_src;    // [n_bias] flat indices of the biases mirrored in LDS
     unsigned long long seed;
     RingDesc rings[QPN_MAX_LAYERS];

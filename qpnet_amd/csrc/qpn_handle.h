@@ -15,6 +15,7 @@ struct qpn_handle {
     int n_slots;
     int aux_woff4, aux_tiles, logRa;
     DecodeParams dp;                 // template (pointers filled per call)
+    FastParams fp;                   // tile map of the specialised kernel
     int* d_map; float* d_wpk; Task* d_tasks; float* d_qb; BiasDesc* d_bd; int* d_status; int* d_bias_src;
     std::vector<int> h_bias_src;
     const float* d_flat; bool have_weights;
