@@ -252,20 +252,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--mode", default="train", choices=["decode", "train"])
+    ap.add_argument("--mode", default="all", choices=["all", "decode", "train"],
+                    help="all (default) = train step as the headline value (BASELINE config[1]) + a 'decode' object (config[3]) at N=1")
     ap.add_argument("--batch", type=int, default=20, help="utterances per GPU (reference decode_batch_size = 20, runQP.py:66)")
     ap.add_argument("--frames", type=int, default=2005, help="frames per utterance (2005 -> 10 s @22.05 kHz)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 50 if args.mode == "train" else 3
+        args.steps = 3 if args.mode == "decode" else 50
     if args.warmup is None:
-        args.warmup = 5 if args.mode == "train" else 1
+        args.warmup = 1 if args.mode == "decode" else 5
     rank, local, world = dist_setup(args.gpus)
     if args.mode == "decode":
         out = run_decode(args, rank, local, world)
     else:
         out = run_train(args, rank, local, world)
+        if args.mode == "all" and world == 1:
+            # the other half of BASELINE.json's metric: AR decode samples/sec/GPU (same JSON line)
+            import copy
+            a2 = copy.copy(args); a2.steps, a2.warmup = 2, 1
+            out["decode"] = run_decode(a2, rank, local, world)
+            a3 = copy.copy(a2); a3.batch, a3.no_cpu = 1, True
+            d1 = run_decode(a3, rank, local, world)
+            out["decode"]["batch1"] = {"value": d1["value"], "unit": d1["unit"], "ms_per_step": d1["ms_per_step"],
+                                       "kernel_ms": d1["roofline"]["kernel_ms"]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

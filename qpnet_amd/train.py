@@ -134,9 +134,8 @@ class FusedTrainer:
                                      self._dlogits.data_ptr(), C.byref(loss) if want_loss else None, stream))
             _lib.check(L.qpn_train_backward(hd, self._dlogits.data_ptr(), self.g.data_ptr(), stream))
             if self.world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(self.g, group=self.pg)
-                self.g.mul_(1.0 / self.world)
+                from .parallel import allreduce_mean_gradient
+                allreduce_mean_gradient(self.g, B * BL, group=self.pg)
             self.step_count += 1
             _lib.check(L.qpn_adam_step(hd, flat.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), flat.numel(),
                                        self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, stream))

@@ -1,0 +1,83 @@
+"""CPU, world_size 2 over gloo: the data-parallel step (chunk sharding + one weighted flat-gradient all-reduce
++ identical Adam on every rank) equals single-process training on the union of the two ranks' rows.
+Gradients come from the numpy oracle here (the HIP kernels need a GPU); the exchange code is the product's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from qpnet_amd import synth, parallel
+    from qpnet_amd.config import TINY
+    from oracle import train_oracle as TO
+    cfg = TINY
+    flat = synth.make_weights(cfg, 3 + rank)          # deliberately different: broadcast must fix it
+    ft = torch.from_numpy(flat)
+    parallel.broadcast_parameters(ft, 0)
+    flat = ft.numpy().copy()
+    opt = TO.Adam(flat.size)
+    chunks = parallel.shard_indices(4, rank, world)   # 4 chunks -> 2 steps of 2 ranks
+    bls = [300, 410, 350, 280]                        # unequal batch_length across ranks
+    for step, ci in enumerate(chunks):
+        x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
+        lg, caches = TO.forward(cfg, flat, x, h, d, b)
+        BL = int(b[0])
+        loss, dl = TO.ce_loss(lg, t[:, -BL:])
+        g = torch.from_numpy(TO.backward(cfg, flat, caches, dl))
+        parallel.allreduce_mean_gradient(g, x.shape[0] * BL)
+        opt.step(flat, g.numpy())
+    out[rank] = flat
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_global_batch():
+    mp.set_start_method("spawn", force=True)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [mp.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    w0, w1 = out[0], out[1]
+    np.testing.assert_array_equal(w0, w1)             # replicas stay bit-identical
+    # single-process reference: each step = mean CE over the rows of both chunks of that step
+    sys.path.insert(0, ROOT)
+    from qpnet_amd import synth
+    from qpnet_amd.config import TINY
+    from oracle import train_oracle as TO
+    cfg = TINY
+    flat = synth.make_weights(cfg, 3)
+    opt = TO.Adam(flat.size)
+    bls = [300, 410, 350, 280]
+    for step in range(2):
+        gs, ns = [], []
+        for ci in (2 * step, 2 * step + 1):
+            x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
+            lg, caches = TO.forward(cfg, flat, x, h, d, b)
+            BL = int(b[0])
+            _, dl = TO.ce_loss(lg, t[:, -BL:])
+            gs.append(TO.backward(cfg, flat, caches, dl)); ns.append(BL)
+        g = (gs[0] * ns[0] + gs[1] * ns[1]) / (ns[0] + ns[1])
+        opt.step(flat, g.astype(np.float32))
+    np.testing.assert_allclose(w0, flat, atol=2e-7, rtol=0)
+
+
+def test_shard_indices():
+    from qpnet_amd.parallel import shard_indices
+    assert shard_indices(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
