@@ -106,7 +106,7 @@ def dilated_index_gen(d, dilation):
 
 
 def decode(cfg, flat_w, h, d, x, n_samples, maxd=None, teacher=None, d_is_f32=False,
-           want_margin=False, want_logits=False):
+           want_margin=False, want_logits=False, mode="argmax", seed=0, row=0):
     """One utterance of batch_fast_generate(mode="argmax") (or teacher-forced logits).
 
     h: (n_aux, F) float32; d: (T,) float64; x: (n_x,) int64 seed.  Returns dict."""
@@ -126,7 +126,8 @@ def decode(cfg, flat_w, h, d, x, n_samples, maxd=None, teacher=None, d_is_f32=Fa
     rc = lib().qpo_decode(C.byref(_cfg(cfg)), _p(flat_w, C.c_float), _p(h, C.c_float), C.c_int64(h.shape[1]),
                           _p(d, C.c_double), C.c_int64(d.size), _p(x, C.c_int64), C.c_int64(x.size),
                           C.c_int64(n_samples), C.c_int(maxd), _p(teacher, C.c_int64), C.c_int(int(d_is_f32)),
-                          _p(out, C.c_int64), _p(margin, C.c_float), _p(logits, C.c_float))
+                          _p(out, C.c_int64), _p(margin, C.c_float), _p(logits, C.c_float),
+                          C.c_int(1 if mode == "sampling" else 0), C.c_uint64(seed), C.c_int(row))
     if rc != 0:
         raise RuntimeError("qpo_decode failed rc=%d" % rc)
     return {"samples": out, "margin": margin, "logits": logits}
@@ -145,18 +146,18 @@ def forward(cfg, flat_w, x, h, d, batch_length):
     return r["logits"]
 
 
-def batch_fast_generate(cfg, flat_w, x, h, n_samples_list, dilated_factors, mode="argmax"):
+def batch_fast_generate(cfg, flat_w, x, h, n_samples_list, dilated_factors, mode="argmax", seed=0):
     """Batch semantics of QPNet.batch_fast_generate (qpnet.py:314-559): rows are independent,
     padding uses the batch-level ceil(max d); results are returned in completion order
     (ascending length, stable) and `n_samples_list` is consumed the way the reference does."""
-    assert mode == "argmax"
     d = np.asarray(dilated_factors)
     d_is_f32 = d.dtype == np.float32
     maxd = int(np.nanmax(np.ceil(d)))
     order = sorted(range(len(n_samples_list)), key=lambda i: n_samples_list[i])
     outs = []
     for i in order:
-        r = decode(cfg, flat_w, h[i], d[i].astype(np.float64), x[i], n_samples_list[i], maxd=maxd, d_is_f32=d_is_f32)
+        r = decode(cfg, flat_w, h[i], d[i].astype(np.float64), x[i], n_samples_list[i], maxd=maxd, d_is_f32=d_is_f32,
+                   mode=mode, seed=seed, row=i)
         outs.append(r["samples"])
     keep = n_samples_list[order[-1]]
     del n_samples_list[:]

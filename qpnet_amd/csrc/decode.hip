@@ -23,6 +23,11 @@
 #include <algorithm>
 
 // ================================================================== device helpers
+// File-scope LDS symbol: device functions index it directly, so the compiler keeps address space 3
+// (a generic float* would turn every LDS access into a FLAT op that also waits on the global-load queue).
+extern __shared__ float4 qpn_lds[];
+#define SM ((float*)qpn_lds)
+#define SMI ((int*)qpn_lds)
 __device__ __forceinline__ float qexp(float x) {
     x = fminf(fmaxf(x, -87.0f), 88.0f);
     float n = rintf(x * 0x1.715476p+0f);
@@ -180,12 +185,50 @@ __global__ void k_known(const int64_t* __restrict__ x, int n_x, int n_pad, int Q
     }
 }
 
+
+// ---------------------------------------------------------------- sampling mode (reference qpnet.py:507-510)
+// softmax + categorical draw by inverse CDF with a counter-based generator (Philox4x32-10, counter = (step, row),
+// key = seed), in the fixed order of DESIGN.md §3 so that the CPU oracle reproduces every draw bit for bit.
+// (Parity with the reference's torch.Generator stream is statistical only.)  One wave, Q = 64 * per, per <= 4.
+__device__ __forceinline__ unsigned philox_first(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
+    unsigned c2 = 0, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+__device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long seed, unsigned row, unsigned step, int lane) {
+    const float* lg = SM + o_lg;
+    const int per = Q >> 6;
+    float l[4], e[4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { l[j] = j < per ? lg[lane * per + j] : -INFINITY; m = fmaxf(m, l[j]); }
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = j < per ? qexp(l[j] - m) : 0.0f;
+    float a = e[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (j < per) a = a + e[j];
+    float v = a;
+    for (int d = 1; d < 64; d <<= 1) { const float up = __shfl_up(v, d); if (lane >= d) v = v + up; }
+    const float total = __shfl(v, 63);
+    float c = __shfl_up(v, 1);
+    if (lane == 0) c = 0.0f;
+    const float u = (float)(philox_first(step, row, (unsigned)seed, (unsigned)(seed >> 32)) >> 8) * 0x1p-24f;
+    const float th = u * total;
+    int idx = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j < per) { c = c + e[j]; if (idx == 0x7fffffff && c > th) idx = lane * per + j; }
+    for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(idx, s); idx = o < idx ? o : idx; }
+    return idx == 0x7fffffff ? Q - 1 : idx;
+}
+
 // ================================================================== the persistent decode kernel
-// File-scope LDS symbol: device functions index it directly, so the compiler keeps address space 3
-// (a generic float* would turn every LDS access into a FLAT op that also waits on the global-load queue).
-extern __shared__ float4 qpn_lds[];
-#define SM ((float*)qpn_lds)
-#define SMI ((int*)qpn_lds)
 struct UttView {            // per-utterance pointers derived from kernel-argument bases (global address space)
     const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
     int n_pad, n0, n_samples, d_is_f32;
@@ -358,6 +401,7 @@ __device__ __forceinline__ void run_slot(const Ctx& c, int slot, int64_t t, floa
         if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
         int next;
         if (i >= 0) {
+            if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, blockIdx.x, (unsigned)i, lane);
             next = bi;
             if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
             if (lane == 0) u.out[i] = bi;
@@ -629,6 +673,7 @@ __global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastPara
             if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
             int next;
             if (i >= 0) {
+                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, blockIdx.x, (unsigned)i, lane);
                 next = bi;
                 if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
                 if (lane == 0) u.out[i] = bi;
@@ -946,7 +991,8 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     int rc = need_device(h); if (rc) return rc;
     if (!h->have_weights) { qpn_set_error("qpn_set_weights must be called before qpn_decode"); return QPN_ESTATE; }
     if (B < 1 || n_x < 1 || F < 1 || !d_x || !d_h || !d_dfac || !h_n_samples || !d_out || maxd < 1) { qpn_set_error("bad decode arguments"); return QPN_EINVAL; }
-    if (mode != QPN_MODE_ARGMAX) { qpn_set_error("mode %d not implemented in this build (argmax only)", mode); return QPN_EINVAL; }
+    if (mode != QPN_MODE_ARGMAX && mode != QPN_MODE_SAMPLING) { qpn_set_error("mode must be QPN_MODE_ARGMAX or QPN_MODE_SAMPLING"); return QPN_EINVAL; }
+    if (mode == QPN_MODE_SAMPLING && (h->g.Q % 64 || h->g.Q > 256)) { qpn_set_error("sampling needs n_quantize in {64,128,192,256}"); return QPN_EINVAL; }
     const Geom& g = h->g;
     hipStream_t stream = (hipStream_t)stream_;
     int64_t max_n = 0;

@@ -116,6 +116,9 @@ class QPNet(nn.Module):
         self._handle = None
         self._handle_dev = None
         self.last_decode_kernel_ms = 0.0
+        self.sampling_seed = None          # set to an int to pin the sampling-mode random stream
+        self._n_generate_calls = 0
+        self.last_sampling_seed = None
 
     # ------------------------------------------------------------------ native handle
     def _native(self, device):
@@ -166,8 +169,6 @@ class QPNet(nn.Module):
         if mode not in ("sampling", "argmax"):
             logging.error("mode should be sampling or argmax")
             sys.exit(1)
-        if mode == "sampling":
-            raise NotImplementedError("sampling decode is scheduled after argmax parity (SURVEY.md §8f rank 1); use mode='argmax'")
         import ctypes as C
         dev = x.device
         L, hd = self._native(dev)
@@ -192,12 +193,18 @@ class QPNet(nn.Module):
         out = torch.empty((B, max(max_n, 1)), dtype=torch.int64, device=dev)
         flat = self.flat_parameters()
         stream = torch.cuda.current_stream(dev).cuda_stream
+        # sampling: a counter-based generator keyed by torch's seed (torch.manual_seed(args.seed) in the reference
+        # decode script, qpnet_decode.py:236-239) plus a per-call counter; draws are reproducible, but they are not
+        # torch.distributions.Categorical's stream (parity with the reference is statistical in this mode)
+        seed = self.sampling_seed if self.sampling_seed is not None else (torch.initial_seed() + self._n_generate_calls) % (1 << 64)
+        self._n_generate_calls += 1
+        self.last_sampling_seed = seed
         with torch.cuda.device(dev):
             _lib.check(L.qpn_set_weights(hd, flat.data_ptr(), flat.numel(), stream))
             arr = (C.c_int64 * B)(*ns)
             _lib.check(L.qpn_decode(hd, B, xd.shape[1], hd_.shape[2], d_dev.shape[1],
                                     xd.data_ptr(), hd_.data_ptr(), d_dev.data_ptr(), d_is_f32,
-                                    arr, maxd, 0, 0, None, out.data_ptr(), None, stream))
+                                    arr, maxd, 1 if mode == "sampling" else 0, seed, None, out.data_ptr(), None, stream))
             self.last_decode_kernel_ms = float(L.qpn_last_decode_kernel_ms(hd))
         out_np = out.cpu().numpy()
         # completion order + in-place consumption of n_samples_list (reference qpnet.py:527-557)

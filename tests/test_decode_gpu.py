@@ -64,3 +64,25 @@ def test_decode_range_error(cuda):
     with pytest.raises(_lib.QpnError) as e:
         m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode="argmax")
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_sampling_mode_bitwise_vs_oracle(cfgname, cuda, oracle):
+    """mode="sampling" (what the reference decode script runs by default, qpnet_decode.py:312-314): softmax +
+    inverse-CDF draw with Philox4x32-10 in the spec order -> every draw equals the oracle's, B=2 unequal lengths."""
+    import torch
+    from qpnet_amd.config import TINY, PAPER
+    cfg = TINY if cfgname == "tiny" else PAPER
+    flat = synth.make_weights(cfg, 31)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(61, 9, 1.0), (62, 6, 1.0)])
+    m.sampling_seed = 0x1234567890ABCDEF
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="sampling")
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd, mode="sampling", seed=0x1234567890ABCDEF)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+    # different seed -> different stream; sampling is not argmax
+    m.sampling_seed = 7
+    outs2 = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="sampling")
+    assert not np.array_equal(outs[0], outs2[0])
+    assert len(np.unique(outs[1])) > 32

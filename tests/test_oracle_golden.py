@@ -88,3 +88,39 @@ def test_qexp_qgate_accuracy(oracle):
     gq = np.array([L.qpo_qgate(float(u), float(v)) for u, v in zip(a, b)])
     gr = 1 / (1 + np.exp(-a.astype(np.float64))) * np.tanh(b.astype(np.float64))
     assert np.max(np.abs(gq - gr)) < 3e-7
+
+
+def test_philox_known_answer(oracle):
+    """Random123 known-answer vector: Philox4x32-10, counter 0, key 0 -> 0x6627e8d5 (first word)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.qpo_philox_first.restype = C.c_uint32
+    L.qpo_philox_first.argtypes = [C.c_uint32] * 4
+    assert L.qpo_philox_first(0, 0, 0, 0) == 0x6627E8D5
+
+
+def test_sampling_spec_is_softmax_distributed(oracle):
+    """statistical parity with the reference's softmax + Categorical (qpnet.py:507-510): the empirical law of the
+    spec sampler on teacher-forced logits matches softmax(logits) (chi-square over the classes with mass)."""
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    flat = synth.make_weights(cfg, 11, gain=3.0)
+    x, h, d, n = synth.decode_inputs(cfg, 3, 5, 1.0)
+    teacher = np.full(n, 128, dtype=np.int64)      # constant input -> (near) stationary logits after the warm-up
+    r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True, mode="sampling", seed=99)
+    lg = r["logits"][-1].astype(np.float64)
+    p = np.exp(lg - lg.max()); p /= p.sum()
+    # draw many samples from the SAME logits by varying the seed (row/step counters change the stream)
+    draws = []
+    for s in range(40):
+        rr = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, mode="sampling", seed=1000 + s)
+        draws.append(rr["samples"][-60:])
+    draws = np.concatenate(draws)
+    # logits over the last 60 steps are identical up to the aux frame; compare against their mean law
+    lgs = r["logits"][-60:].astype(np.float64)
+    pm = np.exp(lgs - lgs.max(1, keepdims=True)); pm /= pm.sum(1, keepdims=True); pm = pm.mean(0)
+    cnt = np.bincount(draws, minlength=256).astype(np.float64)
+    mask = pm * draws.size >= 5
+    chi2 = ((cnt[mask] - pm[mask] * draws.size) ** 2 / (pm[mask] * draws.size)).sum()
+    dof = mask.sum() - 1
+    assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
