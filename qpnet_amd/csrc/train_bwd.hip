@@ -17,17 +17,19 @@
 #include <math.h>
 
 // ------------------------------------------------------------------------------------------ post-net backward
-// dynamic LDS: P[64][lda(max(Q,S))] | R[64][lda(S)]
+// dynamic LDS: P[TM][lda(max(Q,S))] | R[TM][lda(S)]
+template <int MT>
 __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
+    constexpr int TM = 16 * MT;
     extern __shared__ float sm[];
     const int S = p.S, Q = p.Q, LC = p.LC;
     const int ldp = tr_lda(Q > S ? Q : S), ldr = tr_lda(S);
-    float* P = sm; float* R = sm + 64 * ldp;
-    const int b = blockIdx.y, t0 = blockIdx.x * TR_TM;
+    float* P = sm; float* R = sm + TM * ldp;
+    const int b = blockIdx.y, t0 = blockIdx.x * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTS = S / 16;
     // stage dlogits rows
-    for (int idx = tid; idx < TR_TM * (Q / 2); idx += 512) {
+    for (int idx = tid; idx < TM * (Q / 2); idx += 512) {
         const int r = idx / (Q / 2), k = (idx - r * (Q / 2)) * 2;
         float2 v = make_float2(0.f, 0.f);
         if (t0 + r < p.BL) v = *(const float2*)(bw.dlogits + ((size_t)b * p.BL + t0 + r) * Q + k);
@@ -40,17 +42,17 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
         const int np = pb + wave;
         if (np < npairs) {
             const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
-            f32x4 acc[4][2];
+            f32x4 acc[MT][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<4, 2>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
+            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
                 const int c = 16 * (j ? nt1 : nt0) + (lane & 15);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -71,17 +73,17 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
         const int np = pb + wave;
         if (np < npairs) {
             const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
-            f32x4 acc[4][2];
+            f32x4 acc[MT][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<4, 2>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
+            wave_gemm<MT, 2>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
                 const int c = 16 * (j ? nt1 : nt0) + (lane & 15);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -103,17 +105,17 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
         const int np = pb + wave;
         if (np < lpairs) {
             const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTL) ? 2 * np + 1 : 2 * np;
-            f32x4 acc[4][2];
+            f32x4 acc[MT][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<4, 2>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
+            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
                 const int c = 16 * (j ? nt1 : nt0) + (lane & 15);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -125,16 +127,18 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 }
 
 // ------------------------------------------------------------------------------------------ layer backward
-// dynamic LDS: Dx[64][lda(C)] | Dz[64][lda(2C)]
+// dynamic LDS: Dx[TM][lda(C)] | Dz[TM][lda(2C)]
 // DXin = grads w.r.t. this layer's OUTPUT (A: own-row part, B: scattered part, both zero-filled where unwritten);
 // DXout = grads w.r.t. this layer's INPUT (same two-part form), consumed by layer l-1 / the causal backward.
+template <int MT>
 __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, int l, int last, int pp) {
+    constexpr int TM = 16 * MT;
     extern __shared__ float sm[];
     const TrLayer ly = p.layers[l];
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int ldx = tr_lda(C), ldz = tr_lda(2 * C);
-    float* Dx = sm; float* Dz = sm + 64 * ldx;
-    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TR_TM;
+    float* Dx = sm; float* Dz = sm + TM * ldx;
+    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)b * p.N1;
     (void)pp;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     float* DAout = bw.DXA[0] + (size_t)l * nDX + rb * C; float* DBout = bw.DXB[0] + (size_t)l * nDX + rb * C;
     const int NCG = C / 16;
     // ---- dXout tile
-    for (int idx = tid; idx < TR_TM * (C / 2); idx += 256) {
+    for (int idx = tid; idx < TM * (C / 2); idx += 256) {
         const int r = idx / (C / 2), k = (idx - r * (C / 2)) * 2, n = n0 + r;
         float2 v = make_float2(0.f, 0.f);
         if (!last && n < p.N1) {
@@ -159,13 +163,13 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     float* DZg = bw.DZ + ((size_t)l * p.B * p.N1 + rb) * 2 * C;
     const int win0 = p.N1 - p.BL;
     for (int nt = wave; nt < NCG; nt += 4) {
-        f32x4 acc[4][1];
+        f32x4 acc[MT][1];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
-        if (!last) { const int nts[1] = {nt}; wave_gemm<4, 1>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane); }
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
+        if (!last) { const int nts[1] = {nt}; wave_gemm<MT, 1>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane); }
         const int c = 16 * nt + (lane & 15);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i, n = n0 + r;
@@ -187,14 +191,14 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
     float* DH = bw.DHUP + rb * Ap;
     for (int nt = wave; nt < NTK; nt += 4) {
-        f32x4 acc[4][1];
+        f32x4 acc[MT][1];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm<4, 1>(acc, Dz, ldz, p.wp + ly.w1t_f4, NTK, nts, 2 * C, lane);
+        wave_gemm<MT, 1>(acc, Dz, ldz, p.wp + ly.w1t_f4, NTK, nts, 2 * C, lane);
         const int k = 16 * nt + (lane & 15);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i, n = n0 + r;
@@ -486,21 +490,22 @@ __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
-    const size_t lds_post = (size_t)64 * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
-    const size_t lds_layer = (size_t)64 * (tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
+    constexpr int MT = TR_MT, TM = 16 * MT;
+    const size_t lds_post = (size_t)TM * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
+    const size_t lds_layer = (size_t)TM * (tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
     if (lds_post > 160 * 1024 || lds_layer > 160 * 1024) { qpn_set_error("backward tiles do not fit LDS"); return QPN_EINVAL; }
-    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
-    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
+    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
+    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     QPN_HIP(hipMemsetAsync(bw.DXA[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
     QPN_HIP(hipMemsetAsync(bw.DXB[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
-    hipLaunchKernelGGL(k_post_bwd, dim3((BL + TR_TM - 1) / TR_TM, B), dim3(512), lds_post, stream, p, bw);
+    hipLaunchKernelGGL((k_post_bwd<MT>), dim3((BL + TM - 1) / TM, B), dim3(512), lds_post, stream, p, bw);
     qpn_prof_mark(PG_POST_BWD, stream);
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
-        hipLaunchKernelGGL(k_layer_bwd, dim3((rows + TR_TM - 1) / TR_TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
+        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
     }
     qpn_prof_mark(PG_LAYER_BWD, stream);
     // ---- weight gradients: 4 launches over (time chunk, layer)

@@ -11,7 +11,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define TR_TM 64           // time rows per workgroup tile
+#define TR_MT 2            // 16-row MFMA m-tiles per workgroup tile (32 time rows: more workgroups per CU, smaller tail)
 #define TR_MAXL 32          // layers supported by the training kernels (kernel-argument budget)
 
 // leading dimension for an LDS A-tile read "row = lane&15, k = lane>>4" with ds_read_b32:

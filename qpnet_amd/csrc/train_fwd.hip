@@ -62,21 +62,23 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     }
 }
 
-// dynamic LDS: As[64][lda(Ktp)] | Gs[64][lda(C)]
+// dynamic LDS: As[TM][lda(Ktp)] | Gs[TM][lda(C)],  TM = 16*MT rows of time per workgroup
+template <int MT>
 __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
+    constexpr int TM = 16 * MT;
     extern __shared__ float sm[];
     const TrLayer ly = p.layers[l];
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int lda = tr_lda(Ktp), ldg = tr_lda(C);
-    float* As = sm; float* Gs = sm + 64 * lda;
-    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TR_TM;
+    float* As = sm; float* Gs = sm + TM * lda;
+    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
     const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
     // ---- stage [x_cur | x_past | aux | 0] rows into LDS (float2 granularity: lda is even, not /4)
     const int K2 = Ktp / 2;
-    for (int idx = tid; idx < TR_TM * K2; idx += 256) {
+    for (int idx = tid; idx < TM * K2; idx += 256) {
         const int r = idx / K2, k = (idx - r * K2) * 2;
         const int n = n0 + r;
         float2 v = make_float2(0.f, 0.f);
@@ -94,15 +96,15 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
     float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
     const int NCG = C / 16;
     for (int cg = wave; cg < NCG; cg += 4) {
-        f32x4 acc[4][2];
+        f32x4 acc[MT][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
         const int nts[2] = {cg, NCG + cg};
-        wave_gemm<4, 2>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
+        wave_gemm<MT, 2>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
         const int c = 16 * cg + (lane & 15);
         const float bs = bias1[c], bt = bias1[C + c];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -118,15 +120,15 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
     const float* br = p.bp + ly.biasr;
     float* Xout = p.X + ((size_t)((l + 1) * p.B + b) * p.N1) * C;
     for (int nt = wave; nt < NCG; nt += 4) {
-        f32x4 acc[4][1];
+        f32x4 acc[MT][1];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
+        for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm<4, 1>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
+        wave_gemm<MT, 1>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
         const int c = 16 * nt + (lane & 15);
         const float bb = br[c];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -135,14 +137,16 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
     }
 }
 
-// dynamic LDS: St[64][lda(S)] | Yt[64][lda(S)]  (the two G_l staging buffers alias Yt)
+// dynamic LDS: St[TM][lda(S)] | Yt[TM][max(lda(S), 2 lda(C))]  (the two G_l staging buffers alias Yt)
+template <int MT>
 __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
+    constexpr int TM = 16 * MT;
     extern __shared__ float sm[];
     const int C = p.C, S = p.S, Q = p.Q, L = p.L;
     const int lds = tr_lda(S), ldg = tr_lda(C);
-    float* St = sm; float* Yt = sm + 64 * lds;
-    float* Gb[2] = {Yt, Yt + 64 * ldg};
-    const int b = blockIdx.y, t0 = blockIdx.x * TR_TM;      // rows of the last-BL window
+    float* St = sm; float* Yt = sm + TM * lds;
+    float* Gb[2] = {Yt, Yt + TM * ldg};
+    const int b = blockIdx.y, t0 = blockIdx.x * TM;      // rows of the last-BL window
     const int nbase = p.N1 - p.BL + t0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTS = S / 16, NTQ = Q / 16, NCG = C / 16;
@@ -152,14 +156,14 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         const int np = pb + wave;
         const bool active = np < npairs;
         const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
-        f32x4 acc[4][2];
+        f32x4 acc[MT][2];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
         for (int l = 0; l < L; ++l) {
             float* G = Gb[l & 1];
             const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
             const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
-            for (int idx = tid; idx < TR_TM * (C / 2); idx += 512) {
+            for (int idx = tid; idx < TM * (C / 2); idx += 512) {
                 const int r = idx / (C / 2), k = (idx - r * (C / 2)) * 2;
                 float2 g = make_float2(0.f, 0.f);
                 if (t0 + r < p.BL) {
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
             __syncthreads();
             if (active) {
                 const int nts[2] = {nt0, nt1};
-                wave_gemm<4, 2>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
+                wave_gemm<MT, 2>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
             }
         }
         if (active) {
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int c = 16 * nt + (lane & 15);
                 const float bs = p.bp[p.bias_s + c];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -200,11 +204,11 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         const int np = pb + wave;
         if (np < npairs) {
             const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
-            f32x4 acc[4][2];
+            f32x4 acc[MT][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<4, 2>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
+            wave_gemm<MT, 2>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int c = 16 * nt + (lane & 15);
                 const float bb = p.bp[p.bias_p1 + c];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -230,11 +234,11 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         const int np = pb + wave;
         if (np < qpairs) {
             const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTQ) ? 2 * np + 1 : 2 * np;
-            f32x4 acc[4][2];
+            f32x4 acc[MT][2];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<4, 2>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
+            wave_gemm<MT, 2>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int c = 16 * nt + (lane & 15);
                 const float bb = p.bp[p.bias_p2 + c];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
@@ -289,20 +293,21 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     const int C = p.C, S = p.S;
     hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
     qpn_prof_mark(PG_PREP, stream);
-    const size_t lds_layer = (size_t)64 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
-    const size_t lds_post = (size_t)64 * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
+    constexpr int MT = TR_MT, TM = 16 * MT;
+    const size_t lds_layer = (size_t)TM * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
+    const size_t lds_post = (size_t)TM * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
     if (lds_layer > 160 * 1024 || lds_post > 160 * 1024) {
         qpn_set_error("training kernels: tiles do not fit the 160 KiB LDS for n_resch=%d n_skipch=%d (n_resch <= 128 supported)", C, S);
         return QPN_EINVAL;
     }
-    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
-    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
+    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
+    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
     for (int l = 0; l < p.L; ++l) {
         const int rows = p.N1 - p.layers[l].s_out;
-        hipLaunchKernelGGL(k_layer_fwd, dim3((rows + TR_TM - 1) / TR_TM, p.B), dim3(256), lds_layer, stream, p, l, l == p.L - 1 ? 1 : 0);
+        hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds_layer, stream, p, l, l == p.L - 1 ? 1 : 0);
     }
     qpn_prof_mark(PG_LAYER_FWD, stream);
-    hipLaunchKernelGGL(k_post_fwd, dim3((p.BL + TR_TM - 1) / TR_TM, p.B), dim3(512), lds_post, stream, p);
+    hipLaunchKernelGGL((k_post_fwd<MT>), dim3((p.BL + TM - 1) / TM, p.B), dim3(512), lds_post, stream, p);
     qpn_prof_mark(PG_POST_FWD, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
