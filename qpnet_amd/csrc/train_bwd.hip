@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 }
 
 // ------------------------------------------------------------------------------------------ layer backward
-// dynamic LDS: Dx[TM][lda(C)] | Dz[TM][lda(2C)]
+// dynamic LDS: Dx[TM][lda(C)] | Dz[TM][lda(2C)] | Sg, Th, Dg [TM][lda(C)] each
 // DXin = grads w.r.t. this layer's OUTPUT (A: own-row part, B: scattered part, both zero-filled where unwritten);
 // DXout = grads w.r.t. this layer's INPUT (same two-part form), consumed by layer l-1 / the causal backward.
 template <int MT>
@@ -146,22 +146,38 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const float* DAin = bw.DXA[0] + (size_t)(l + 1) * nDX + rb * C; const float* DBin = bw.DXB[0] + (size_t)(l + 1) * nDX + rb * C;
     float* DAout = bw.DXA[0] + (size_t)l * nDX + rb * C; float* DBout = bw.DXB[0] + (size_t)l * nDX + rb * C;
     const int NCG = C / 16;
-    // ---- dXout tile
-    for (int idx = tid; idx < TM * (C / 2); idx += 256) {
-        const int r = idx / (C / 2), k = (idx - r * (C / 2)) * 2, n = n0 + r;
-        float2 v = make_float2(0.f, 0.f);
-        if (!last && n < p.N1) {
-            const float2 a = *(const float2*)(DAin + (size_t)n * C + k), bb = *(const float2*)(DBin + (size_t)n * C + k);
-            v = make_float2(a.x + bb.x, a.y + bb.y);
-        }
-        *(float2*)(Dx + (size_t)r * ldx + k) = v;
+    // ---- stage dXout (= own-row part + scattered part), the saved gate halves and the skip-path gate grads: 16-byte loads
+    float* Sg = Dz + TM * ldz; float* Th = Sg + TM * ldx; float* Dg = Th + TM * ldx;
+    const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
+    const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
+    const int win0 = p.N1 - p.BL;
+    {
+        const int C4 = C / 4, tpr = C4 < 64 ? C4 : 64, rpp = 256 / tpr;
+        const int tr = tid / tpr, tc = tid - tr * tpr;
+        if (tr < rpp)
+            for (int r = tr; r < TM; r += rpp) {
+                const int n = n0 + r;
+                for (int c4 = tc; c4 < C4; c4 += tpr) {
+                    const int c = c4 * 4;
+                    float4 dx = make_float4(0.f, 0.f, 0.f, 0.f), sg = dx, th = dx, dgs = dx;
+                    if (n < p.N1) {
+                        if (!last) {
+                            const float4 a = *(const float4*)(DAin + (size_t)n * C + c), bb = *(const float4*)(DBin + (size_t)n * C + c);
+                            dx = make_float4(a.x + bb.x, a.y + bb.y, a.z + bb.z, a.w + bb.w);
+                        }
+                        sg = *(const float4*)(SG + (size_t)n * C + c); th = *(const float4*)(TH + (size_t)n * C + c);
+                        if (n >= win0) dgs = *(const float4*)(bw.DGS + ((size_t)b * p.BL + (n - win0)) * p.LC + (size_t)l * C + c);
+                    }
+                    float* d0 = Dx + (size_t)r * ldx + c; *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
+                    float* d1 = Sg + (size_t)r * ldx + c; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
+                    float* d2 = Th + (size_t)r * ldx + c; *(float2*)d2 = make_float2(th.x, th.y); *(float2*)(d2 + 2) = make_float2(th.z, th.w);
+                    float* d3 = Dg + (size_t)r * ldx + c; *(float2*)d3 = make_float2(dgs.x, dgs.y); *(float2*)(d3 + 2) = make_float2(dgs.z, dgs.w);
+                }
+            }
     }
     __syncthreads();
     // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
-    const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
-    const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
     float* DZg = bw.DZ + ((size_t)l * p.B * p.N1 + rb) * 2 * C;
-    const int win0 = p.N1 - p.BL;
     for (int nt = wave; nt < NCG; nt += 4) {
         f32x4 acc[MT][1];
 #pragma unroll
@@ -173,15 +189,11 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i, n = n0 + r;
-                float dzs = 0.f, dzt = 0.f;
-                if (n < p.N1) {
-                    float dg = acc[mt][0][i];
-                    if (n >= win0) dg += bw.DGS[((size_t)b * p.BL + (n - win0)) * p.LC + (size_t)l * C + c];
-                    const float sg = SG[(size_t)n * C + c], th = TH[(size_t)n * C + c];
-                    dzs = dg * th * sg * (1.0f - sg);
-                    dzt = dg * sg * (1.0f - th * th);
-                    DZg[(size_t)n * 2 * C + c] = dzs; DZg[(size_t)n * 2 * C + C + c] = dzt;
-                }
+                const float dg = acc[mt][0][i] + Dg[(size_t)r * ldx + c];
+                const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
+                const float dzs = dg * th * sg * (1.0f - sg);
+                const float dzt = dg * sg * (1.0f - th * th);
+                if (n < p.N1) { DZg[(size_t)n * 2 * C + c] = dzs; DZg[(size_t)n * 2 * C + C + c] = dzt; }
                 Dz[(size_t)r * ldz + c] = dzs; Dz[(size_t)r * ldz + C + c] = dzt;
             }
     }
@@ -492,7 +504,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     const size_t nDX = (size_t)B * N1 * C;
     constexpr int MT = TR_MT, TM = 16 * MT;
     const size_t lds_post = (size_t)TM * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
-    const size_t lds_layer = (size_t)TM * (tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
+    const size_t lds_layer = (size_t)TM * (4 * tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
     if (lds_post > 160 * 1024 || lds_layer > 160 * 1024) { qpn_set_error("backward tiles do not fit LDS"); return QPN_EINVAL; }
     if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));

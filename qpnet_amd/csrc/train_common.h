@@ -83,10 +83,18 @@ template <int MT, int NJ>
 __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
                                           const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
     const int arow = lane & 15, ak = lane >> 4;
-    for (int ks4 = 0; ks4 < K / 16; ++ks4) {
+    const int nk = K / 16;
+    float4 bn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bn[j] = Bp[(size_t)nts[j] * 64 + lane];
+    for (int ks4 = 0; ks4 < nk; ++ks4) {
         float4 b[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = Bp[((size_t)ks4 * NT + nts[j]) * 64 + lane];
+        for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+        // the weight fragments of the next 16-deep step are requested before this step's MFMAs (L2 latency hidden)
+        const int kn = ks4 + 1 < nk ? ks4 + 1 : ks4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bn[j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float* ap = A_lds + (size_t)(16 * mt + arow) * lda + 16 * ks4 + ak;

@@ -14,7 +14,10 @@
 //                  (B, BL, Q) exactly as the reference returns them.
 #include "train_common.h"
 
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+// gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32): ~6 instructions each instead of
+// the ~50 of libm's expf/tanhf, which made the epilogue as long as the GEMM; abs error ~1e-7 (tolerance: loss 1e-4)
+__device__ __forceinline__ float sigmoidf_(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float tanhf_(float z) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * z)) - 1.0f; }
 
 __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     const int b = blockIdx.y;
@@ -76,18 +79,28 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
     const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
     const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
-    // ---- stage [x_cur | x_past | aux | 0] rows into LDS (float2 granularity: lda is even, not /4)
-    const int K2 = Ktp / 2;
-    for (int idx = tid; idx < TM * K2; idx += 256) {
-        const int r = idx / K2, k = (idx - r * K2) * 2;
-        const int n = n0 + r;
-        float2 v = make_float2(0.f, 0.f);
-        if (n < p.N1) {
-            if (k < C) v = *(const float2*)(Xin + (size_t)n * C + k);
-            else if (k < 2 * C) { const int tp = taps ? taps[n] : n - ly.dilation; v = *(const float2*)(Xin + (size_t)tp * C + (k - C)); }
-            else if (k < 2 * C + Ap) v = *(const float2*)(hup + (size_t)n * Ap + (k - 2 * C));
-        }
-        *(float2*)(As + (size_t)r * lda + k) = v;
+    // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4)
+    {
+        const int K4 = Ktp / 4;                       // float4 columns per row
+        const int tpr = K4 < 64 ? K4 : 64;            // threads per row (one float4 each, extra columns in a second pass)
+        const int rpp = 256 / tpr;                    // rows per pass
+        const int tr = tid / tpr, tc = tid - tr * tpr;
+        if (tr < rpp)
+            for (int r = tr; r < TM; r += rpp) {
+                const int n = n0 + r;
+                const int tp = n < p.N1 ? (taps ? taps[n] : n - ly.dilation) : 0;
+                for (int c4 = tc; c4 < K4; c4 += tpr) {
+                    const int k = c4 * 4;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < p.N1) {
+                        if (k < C) v = *(const float4*)(Xin + (size_t)n * C + k);
+                        else if (k < 2 * C) v = *(const float4*)(Xin + (size_t)tp * C + (k - C));
+                        else if (k < 2 * C + Ap) v = *(const float4*)(hup + (size_t)n * Ap + (k - 2 * C));
+                    }
+                    float* dst = As + (size_t)r * lda + k;
+                    *(float2*)dst = make_float2(v.x, v.y); *(float2*)(dst + 2) = make_float2(v.z, v.w);
+                }
+            }
     }
     __syncthreads();
     const float4* W1 = p.wp + ly.w1_f4;
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * (lane >> 4) + i;
                 const float sg = sigmoidf_(acc[mt][0][i] + bs);
-                const float th = tanhf(acc[mt][1][i] + bt);
+                const float th = tanhf_(acc[mt][1][i] + bt);
                 Gs[(size_t)r * ldg + c] = sg * th;
                 if (n0 + r < p.N1) { SG[(size_t)(n0 + r) * C + c] = sg; TH[(size_t)(n0 + r) * C + c] = th; }
             }
@@ -271,15 +284,26 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
         const int64_t b = row / BL, t = row - b * BL;
         const int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
         float m = -INFINITY;
-        for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
+        const bool vec = (Q & 255) == 0;             // 4 contiguous logits per lane per pass (16-byte accesses)
+        if (vec) for (int q = lane * 4; q < Q; q += 256) { const float4 v = *(const float4*)(lg + q); m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
+        else for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
         for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
         float se = 0.f;
-        for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
+        if (vec) for (int q = lane * 4; q < Q; q += 256) { const float4 v = *(const float4*)(lg + q); se += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m)); }
+        else for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
         for (int s = 32; s >= 1; s >>= 1) se += __shfl_xor(se, s);
         const float lse = logf(se) + m;
-        if (dlogits) for (int q = lane; q < Q; q += 64) {
-            const float pr = expf(lg[q] - lse);
-            dlogits[(size_t)row * Q + q] = (pr - (q == tg ? 1.0f : 0.0f)) * inv;
+        if (dlogits) {
+            if (vec) for (int q = lane * 4; q < Q; q += 256) {
+                const float4 v = *(const float4*)(lg + q);
+                float4 g = make_float4(__expf(v.x - lse), __expf(v.y - lse), __expf(v.z - lse), __expf(v.w - lse));
+                const int dq = (int)tg - q;
+                if (dq == 0) g.x -= 1.0f; else if (dq == 1) g.y -= 1.0f; else if (dq == 2) g.z -= 1.0f; else if (dq == 3) g.w -= 1.0f;
+                *(float4*)(dlogits + (size_t)row * Q + q) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+            } else for (int q = lane; q < Q; q += 64) {
+                const float pr = expf(lg[q] - lse);
+                dlogits[(size_t)row * Q + q] = (pr - (q == tg ? 1.0f : 0.0f)) * inv;
+            }
         }
         lsum += (double)(lse - lg[tg]);
     }
