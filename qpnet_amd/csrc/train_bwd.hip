@@ -14,6 +14,7 @@
 #include "train_common.h"
 #include "qpn_handle.h"
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 
 // ------------------------------------------------------------------------------------------ post-net backward
@@ -251,8 +252,24 @@ struct Wg2L {            // per-workgroup scalars hoisted out of the kernel-argu
     unsigned uR;
 };
 
+// tap rows of the stage starting at rs (pitch-dependent gather source rows), loaded one stage ahead of their use
+template <int NB>
+__device__ __forceinline__ void wg_taps(const Wg2L& q, int rs, int (&tp)[NB], bool b_act, int b_row0, int b_rstep) {
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int r = b_row0 + k * b_rstep, rr = rs + r;
+        int v = 0;
+        if (b_act && r < 32 && rr < q.rend) {
+            const unsigned b = q.nb > 1 ? (unsigned)rr / q.uR : 0u; const int i = rr - (int)(b * q.uR);
+            const int nloc = q.row0B + i;
+            v = q.tap ? q.tap[(size_t)b * q.rowsB + nloc] : nloc - q.dil;
+        }
+        tp[k] = v;
+    }
+}
+
 template <int BMODE, int NA, int NB>
-__device__ __forceinline__ void wg_fetch(const Wg2L& q, int rs, float4 (&ra)[NA], float4 (&ra2)[NA], float4 (&rb)[NB], float4 (&rb2)[NB],
+__device__ __forceinline__ void wg_fetch(const Wg2L& q, int rs, float4 (&ra)[NA], float4 (&ra2)[NA], float4 (&rb)[NB], float4 (&rb2)[NB], const int (&tpv)[NB],
                                          bool a_act, int a_row0, int a_rstep, int a_col, bool b_act, int b_row0, int b_rstep, int b_col) {
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -279,7 +296,7 @@ __device__ __forceinline__ void wg_fetch(const Wg2L& q, int rs, float4 (&ra)[NA]
             else if (BMODE == 2) { v = *(const float4*)(q.B1 + row * q.ldb + n); v2 = *(const float4*)(q.B2 + row * q.ldb + n); }
             else {
                 if (n < q.C) v = *(const float4*)(q.B1 + row * q.C + n);
-                else if (n < 2 * q.C) { const int tp = q.tap ? q.tap[(size_t)b * q.rowsB + nloc] : nloc - q.dil; v = *(const float4*)(q.B1 + ((size_t)b * q.rowsB + tp) * q.C + (n - q.C)); }
+                else if (n < 2 * q.C) v = *(const float4*)(q.B1 + ((size_t)b * q.rowsB + tpv[k]) * q.C + (n - q.C));
                 else v = *(const float4*)(q.hup + row * q.Ap + (n - 2 * q.C));
             }
         }
@@ -323,7 +340,12 @@ __global__ __launch_bounds__(256) void k_wgrad2(Wg2 w, int nch) {
         for (int b = 0; b < NTMAX; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
     float csum = 0.f;
     float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
-    if (rbeg < rend) wg_fetch<BMODE, NA, NB>(q, rbeg, ra, ra2, rb, rb2, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+    int tpv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) tpv[k] = 0;
+    if (BMODE == 3 && rbeg < rend) wg_taps<NB>(q, rbeg, tpv, b_act, b_row0, b_rstep);
+    if (rbeg < rend) wg_fetch<BMODE, NA, NB>(q, rbeg, ra, ra2, rb, rb2, tpv, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+    if (BMODE == 3 && rbeg + RS < rend) wg_taps<NB>(q, rbeg + RS, tpv, b_act, b_row0, b_rstep);
     const int g = lane >> 4, cl = lane & 15;
     for (int rs = rbeg; rs < rend; rs += RS) {
         // registers -> LDS
@@ -348,7 +370,8 @@ __global__ __launch_bounds__(256) void k_wgrad2(Wg2 w, int nch) {
         }
         __syncthreads();
         // next stage's rows fly while the matrix cores work on this one
-        if (rs + RS < rend) wg_fetch<BMODE, NA, NB>(q, rs + RS, ra, ra2, rb, rb2, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+        if (rs + RS < rend) wg_fetch<BMODE, NA, NB>(q, rs + RS, ra, ra2, rb, rb2, tpv, a_act, a_row0, a_rstep, a_col, b_act, b_row0, b_rstep, b_col);
+        if (BMODE == 3 && rs + 2 * RS < rend) wg_taps<NB>(q, rs + 2 * RS, tpv, b_act, b_row0, b_rstep);   // gather rows of the stage after next
         if (gbias >= 0 && tid < q.M) { float s = 0.f; for (int r = 0; r < RS; ++r) s += As[r * ldA + tid]; csum += s; }
 #pragma unroll
         for (int ks = 0; ks < RS / 4; ++ks) {
@@ -532,7 +555,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         for (int l = 0; l < L; ++l) {
             const TrLayer& ly = p.layers[l];
             w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
-            w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
+            w.tap_off[l] = (ly.adaptive && !getenv("QPN_EXP_NOTAP")) ? ly.tap_off : -1; w.dil[l] = ly.dilation;
         }
         ok = ok && wgrad2_any(w, nch, stream);
     }
