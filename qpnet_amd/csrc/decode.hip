@@ -100,11 +100,16 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// Ring-buffer traffic stays inside ONE workgroup (= one CU): producer waves store, drain vmcnt and pass a workgroup
+// barrier before any wave loads the row -- the visibility HIP guarantees for global memory across __syncthreads().
+// Workgroup scope keeps the rows in the CU's L1 / the XCD's L2 (write-back).  Agent scope (sc1, write-through) was
+// measured to push every 4-byte store to the fabric: 2.0 KB written + ~1.8 KB fetched per generated sample
+// (profiles/r01_decode_traffic_pmc.txt) against 172 B of algorithmic HBM bytes.
 __device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ================================================================== small setup kernels
