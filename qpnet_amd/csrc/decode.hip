@@ -474,10 +474,10 @@ __global__ __launch_bounds__(QPN_NT) void k_decode(DecodeParams p) {
 // ~170, addresses and LDS offsets folded, reductions chosen at compile time.  (In-kernel stamps showed the
 // interpreter spends ~1500 cycles of pure instruction issue per slot; the memory system was idle half the time.)
 //   Z phase (per layer)  waves [0,NZ): this step's z tiles + gate      waves [NZ,2NZ): next step's past-tap dots
-//   R phase              waves [0,NRES): residual 1x1 (-> next layer)  the others: skip 1x1 rows, the NSKD tiles
-//                        that do not fit are deferred to the tail (their dots are parked and summed in layer order)
-//   tail                 deferred skip dots -> skip total/relu -> post 1x1 #1 -> post 1x1 #2 -> argmax/causal/staging
-// Each wave requests its next layer's two tiles one full layer ahead (plain loads, counted waits by hipcc).
+//   R phase              residual 1x1 tiles first (-> next layer input), then the skip 1x1 tiles
+//   tail                 skip total/relu -> post 1x1 #1 -> post 1x1 #2 -> argmax/causal/staging
+// With 8 waves (256 VGPRs each) every wave keeps the NEXT layer's tiles in a second register set, requested a full
+// layer ahead with plain loads (hipcc's counted waits work in this straight-line code).
 template <int V> struct ILog2 { static constexpr int v = 1 + ILog2<V / 2>::v; };
 template <> struct ILog2<1> { static constexpr int v = 0; };
 
@@ -496,22 +496,33 @@ __device__ __forceinline__ void read_x(float4 (&x)[4], int xoff_plus_16q) {
     for (int j = 0; j < 4; ++j) x[j] = xv[j];
 }
 
-template <int C, int S, int Q>
-__global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastParams f) {
+// One tile's worth of work for the straight-line kernel: 4 coalesced 1 KiB loads / the spec dot product of a tile.
+__device__ __forceinline__ void tile_load(float4 (&w)[4], const float4* tp) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = tp[j * 64];
+}
+
+// NWV waves per workgroup.  Per layer a wave owns ZT tiles of the Z phase (ids w, w+NWV, ..: z tiles first, then the
+// next step's past-tap tiles) and RT tiles of the R phase (residual tiles first, then skip tiles).  DB = the next
+// layer's tiles are requested a full layer ahead into a second register set (needs the 256-VGPR budget of <= 8 waves);
+// otherwise every tile is re-requested in place right after it has been consumed (one phase ahead).
+template <int C, int S, int Q, int NWV, bool DB>
+__global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastParams f) {
+    constexpr int NTH = NWV * 64;
     constexpr int R = C / 16, LOGR = ILog2<R>::v, RPT = 64 / R;
     constexpr int NZ = 2 * C / RPT, NRES = C / RPT, NSK = S / RPT;
-    constexpr int NSKI = NSK < QPN_NW - NRES ? NSK : QPN_NW - NRES, NSKD = NSK - NSKI;
+    constexpr int ZT = (2 * NZ + NWV - 1) / NWV, RT = (NRES + NSK + NWV - 1) / NWV;
     constexpr int RS = S / 16, LOGRS = ILog2<RS>::v, RPTS = 64 / RS;
     constexpr int NP1 = S / RPTS, NP2 = Q / RPTS;
-    static_assert(2 * NZ <= QPN_NW && NRES <= QPN_NW && R <= 8 && RS <= 32, "geometry not covered by the fast kernel");
-    static_assert(NSKD * RPT <= 64, "deferred skip rows exceed the parking area");
+    constexpr int T1 = (NP1 + NWV - 1) / NWV, T2 = (NP2 + NWV - 1) / NWV;
+    static_assert(R <= 8 && RS <= 32 && ZT >= 1 && RT >= 1, "geometry not covered by the fast kernel");
     float* sm = SM; int* smi = SMI;
     const UttView u = make_view(p, p.utts[blockIdx.x]);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = p.L;
-    for (int i = tid; i < p.state_floats; i += QPN_NT) sm[i] = 0.0f;
-    for (int i = tid; i < p.n_bias; i += QPN_NT) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
+    for (int i = tid; i < p.state_floats; i += NTH) sm[i] = 0.0f;
+    for (int i = tid; i < p.n_bias; i += NTH) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
     __syncthreads();
     const int Ttot = u.n0 + u.n_samples;
     if (Ttot < 3) return;
@@ -519,116 +530,122 @@ __global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastPara
         causal_rows(p, u, u.known[0], u.known[1], 1, lane);
         if (lane == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.known[1]; }
     }
-    stage_aux(p, u, 1, tid, QPN_NT);
+    stage_aux(p, u, 1, tid, NTH);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (Ttot > 3) stage_taps(p, u, 2, tid, QPN_NT, p.status);
+    if (Ttot > 3) stage_taps(p, u, 2, tid, NTH, p.status);
     __syncthreads();
 
+    int stamp_i = 0;
+#ifdef QPN_ENABLE_STAMPS   // dev aid (-DQPN_ENABLE_STAMPS + QPN_STAMPS=1): s_memtime at every phase boundary of step 3000
+#define QPN_STAMP() do { if (p.stamps && t == 3000 && lane == 0 && stamp_i < 120) p.stamps[(size_t)stamp_i * QPN_NW + (wave < QPN_NW ? wave : 0)] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define QPN_STAMP() do { (void)stamp_i; } while (0)
+#endif
     const int q0 = lane & (R - 1), grp0 = lane >> LOGR;
     const int qs0 = lane & (RS - 1), grps0 = lane >> LOGRS;
-    const bool zrole = wave < NZ, prole = !zrole && wave < 2 * NZ;
-    const int ztile = zrole ? wave : wave - NZ;
-    const bool rrole = wave < NRES, srole = !rrole && wave - NRES < NSKI;
-    const int rtile = rrole ? wave : wave - NRES;
     const float4* wl0 = p.wpk + lane;
     const int C2 = 2 * C, LC2 = L * C2;
-    float4 wz[4], wr[4];
+    float4 wz[ZT][4], wr[RT][4], wzn[DB ? ZT : 1][4], wrn[DB ? RT : 1][4];
+    // tile address helpers (ids are compile-time offsets from the wave index)
+#define QPN_ZPTR(wl, l, id) ((wl) + ((id) < NZ ? f.w_cur[l] + (id) * 256 : f.w_past[l] + ((id) - NZ) * 256))
+#define QPN_RPTR(wl, l, id) ((wl) + ((id) < NRES ? f.w_res[l] + (id) * 256 : f.w_skip[l] + ((id) - NRES) * 256))
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { wz[j] = wr[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    if (zrole || prole) { const float4* t = wl0 + (zrole ? f.w_cur[0] : f.w_past[0]) + ztile * 256;
+    for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl0, 0, id)); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wz[j] = t[j * 64]; }
-    if (rrole || srole) { const float4* t = wl0 + (rrole ? f.w_res[0] : f.w_skip[0]) + rtile * 256;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wr[j] = t[j * 64]; }
+    for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl0, 0, id)); }
 
     for (int t = 1; t + 1 < Ttot; ++t) {
-        // hipcc hoists every lane-constant address out of the step loop and then spills them (128-VGPR budget):
-        // an opaque zero re-derives the few bases per step instead, so nothing derived from them can be hoisted
+        // hipcc hoists every lane-constant address out of the step loop and then spills them: an opaque zero
+        // re-derives the few bases per step instead, so nothing derived from them can be hoisted
         int zero = 0;
         asm volatile("" : "+s"(zero));
         const float4* wl = wl0 + zero;
         const int q = q0 + zero, grp = grp0 + zero, qs = qs0 + zero, grps = grps0 + zero;
         const int par = (t & 1) * LC2;
+        stamp_i = 0;
         for (int l = 0; l < L; ++l) {
             const int ln = l + 1 < L ? l + 1 : 0;
-            wg_barrier();                                   // layer input x_l, pd[par], aux terms are in LDS
-            // ---- Z phase
-            if (zrole) {
-                float4 x[4]; read_x(x, p.o_xbuf + l * p.Cp + 16 * q);
-                const float acc = tree_reduce_c<LOGR>(chunk16(wz, x));
-                const int row = ztile * RPT + grp, ch = row >> 1, half = row & 1, nat = half * C + ch;
-                const float z = (acc + sm[p.o_pd + par + l * C2 + nat]) + sm[p.o_auxv + l * C2 + nat];
-                const float zo = dpp_f<0x100 + R>(z);       // row_shl:R -> the tanh group's pre-activation
-                if (q == 0 && !half) sm[p.o_gl + l * p.Cp + ch] = qgate(z, zo);
-            } else if (prole) {
-                const int xo = smi[p.o_sel + l] ? p.o_xbuf + l * p.Cp : p.o_xp + l * p.Cp;
-                float4 x[4]; read_x(x, xo + 16 * q);
-                const float acc = tree_reduce_c<LOGR>(chunk16(wz, x));
-                if (q == 0) sm[p.o_pd + (LC2 - par) + l * C2 + ztile * RPT + grp] = acc;    // next step's parity
-            }
-            // this wave's Z-phase tile of the next layer is requested as soon as the current one has been consumed
-            if (l + 1 < L && (zrole || prole)) { const float4* tp = wl + (zrole ? f.w_cur[ln] : f.w_past[ln]) + ztile * 256;
+            if constexpr (DB) {
+                if (l + 1 < L) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wz[j] = tp[j * 64]; }
-            wg_barrier();                                   // gate vector g_l is in LDS
-            // ---- R phase
-            if (rrole) {
-                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
-                const float acc = tree_reduce_c<LOGR>(chunk16(wr, x));
-                const int row = rtile * RPT + grp;
-                if (q == 0) {
-                    const float v = (acc + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row];
-                    sm[p.o_xbuf + (l + 1) * p.Cp + row] = v;
-                    if (l + 1 < L) { const RingDesc r = p.rings[l + 1]; st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + row, v); }
+                    for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wzn[i], QPN_ZPTR(wl, ln, id)); }
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wrn[i], QPN_RPTR(wl, ln, id)); }
                 }
-            } else if (srole) {
-                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
-                const float acc = tree_reduce_c<LOGR>(chunk16(wr, x));
-                const int row = rtile * RPT + grp;
-                if (q == 0) { const int a = (f.adaptive[l] ? p.o_ska : p.o_skf) + row; sm[a] = sm[a] + (acc + sm[f.b_skip[l] + row]); }
             }
-            if (l + 1 < L && (rrole || srole)) { const float4* tp = wl + (rrole ? f.w_res[ln] : f.w_skip[ln]) + rtile * 256;
+            wg_barrier();                                   // layer input x_l, pd[par], aux terms are in LDS
+            QPN_STAMP();
+            // ---- Z phase
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wr[j] = tp[j * 64]; }
-        }
-        // ---- tail: deferred skip rows (dots parked per layer, summed in layer order below)
-        if constexpr (NSKD > 0) {
-            for (int d = wave; d < L * NSKD; d += QPN_NW) {
-                const int l = d / NSKD, k = d - l * NSKD;
-                float4 w[4]; const float4* tp = wl + f.w_skip[l] + (NSKI + k) * 256;
+            for (int i = 0; i < ZT; ++i) {
+                const int id = wave + i * NWV;
+                if (id < NZ) {
+                    float4 x[4]; read_x(x, p.o_xbuf + l * p.Cp + 16 * q);
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[i], x));
+                    const int row = id * RPT + grp, ch = row >> 1, half = row & 1, nat = half * C + ch;
+                    const float z = (acc + sm[p.o_pd + par + l * C2 + nat]) + sm[p.o_auxv + l * C2 + nat];
+                    const float zo = dpp_f<0x100 + R>(z);   // row_shl:R -> the tanh group's pre-activation
+                    if (q == 0 && !half) sm[p.o_gl + l * p.Cp + ch] = qgate(z, zo);
+                } else if (id < 2 * NZ) {
+                    const int xo = smi[p.o_sel + l] ? p.o_xbuf + l * p.Cp : p.o_xp + l * p.Cp;
+                    float4 x[4]; read_x(x, xo + 16 * q);
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[i], x));
+                    if (q == 0) sm[p.o_pd + (LC2 - par) + l * C2 + (id - NZ) * RPT + grp] = acc;    // next step's parity
+                }
+                if constexpr (!DB) { if (l + 1 < L && id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl, ln, id)); }
+            }
+            QPN_STAMP();
+            wg_barrier();                                   // gate vector g_l is in LDS
+            QPN_STAMP();
+            // ---- R phase
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = tp[j * 64];
-                float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
-                const float acc = tree_reduce_c<LOGR>(chunk16(w, x));
-                if (q == 0) sm[p.o_sdef + l * 64 + k * RPT + grp] = acc + sm[f.b_skip[l] + (NSKI + k) * RPT + grp];
+            for (int i = 0; i < RT; ++i) {
+                const int id = wave + i * NWV;
+                if (id < NRES) {
+                    float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wr[i], x));
+                    const int row = id * RPT + grp;
+                    if (q == 0) {
+                        const float v = (acc + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row];
+                        sm[p.o_xbuf + (l + 1) * p.Cp + row] = v;
+                        if (l + 1 < L) { const RingDesc r = p.rings[l + 1]; st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + row, v); }
+                    }
+                } else if (id < NRES + NSK) {
+                    float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wr[i], x));
+                    const int row = (id - NRES) * RPT + grp;
+                    if (q == 0) { const int a = (f.adaptive[l] ? p.o_ska : p.o_skf) + row; sm[a] = sm[a] + (acc + sm[f.b_skip[l] + row]); }
+                }
+                if constexpr (!DB) { if (l + 1 < L && id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl, ln, id)); }
+            }
+            if constexpr (DB) {
+                if (l + 1 < L) {
+#pragma unroll
+                    for (int i = 0; i < ZT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wz[i][j] = wzn[i][j];
+#pragma unroll
+                    for (int i = 0; i < RT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wr[i][j] = wrn[i][j];
+                }
             }
         }
-        // first post-1 tile of this wave is requested before the barrier
-        float4 (&wa)[4] = wz; float4 (&wb)[4] = wr;       // the layer tile sets are idle during the tail
-        constexpr int T1 = (NP1 + QPN_NW - 1) / QPN_NW, T2 = (NP2 + QPN_NW - 1) / QPN_NW;
-        if (wave < NP1) { const float4* tp = wl + f.w_p1 + wave * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = tp[j * 64]; }
+        QPN_STAMP();
+        // ---- tail: skip total / relu -> post 1x1 #1 -> post 1x1 #2; the tile register sets of the layers are idle
+        float4 (&wa)[4] = wz[0]; float4 (&wb)[4] = wr[0];
+        if (wave < NP1) tile_load(wa, wl + f.w_p1 + wave * 256);
         wg_barrier();
-        // skip total: rows handled in the R phases already hold their sums; deferred rows are summed now, in layer order
-        for (int row = tid; row < S; row += QPN_NT) {
-            float aF = sm[p.o_skf + row], aA = sm[p.o_ska + row];
-            if (NSKD > 0 && row >= NSKI * RPT) {
-                const int rl = row - NSKI * RPT;
-                for (int l = 0; l < L; ++l) { const float v = sm[p.o_sdef + l * 64 + rl]; if (f.adaptive[l]) aA = aA + v; else aF = aF + v; }
-            }
-            const float tot = aF + aA;                      // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
+        for (int row = tid; row < S; row += NTH) {
+            const float tot = sm[p.o_skf + row] + sm[p.o_ska + row];      // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
             sm[p.o_y1 + row] = tot > 0.0f ? tot : 0.0f;
         }
         wg_barrier();
 #pragma unroll
         for (int i = 0; i < T1; ++i) {
-            const int tile = wave + i * QPN_NW;
-            if (i + 1 < T1 && tile + QPN_NW < NP1) { const float4* tp = wl + f.w_p1 + (tile + QPN_NW) * 256;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wb[j] = tp[j * 64]; }
+            const int tile = wave + i * NWV;
+            if (i + 1 < T1 && tile + NWV < NP1) tile_load(wb, wl + f.w_p1 + (tile + NWV) * 256);
             if (tile < NP1) {
                 float4 x[4]; read_x(x, p.o_y1 + 16 * qs);
                 const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
@@ -638,16 +655,12 @@ __global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastPara
 #pragma unroll
             for (int j = 0; j < 4; ++j) wa[j] = wb[j];
         }
-        if (wave < NP2) { const float4* tp = wl + f.w_p2 + wave * 256;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = tp[j * 64]; }
+        if (wave < NP2) tile_load(wa, wl + f.w_p2 + wave * 256);
         wg_barrier();
 #pragma unroll
         for (int i = 0; i < T2; ++i) {
-            const int tile = wave + i * QPN_NW;
-            if (i + 1 < T2 && tile + QPN_NW < NP2) { const float4* tp = wl + f.w_p2 + (tile + QPN_NW) * 256;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wb[j] = tp[j * 64]; }
+            const int tile = wave + i * NWV;
+            if (i + 1 < T2 && tile + NWV < NP2) tile_load(wb, wl + f.w_p2 + (tile + NWV) * 256);
             if (tile < NP2) {
                 float4 x[4]; read_x(x, p.o_y2 + 16 * qs);
                 const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
@@ -657,16 +670,15 @@ __global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastPara
 #pragma unroll
             for (int j = 0; j < 4; ++j) wa[j] = wb[j];
         }
+        QPN_STAMP();
         // ---- end of step: pick the sample, look up the next layer-0 input, stage aux terms / past rows
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's ring rows have left the CU
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's ring rows have left the wave
         wg_barrier();
         // layer-0 tiles of the next step fly while the sample is picked
-        if (zrole || prole) { const float4* tp = wl + (zrole ? f.w_cur[0] : f.w_past[0]) + ztile * 256;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wz[j] = tp[j * 64]; }
-        if (rrole || srole) { const float4* tp = wl + (rrole ? f.w_res[0] : f.w_skip[0]) + rtile * 256;
+        for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl, 0, id)); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wr[j] = tp[j * 64]; }
+        for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl, 0, id)); }
         if (wave == 0) {
             float bv = -INFINITY; int bi = 0x7fffffff;
             for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
@@ -687,12 +699,15 @@ __global__ __launch_bounds__(QPN_NT) void k_decode_fast(DecodeParams p, FastPara
             if (t + 2 < Ttot) causal_rows(p, u, cur, next, t + 1, lane);
             if (lane == 0) { smi[p.o_samp] = cur; smi[p.o_samp + 1] = next; }
         } else {
-            const int stid = (wave - 1) * 64 + lane, nst = (QPN_NW - 1) * 64;
+            const int stid = (wave - 1) * 64 + lane, nst = (NWV - 1) * 64;
             for (int i = stid; i < S; i += nst) { sm[p.o_skf + i] = 0.0f; sm[p.o_ska + i] = 0.0f; }
             if (t + 2 < Ttot) stage_aux(p, u, t + 1, stid, nst);
             if (t + 3 < Ttot) stage_taps(p, u, t + 2, stid, nst, p.status);
         }
     }
+#undef QPN_STAMP
+#undef QPN_ZPTR
+#undef QPN_RPTR
 }
 
 // ================================================================== host side
@@ -951,7 +966,7 @@ extern "C" int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, voi
         QPN_HIP(hipMalloc(&h->d_tasks, h->h_tasks.size() * sizeof(Task)));
         QPN_HIP(hipMalloc(&h->d_qb, (size_t)g.L * 2 * g.C * sizeof(float)));
         QPN_HIP(hipMalloc(&h->d_bd, (size_t)g.L * sizeof(BiasDesc)));
-        QPN_HIP(hipMalloc(&h->d_status, 64));
+        QPN_HIP(hipMalloc(&h->d_status, 64 + 128 * QPN_NW * sizeof(long long)));
         QPN_HIP(hipMalloc(&h->d_bias_src, h->h_bias_src.size() * sizeof(int)));
         QPN_HIP(hipMemcpy(h->d_bias_src, h->h_bias_src.data(), h->h_bias_src.size() * sizeof(int), hipMemcpyHostToDevice));
         QPN_HIP(hipMemcpy(h->d_map, h->h_map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
@@ -1049,20 +1064,29 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
                        h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.L, h->d_pproj);
     p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
     p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
+    p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024) {
         QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
+        const int lb = p.lds_floats * (int)sizeof(float);
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     }
     QPN_HIP(hipEventRecord(h->ev0, stream));
     const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
+    // 16 waves, tiles re-requested in place (one phase ahead) measured 54k samples/s at B=1; the 8-wave variant that
+    // double-buffers a full layer of tiles is instruction-issue bound (42k) -- kept behind QPN_DECODE_W8 for study
+    const bool w16 = getenv("QPN_DECODE_W8") == nullptr;
     const size_t lds_bytes = (size_t)p.lds_floats * sizeof(float);
-    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256)
-        hipLaunchKernelGGL((k_decode_fast<64, 256, 256>), dim3(B), dim3(QPN_NT), lds_bytes, stream, p, h->fp);
-    else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256)
-        hipLaunchKernelGGL((k_decode_fast<32, 32, 256>), dim3(B), dim3(QPN_NT), lds_bytes, stream, p, h->fp);
-    else
+    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256) {
+        if (w16) hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 8, true>), dim3(B), dim3(512), lds_bytes, stream, p, h->fp);
+    } else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256) {
+        if (w16) hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 8, true>), dim3(B), dim3(512), lds_bytes, stream, p, h->fp);
+    } else
         hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), lds_bytes, stream, p);
     QPN_HIP(hipGetLastError());
     QPN_HIP(hipEventRecord(h->ev1, stream));
@@ -1079,6 +1103,15 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
     int status = 0;
     QPN_HIP(hipMemcpy(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
     QPN_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if (getenv("QPN_STAMPS")) {      // dev aid: stamp times (cycles, relative to the first stamp of wave 0) of step 3000
+        std::vector<long long> st((size_t)120 * QPN_NW);
+        QPN_HIP(hipMemcpy(st.data(), h->d_status + 16, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int s = 0; s < 40; ++s) {
+            fprintf(stderr, "stamp %2d:", s);
+            for (int w = 0; w < QPN_NW; w += 5) fprintf(stderr, " w%-2d %7lld", w, st[(size_t)s * QPN_NW + w] - st[0]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (status & 1) { qpn_set_error("pitch-dependent tap left its ring buffer (dilated factor <= 0.5 or > maxd)"); return QPN_ERANGE; }
     return QPN_OK;
 }

@@ -95,6 +95,7 @@ struct DecodeParams {
     const UttDesc* utts;
     const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
     int* status;
+    long long* stamps;      // dev aid (QPN_STAMPS=1): s_memtime stamps of one step, [stamp][wave]
     int n_slots;
     int C, Cp, S, Q, L, U, mode;
     int64_t causal_w, causal_b, up_w;
