@@ -57,6 +57,15 @@ def max_over_ranks(v, world, dev):
     return float(t.item())
 
 
+def measured_traffic():
+    """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (committed under profiles/)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def decode_weight_bytes_per_sample(cfg):
     """172 B of per-sample inputs/outputs + 4 B x the parameters touched per sample
     (all but the one-hot table, of which two columns are looked up)."""
@@ -122,8 +131,11 @@ def run_decode(args, rank, local, world):
                                "(C=64,S=256,4F+4A), F=%d frames -> %d samples each" % (B, ns[0] / 22050.0, F, ns[0]),
                    "batch_per_gpu": B, "parallelism": "replicas x%d (no collective)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_decode", "kernel_ms": k_ms,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (measured_traffic() or {}).get("decode", {}).get("hbm_bytes_per_sample", 0) * sum(ns) or None,
+                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per sample x samples of this launch)",
+                     "kernel": "k_decode_fast" if cfg.n_resch <= 64 else "k_decode", "kernel_ms": k_ms,
+                     "l2_stream_floor_us_per_sample": 11.65,
                      "note": "algorithmic bytes = (172 + 4*params touched) B/sample = %d B/sample (SURVEY 8d, weights re-streamed "
                              "every sample; they are L2-resident so this is L2->CU traffic, not HBM)" % bps},
     }
@@ -235,7 +247,10 @@ def run_train(args, rank, local, world):
                                "of %d samples (RF %d + batch_length %d), batch 1 per GPU" % (x0.shape[1], N1 + 1 - BL, BL),
                    "global_batch": world, "parallelism": "dp%d (utterance-sharded chunks, one flat-gradient all-reduce per step)" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": PG_NAMES[dom],
+                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
+                     "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None,
+                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc, k_wgrad2 launches of one step)",
+                     "kernel": PG_NAMES[dom],
                      "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
                      "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
