@@ -503,182 +503,189 @@ __device__ __forceinline__ void tile_load(float4 (&w)[4], const float4* tp) {
 }
 
 // NWV waves per workgroup.  Per layer a wave owns ZT tiles of the Z phase (ids w, w+NWV, ..: z tiles first, then the
-// next step's past-tap tiles) and RT tiles of the R phase (residual tiles first, then skip tiles).  DB = the next
-// layer's tiles are requested a full layer ahead into a second register set (needs the 256-VGPR budget of <= 8 waves);
-// otherwise every tile is re-requested in place right after it has been consumed (one phase ahead).
-template <int C, int S, int Q, int NWV, bool DB>
-__global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastParams f) {
-    constexpr int NTH = NWV * 64;
-    constexpr int R = C / 16, LOGR = ILog2<R>::v, RPT = 64 / R;
-    constexpr int NZ = 2 * C / RPT, NRES = C / RPT, NSK = S / RPT;
-    constexpr int ZT = (2 * NZ + NWV - 1) / NWV, RT = (NRES + NSK + NWV - 1) / NWV;
-    constexpr int RS = S / 16, LOGRS = ILog2<RS>::v, RPTS = 64 / RS;
-    constexpr int NP1 = S / RPTS, NP2 = Q / RPTS;
-    constexpr int T1 = (NP1 + NWV - 1) / NWV, T2 = (NP2 + NWV - 1) / NWV;
-    static_assert(R <= 8 && RS <= 32 && ZT >= 1 && RT >= 1, "geometry not covered by the fast kernel");
-    float* sm = SM; int* smi = SMI;
-    const UttView u = make_view(p, p.utts[blockIdx.x]);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int L = p.L;
-    for (int i = tid; i < p.state_floats; i += NTH) sm[i] = 0.0f;
-    for (int i = tid; i < p.n_bias; i += NTH) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
-    __syncthreads();
-    const int Ttot = u.n0 + u.n_samples;
-    if (Ttot < 3) return;
-    if (wave == 0) {
-        causal_rows(p, u, u.known[0], u.known[1], 1, lane);
-        if (lane == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.known[1]; }
+// next step's past-tap tiles) and RT tiles of the R phase (residual tiles first, then skip tiles); every tile is
+// re-requested in place for the next layer right after it has been consumed (a full layer ahead of its use).
+// What a wave does with its slots depends only on which interval of wave ids it falls in, so the step loop is
+// instantiated once per interval ("role", W0 = its first wave): inside a role the code is straight-line with no
+// wave-dependent branches around the tile requests, and hipcc's waitcnt pass can then count the outstanding loads
+// (vmcnt(N)) instead of draining the queue (vmcnt(0)) in front of every tile.
+template <int C, int S, int Q, int NWV>
+struct FastGeo {
+    static constexpr int R = C / 16, LOGR = ILog2<R>::v, RPT = 64 / R;
+    static constexpr int NZ = 2 * C / RPT, NRES = C / RPT, NSK = S / RPT;
+    static constexpr int ZT = (2 * NZ + NWV - 1) / NWV, RT = (NRES + NSK + NWV - 1) / NWV;
+    static constexpr int RS = S / 16, LOGRS = ILog2<RS>::v, RPTS = 64 / RS;
+    static constexpr int NP1 = S / RPTS, NP2 = Q / RPTS;
+    static constexpr int T1 = (NP1 + NWV - 1) / NWV, T2 = (NP2 + NWV - 1) / NWV;
+    static constexpr int zkind(int id) { return id < NZ ? 1 : id < 2 * NZ ? 2 : 0; }            // 1 z tile, 2 past-tap tile
+    static constexpr int rkind(int id) { return id < NRES ? 1 : id < NRES + NSK ? 2 : 0; }      // 1 residual, 2 skip
+    static constexpr int next_boundary(int w0) {
+        int nb = NWV;
+        for (int i = 0; i < 16; ++i) {
+            const int th[6] = {NZ - i * NWV, 2 * NZ - i * NWV, NRES - i * NWV, NRES + NSK - i * NWV, NP1 - i * NWV, NP2 - i * NWV};
+            for (int k = 0; k < 6; ++k) if (th[k] > w0 && th[k] < nb) nb = th[k];
+        }
+        return nb;
     }
-    stage_aux(p, u, 1, tid, NTH);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (Ttot > 3) stage_taps(p, u, 2, tid, NTH, p.status);
-    __syncthreads();
+};
 
+template <int C, int S, int Q, int NWV, int W0>
+__device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastParams& f, const UttView& u,
+                                           const int wave, const int lane0, const int tid0, const int Ttot) {
+    using G = FastGeo<C, S, Q, NWV>;
+    constexpr int NTH = NWV * 64;
+    constexpr int R = G::R, LOGR = G::LOGR, RPT = G::RPT, NZ = G::NZ, NRES = G::NRES, ZT = G::ZT, RT = G::RT;
+    constexpr int RS = G::RS, LOGRS = G::LOGRS, RPTS = G::RPTS, T1 = G::T1, T2 = G::T2;
+    static_assert(ZT <= 4 && RT <= 4 && T1 <= 4 && T2 <= 4, "slot macros are expanded four times");
+    float* sm = SM; int* smi = SMI;
+    const int L = p.L;
     int stamp_i = 0;
-#ifdef QPN_ENABLE_STAMPS   // dev aid (-DQPN_ENABLE_STAMPS + QPN_STAMPS=1): s_memtime at every phase boundary of step 3000
-#define QPN_STAMP() do { if (p.stamps && t == 3000 && lane == 0 && stamp_i < 120) p.stamps[(size_t)stamp_i * QPN_NW + (wave < QPN_NW ? wave : 0)] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#ifdef QPN_ENABLE_STAMPS   // dev aid (-DQPN_ENABLE_STAMPS + QPN_STAMPS=1): s_memtime at every phase boundary of step 3000,
+                           // parked in LDS behind the kernel's own state (no global stores in the timed code), dumped after the step
+#define QPN_STAMP() do { if (p.stamps && t == 3000 && lane == 0 && stamp_i < 120) smi[p.lds_floats + stamp_i * QPN_NW + (wave < QPN_NW ? wave : 0)] = (int)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#define QPN_STAMP_DUMP() do { if (p.stamps && t == 3000 && lane == 0) for (int k = 0; k < stamp_i && k < 120; ++k) p.stamps[(size_t)k * QPN_NW + (wave < QPN_NW ? wave : 0)] = (long long)(unsigned)smi[p.lds_floats + k * QPN_NW + (wave < QPN_NW ? wave : 0)]; } while (0)
 #else
 #define QPN_STAMP() do { (void)stamp_i; } while (0)
+#define QPN_STAMP_DUMP() do { } while (0)
 #endif
-    const int q0 = lane & (R - 1), grp0 = lane >> LOGR;
-    const int qs0 = lane & (RS - 1), grps0 = lane >> LOGRS;
-    const float4* wl0 = p.wpk + lane;
+    const float4* wl0 = p.wpk + lane0;
     const int C2 = 2 * C, LC2 = L * C2;
-    float4 wz[ZT][4], wr[RT][4], wzn[DB ? ZT : 1][4], wrn[DB ? RT : 1][4];
-    // tile address helpers (ids are compile-time offsets from the wave index)
+    float4 wz[ZT][4], wr[RT][4], wp[4];
 #define QPN_ZPTR(wl, l, id) ((wl) + ((id) < NZ ? f.w_cur[l] + (id) * 256 : f.w_past[l] + ((id) - NZ) * 256))
 #define QPN_RPTR(wl, l, id) ((wl) + ((id) < NRES ? f.w_res[l] + (id) * 256 : f.w_skip[l] + ((id) - NRES) * 256))
-#pragma unroll
-    for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl0, 0, id)); }
-#pragma unroll
-    for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl0, 0, id)); }
+#define QPN_ZINIT(wl, i) if constexpr ((i) < ZT && G::zkind(W0 + (i) * NWV) != 0) tile_load(wz[(i) < ZT ? (i) : 0], QPN_ZPTR(wl, 0, wave + (i) * NWV));
+#define QPN_RINIT(wl, i) if constexpr ((i) < RT && G::rkind(W0 + (i) * NWV) != 0) tile_load(wr[(i) < RT ? (i) : 0], QPN_RPTR(wl, 0, wave + (i) * NWV));
+    QPN_ZINIT(wl0, 0) QPN_ZINIT(wl0, 1) QPN_ZINIT(wl0, 2) QPN_ZINIT(wl0, 3)
+    QPN_RINIT(wl0, 0) QPN_RINIT(wl0, 1) QPN_RINIT(wl0, 2) QPN_RINIT(wl0, 3)
+
+    // The post-net tiles of a wave form one sequence s = 0..T1+T2-1 (post 1x1 #1 tiles, then #2) that cycles through three
+    // register sets: wp, and the layer sets wz[0] / wr[0] once the last layer has consumed them.  Tile s is requested as
+    // soon as tile s-3 has been consumed, the first three during the last layer.
+#define QPN_TB(s) ((s) % 3 == 0 ? wp : (s) % 3 == 1 ? wz[0] : wr[0])
+#define QPN_TVALID(s) ((s) < T1 ? (W0 + (s) * NWV < G::NP1) : ((s) < T1 + T2 && W0 + ((s) - T1) * NWV < G::NP2))
+#define QPN_TLOAD(s) if constexpr (QPN_TVALID(s)) tile_load(QPN_TB(s), wl + ((s) < T1 ? f.w_p1 + (wave + (s) * NWV) * 256 : f.w_p2 + (wave + ((s) - T1) * NWV) * 256));
+
+    // ---- one layer; LAST = the final layer, which hands its tile registers to the post-net instead of re-requesting
+#define QPN_ZSLOT(i, LAST)                                                                                        \
+            if constexpr ((i) < ZT) {                                                                             \
+                constexpr int zk = G::zkind(W0 + (i) * NWV);                                                      \
+                const int id = wave + (i) * NWV;                                                                  \
+                if constexpr (zk == 1) {                                                                          \
+                    float4 x[4]; read_x(x, p.o_xbuf + l * p.Cp + 16 * q);                                         \
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[(i) < ZT ? (i) : 0], x));                    \
+                    const int row = id * RPT + grp, ch = row >> 1, half = row & 1, nat = half * C + ch;           \
+                    const float z = (acc + sm[p.o_pd + par + l * C2 + nat]) + sm[p.o_auxv + l * C2 + nat];        \
+                    const float zo = dpp_f<0x100 + R>(z);   /* row_shl:R -> the tanh group's pre-activation */    \
+                    if (q == 0 && !half) sm[p.o_gl + l * p.Cp + ch] = qgate(z, zo);                               \
+                } else if constexpr (zk == 2) {                                                                   \
+                    const int xo = smi[p.o_sel + l] ? p.o_xbuf + l * p.Cp : p.o_xp + l * p.Cp;                    \
+                    float4 x[4]; read_x(x, xo + 16 * q);                                                          \
+                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[(i) < ZT ? (i) : 0], x));                    \
+                    if (q == 0) sm[p.o_pd + (LC2 - par) + l * C2 + (id - NZ) * RPT + grp] = acc;  /* next parity */ \
+                }                                                                                                 \
+                if constexpr (!(LAST)) { if constexpr (zk != 0) tile_load(wz[(i) < ZT ? (i) : 0], QPN_ZPTR(wl, l + 1, id)); } \
+                else if constexpr ((i) == 0) { QPN_TLOAD(1) }                                                     \
+            }
+#define QPN_RDOT(i, LAST)                                                                                         \
+            if constexpr ((i) < RT) {                                                                             \
+                constexpr int rk = G::rkind(W0 + (i) * NWV);                                                      \
+                if constexpr (rk != 0) racc[(i) < RT ? (i) : 0] = tree_reduce_c<LOGR>(chunk16(wr[(i) < RT ? (i) : 0], xg)); \
+                if constexpr (!(LAST)) { if constexpr (rk != 0) tile_load(wr[(i) < RT ? (i) : 0], QPN_RPTR(wl, l + 1, wave + (i) * NWV)); } \
+                else if constexpr ((i) == 0) { QPN_TLOAD(2) }                                                     \
+            }
+#define QPN_RPUT(i)                                                                                               \
+            if constexpr ((i) < RT) {                                                                             \
+                constexpr int rk = G::rkind(W0 + (i) * NWV);                                                      \
+                const int id = wave + (i) * NWV;                                                                  \
+                if constexpr (rk == 1) {                                                                          \
+                    const int row = id * RPT + grp;                                                               \
+                    /* x_{l+1}; its ring row is written once per step at the end (no stores in the load queue here) */ \
+                    sm[p.o_xbuf + (l + 1) * p.Cp + row] = (racc[(i) < RT ? (i) : 0] + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row]; \
+                } else if constexpr (rk == 2) {                                                                   \
+                    const int row = (id - NRES) * RPT + grp;                                                      \
+                    const int a = (f.adaptive[l] ? p.o_ska : p.o_skf) + row;                                      \
+                    sm[a] = sm[a] + (racc[(i) < RT ? (i) : 0] + sm[f.b_skip[l] + row]);                           \
+                }                                                                                                 \
+            }
+#define QPN_LAYER(LAST)                                                                                           \
+            if constexpr (LAST) { QPN_TLOAD(0) }                                                                  \
+            wg_barrier();                                   /* layer input x_l, pd[par], aux terms are in LDS */  \
+            QPN_STAMP();                                                                                          \
+            QPN_ZSLOT(0, LAST) QPN_ZSLOT(1, LAST) QPN_ZSLOT(2, LAST) QPN_ZSLOT(3, LAST)                           \
+            QPN_STAMP();                                                                                          \
+            wg_barrier();                                   /* gate vector g_l is in LDS */                       \
+            QPN_STAMP();                                                                                          \
+            if constexpr (G::rkind(W0) != 0) {              /* every R tile of the wave reads the same g_l */     \
+                float4 xg[4]; read_x(xg, p.o_gl + l * p.Cp + 16 * q);                                             \
+                float racc[RT];                                                                                   \
+                QPN_RDOT(0, LAST) QPN_RDOT(1, LAST) QPN_RDOT(2, LAST) QPN_RDOT(3, LAST)                           \
+                if (q == 0) { QPN_RPUT(0) QPN_RPUT(1) QPN_RPUT(2) QPN_RPUT(3) }                                   \
+            } else if constexpr (LAST) { QPN_TLOAD(2) }
 
     for (int t = 1; t + 1 < Ttot; ++t) {
         // hipcc hoists every lane-constant address out of the step loop and then spills them: an opaque zero
-        // re-derives the few bases per step instead, so nothing derived from them can be hoisted
+        // re-derives the lane ids per step instead, so nothing derived from them can be hoisted
         int zero = 0;
         asm volatile("" : "+s"(zero));
+        const int lane = lane0 + zero, tid = tid0 + zero;
         const float4* wl = wl0 + zero;
-        const int q = q0 + zero, grp = grp0 + zero, qs = qs0 + zero, grps = grps0 + zero;
+        const int q = lane & (R - 1), grp = lane >> LOGR, qs = lane & (RS - 1), grps = lane >> LOGRS;
         const int par = (t & 1) * LC2;
         stamp_i = 0;
-        for (int l = 0; l < L; ++l) {
-            const int ln = l + 1 < L ? l + 1 : 0;
-            if constexpr (DB) {
-                if (l + 1 < L) {
-#pragma unroll
-                    for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wzn[i], QPN_ZPTR(wl, ln, id)); }
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wrn[i], QPN_RPTR(wl, ln, id)); }
-                }
-            }
-            wg_barrier();                                   // layer input x_l, pd[par], aux terms are in LDS
-            QPN_STAMP();
-            // ---- Z phase
-#pragma unroll
-            for (int i = 0; i < ZT; ++i) {
-                const int id = wave + i * NWV;
-                if (id < NZ) {
-                    float4 x[4]; read_x(x, p.o_xbuf + l * p.Cp + 16 * q);
-                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[i], x));
-                    const int row = id * RPT + grp, ch = row >> 1, half = row & 1, nat = half * C + ch;
-                    const float z = (acc + sm[p.o_pd + par + l * C2 + nat]) + sm[p.o_auxv + l * C2 + nat];
-                    const float zo = dpp_f<0x100 + R>(z);   // row_shl:R -> the tanh group's pre-activation
-                    if (q == 0 && !half) sm[p.o_gl + l * p.Cp + ch] = qgate(z, zo);
-                } else if (id < 2 * NZ) {
-                    const int xo = smi[p.o_sel + l] ? p.o_xbuf + l * p.Cp : p.o_xp + l * p.Cp;
-                    float4 x[4]; read_x(x, xo + 16 * q);
-                    const float acc = tree_reduce_c<LOGR>(chunk16(wz[i], x));
-                    if (q == 0) sm[p.o_pd + (LC2 - par) + l * C2 + (id - NZ) * RPT + grp] = acc;    // next step's parity
-                }
-                if constexpr (!DB) { if (l + 1 < L && id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl, ln, id)); }
-            }
-            QPN_STAMP();
-            wg_barrier();                                   // gate vector g_l is in LDS
-            QPN_STAMP();
-            // ---- R phase
-#pragma unroll
-            for (int i = 0; i < RT; ++i) {
-                const int id = wave + i * NWV;
-                if (id < NRES) {
-                    float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
-                    const float acc = tree_reduce_c<LOGR>(chunk16(wr[i], x));
-                    const int row = id * RPT + grp;
-                    if (q == 0) {
-                        const float v = (acc + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row];
-                        sm[p.o_xbuf + (l + 1) * p.Cp + row] = v;
-                        if (l + 1 < L) { const RingDesc r = p.rings[l + 1]; st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + row, v); }
-                    }
-                } else if (id < NRES + NSK) {
-                    float4 x[4]; read_x(x, p.o_gl + l * p.Cp + 16 * q);
-                    const float acc = tree_reduce_c<LOGR>(chunk16(wr[i], x));
-                    const int row = (id - NRES) * RPT + grp;
-                    if (q == 0) { const int a = (f.adaptive[l] ? p.o_ska : p.o_skf) + row; sm[a] = sm[a] + (acc + sm[f.b_skip[l] + row]); }
-                }
-                if constexpr (!DB) { if (l + 1 < L && id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl, ln, id)); }
-            }
-            if constexpr (DB) {
-                if (l + 1 < L) {
-#pragma unroll
-                    for (int i = 0; i < ZT; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) wz[i][j] = wzn[i][j];
-#pragma unroll
-                    for (int i = 0; i < RT; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) wr[i][j] = wrn[i][j];
-                }
-            }
-        }
+        for (int l = 0; l + 1 < L; ++l) { QPN_LAYER(false) }
+        { const int l = L - 1; QPN_LAYER(true) }
         QPN_STAMP();
-        // ---- tail: skip total / relu -> post 1x1 #1 -> post 1x1 #2; the tile register sets of the layers are idle
-        float4 (&wa)[4] = wz[0]; float4 (&wb)[4] = wr[0];
-        if (wave < NP1) tile_load(wa, wl + f.w_p1 + wave * 256);
+        // ---- tail: skip total / relu -> post 1x1 #1 -> post 1x1 #2
         wg_barrier();
         for (int row = tid; row < S; row += NTH) {
             const float tot = sm[p.o_skf + row] + sm[p.o_ska + row];      // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
             sm[p.o_y1 + row] = tot > 0.0f ? tot : 0.0f;
         }
         wg_barrier();
+#define QPN_PDOT(s, acc) if constexpr (QPN_TVALID(s)) { acc = tree_reduce_c<LOGRS>(chunk16(QPN_TB(s), xq)); } QPN_TLOAD((s) + 3)
+        if constexpr (W0 < G::NP1) {
+            float4 xq[4]; read_x(xq, p.o_y1 + 16 * qs);
+            float pa[T1];
+            if constexpr (0 < T1) { QPN_PDOT(0, pa[0]) } if constexpr (1 < T1) { QPN_PDOT(1, pa[1 < T1 ? 1 : 0]) }
+            if constexpr (2 < T1) { QPN_PDOT(2, pa[2 < T1 ? 2 : 0]) } if constexpr (3 < T1) { QPN_PDOT(3, pa[3 < T1 ? 3 : 0]) }
+            if (qs == 0) {
 #pragma unroll
-        for (int i = 0; i < T1; ++i) {
-            const int tile = wave + i * NWV;
-            if (i + 1 < T1 && tile + NWV < NP1) tile_load(wb, wl + f.w_p1 + (tile + NWV) * 256);
-            if (tile < NP1) {
-                float4 x[4]; read_x(x, p.o_y1 + 16 * qs);
-                const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
-                const int row = tile * RPTS + grps;
-                if (qs == 0) { const float v = acc + sm[f.b_p1 + row]; sm[p.o_y2 + row] = v > 0.0f ? v : 0.0f; }
+                for (int i = 0; i < T1; ++i) if (W0 + i * NWV < G::NP1) {
+                    const int row = (wave + i * NWV) * RPTS + grps;
+                    const float v = pa[i] + sm[f.b_p1 + row];
+                    sm[p.o_y2 + row] = v > 0.0f ? v : 0.0f;
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+        } else {                                            // no post #1 tile here: its slots of the sequence are free at once
+            if constexpr (0 < T1) { QPN_TLOAD(3) } if constexpr (1 < T1) { QPN_TLOAD(4) } if constexpr (2 < T1) { QPN_TLOAD(5) }
         }
-        if (wave < NP2) tile_load(wa, wl + f.w_p2 + wave * 256);
         wg_barrier();
+        if constexpr (W0 < G::NP2) {
+            float4 xq[4]; read_x(xq, p.o_y2 + 16 * qs);
+            float pa[T2];
+            if constexpr (0 < T2) { QPN_PDOT(T1 + 0, pa[0]) } if constexpr (1 < T2) { QPN_PDOT(T1 + 1, pa[1 < T2 ? 1 : 0]) }
+            if constexpr (2 < T2) { QPN_PDOT(T1 + 2, pa[2 < T2 ? 2 : 0]) } if constexpr (3 < T2) { QPN_PDOT(T1 + 3, pa[3 < T2 ? 3 : 0]) }
+            if (qs == 0) {
 #pragma unroll
-        for (int i = 0; i < T2; ++i) {
-            const int tile = wave + i * NWV;
-            if (i + 1 < T2 && tile + NWV < NP2) tile_load(wb, wl + f.w_p2 + (tile + NWV) * 256);
-            if (tile < NP2) {
-                float4 x[4]; read_x(x, p.o_y2 + 16 * qs);
-                const float acc = tree_reduce_c<LOGRS>(chunk16(wa, x));
-                const int row = tile * RPTS + grps;
-                if (qs == 0) sm[p.o_lg + row] = acc + sm[f.b_p2 + row];
+                for (int i = 0; i < T2; ++i) if (W0 + i * NWV < G::NP2) sm[p.o_lg + (wave + i * NWV) * RPTS + grps] = pa[i] + sm[f.b_p2 + (wave + i * NWV) * RPTS + grps];
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = wb[j];
+        }
+#undef QPN_PDOT
+        QPN_STAMP();
+        // ---- end of step: this step's layer inputs x_1..x_{L-1} go to their rings (one row each) ...
+        for (int i = tid; i < (L - 1) * C; i += NTH) {
+            const int l1 = 1 + i / C, row = i % C;
+            const RingDesc r = p.rings[l1];
+            st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + row, sm[p.o_xbuf + l1 * p.Cp + row]);
         }
         QPN_STAMP();
-        // ---- end of step: pick the sample, look up the next layer-0 input, stage aux terms / past rows
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's ring rows have left the wave
+        QPN_STAMP_DUMP();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): the ring rows have left the wave
         wg_barrier();
-        // layer-0 tiles of the next step fly while the sample is picked
-#pragma unroll
-        for (int i = 0; i < ZT; ++i) { const int id = wave + i * NWV; if (id < 2 * NZ) tile_load(wz[i], QPN_ZPTR(wl, 0, id)); }
-#pragma unroll
-        for (int i = 0; i < RT; ++i) { const int id = wave + i * NWV; if (id < NRES + NSK) tile_load(wr[i], QPN_RPTR(wl, 0, id)); }
+        // ... layer-0 tiles of the next step fly while the sample is picked, the next layer-0 input looked up and the
+        // aux terms / past rows staged
+        QPN_ZINIT(wl, 0) QPN_ZINIT(wl, 1) QPN_ZINIT(wl, 2) QPN_ZINIT(wl, 3)
+        QPN_RINIT(wl, 0) QPN_RINIT(wl, 1) QPN_RINIT(wl, 2) QPN_RINIT(wl, 3)
         if (wave == 0) {
             float bv = -INFINITY; int bi = 0x7fffffff;
             for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
@@ -706,8 +713,55 @@ __global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastPa
         }
     }
 #undef QPN_STAMP
+#undef QPN_STAMP_DUMP
 #undef QPN_ZPTR
 #undef QPN_RPTR
+#undef QPN_ZINIT
+#undef QPN_RINIT
+#undef QPN_TB
+#undef QPN_TVALID
+#undef QPN_TLOAD
+#undef QPN_ZSLOT
+#undef QPN_RDOT
+#undef QPN_RPUT
+#undef QPN_LAYER
+}
+
+template <int C, int S, int Q, int NWV, int W0>
+__device__ __forceinline__ void fast_dispatch(const DecodeParams& p, const FastParams& f, const UttView& u,
+                                              const int wave, const int lane, const int tid, const int Ttot) {
+    constexpr int NB = FastGeo<C, S, Q, NWV>::next_boundary(W0);
+    if constexpr (NB >= NWV) fast_steps<C, S, Q, NWV, W0>(p, f, u, wave, lane, tid, Ttot);
+    else {
+        if (wave < NB) fast_steps<C, S, Q, NWV, W0>(p, f, u, wave, lane, tid, Ttot);
+        else fast_dispatch<C, S, Q, NWV, NB>(p, f, u, wave, lane, tid, Ttot);
+    }
+}
+
+template <int C, int S, int Q, int NWV>
+__global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastParams f) {
+    using G = FastGeo<C, S, Q, NWV>;
+    static_assert(G::R <= 8 && G::RS <= 32 && G::ZT >= 1 && G::RT >= 1, "geometry not covered by the fast kernel");
+    constexpr int NTH = NWV * 64;
+    float* sm = SM; int* smi = SMI;
+    const UttView u = make_view(p, p.utts[blockIdx.x]);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < p.state_floats; i += NTH) sm[i] = 0.0f;
+    for (int i = tid; i < p.n_bias; i += NTH) sm[p.o_bias + i] = p.flat[p.bias_src[i]];
+    __syncthreads();
+    const int Ttot = u.n0 + u.n_samples;
+    if (Ttot < 3) return;
+    if (wave == 0) {
+        causal_rows(p, u, u.known[0], u.known[1], 1, lane);
+        if (lane == 0) { smi[p.o_samp] = u.known[0]; smi[p.o_samp + 1] = u.known[1]; }
+    }
+    stage_aux(p, u, 1, tid, NTH);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (Ttot > 3) stage_taps(p, u, 2, tid, NTH, p.status);
+    __syncthreads();
+    fast_dispatch<C, S, Q, NWV, 0>(p, f, u, wave, lane, tid, Ttot);
 }
 
 // ================================================================== host side
@@ -1069,24 +1123,17 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024) {
         QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
         const int lb = p.lds_floats * (int)sizeof(float);
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     }
     QPN_HIP(hipEventRecord(h->ev0, stream));
     const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
-    // 16 waves, tiles re-requested in place (one phase ahead) measured 54k samples/s at B=1; the 8-wave variant that
-    // double-buffers a full layer of tiles is instruction-issue bound (42k) -- kept behind QPN_DECODE_W8 for study
-    const bool w16 = getenv("QPN_DECODE_W8") == nullptr;
-    const size_t lds_bytes = (size_t)p.lds_floats * sizeof(float);
-    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256) {
-        if (w16) hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-        else hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 8, true>), dim3(B), dim3(512), lds_bytes, stream, p, h->fp);
-    } else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256) {
-        if (w16) hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-        else hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 8, true>), dim3(B), dim3(512), lds_bytes, stream, p, h->fp);
-    } else
+    const size_t lds_bytes = ((size_t)p.lds_floats + (p.stamps ? 120 * QPN_NW : 0)) * sizeof(float);
+    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256)
+        hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+    else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256)
+        hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+    else
         hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), lds_bytes, stream, p);
     QPN_HIP(hipGetLastError());
     QPN_HIP(hipEventRecord(h->ev1, stream));
