@@ -425,7 +425,185 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
     if (launch_wgrad2<BMODE, 2, 12>(w, nch, stream) == 0) return true;
     return false;
 }
+// ------------------------------------------------------------------------------------------ weight gradients, v3
+// Same contraction and slab layout as k_wgrad2, for the geometries where the tile counts are known at compile time
+// (M = 64*MPW rows of dW -> every wave owns exactly MPW m-tiles, N per column group = 16*NT): no per-tile guards in
+// the matrix-core loop, no branches around the staging loads (out-of-range rows are clamped and zeroed, the three
+// sources of the [x_cur | x_past | aux] operand become one per-thread base/stride), bias column sums taken from the
+// staging registers instead of 32 LDS reads per stage.  k_wgrad2 stays as the generic fallback.
+template <int BMODE, int MPW, int NT>
+__global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
+    extern __shared__ float sm[];
+    constexpr int RS = 32, Mp = 64 * MPW, Np = 16 * NT;
+    constexpr int ldA = ((Mp + 15) / 32) * 32 + 16, ldB = ((Np + 15) / 32) * 32 + 16;       // tr_ldt
+    constexpr int A4 = Mp / 4, ARS = 256 / A4, NA = RS / ARS;                               // A: every thread active, NA full passes
+    constexpr int B4 = Np / 4, BRS = 256 / B4, NB = (RS + BRS - 1) / BRS;                   // B: threads < BRS*B4 active
+    static_assert(256 % A4 == 0 && RS % ARS == 0, "A staging must tile 32 rows exactly");
+    const int y = blockIdx.y, ch = blockIdx.x, zg = blockIdx.z;
+    float* As = sm; float* Bs = sm + RS * ldA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Rl = w.R[y];
+    const int64_t total = (int64_t)Rl * w.nb;
+    const int64_t per = ((total + nch - 1) / nch + RS - 1) / RS * RS;
+    const int rbeg = (int)(per * ch), rend = (int)(per * ch + per < total ? per * ch + per : total);
+    const float* A = w.A + (size_t)y * w.A_lstride;
+    const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
+    const float* B1 = w.B1 + (size_t)y * w.B_lstride;
+    const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
+    const int* tap = (BMODE == 3 && w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
+    const int row0A = w.row0A[y], row0B = w.row0B[y], dil = w.dil[y], ncol0 = zg * Np;
+    const unsigned uR = (unsigned)(Rl > 0 ? Rl : 1);
+    const bool multi = w.nb > 1;
+    const int gbias = zg == 0 ? w.gbias[y] : -1, goff = w.goff[y];
+    const int a_col = (tid % A4) * 4, a_row0 = tid / A4;
+    const int b_col = (tid % B4) * 4, b_row0 = tid / B4;
+    const int n = ncol0 + b_col;
+    const bool b_act = tid < BRS * B4;
+    const bool b_pad = n >= w.Nvalid;                           // zero padding columns of the operand (K padded to 16)
+    // B operand source of this thread's four columns
+    const float* bbase; int bstride; bool use_tap = false;
+    if (BMODE == 3) {
+        if (n < w.C) { bbase = B1 + n; bstride = w.C; }
+        else if (n < 2 * w.C) { bbase = B1 + (n - w.C); bstride = w.C; use_tap = true; }
+        else { bbase = w.hup + (b_pad ? 0 : n - 2 * w.C); bstride = w.Ap; }
+    } else { bbase = B1 + n; bstride = w.ldb; }
+    const ptrdiff_t b2off = (BMODE == 2) ? (B2 - B1) : 0;
+
+    f32x4 acc[MPW][NT];
+#pragma unroll
+    for (int a = 0; a < MPW; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = (f32x4){0, 0, 0, 0};
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
+    int tpv[NB];
+
+    // rows of a stage: r in [0,32); rows at or past rend are clamped to the last valid row and zeroed
+    auto rowsplit = [&](int rr, int& b, int& i) { if (multi) { b = (int)((unsigned)rr / uR); i = rr - b * (int)uR; } else { b = 0; i = rr; } };
+    auto taps = [&](int rs) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int r = b_row0 + k * BRS;
+            int rr = rs + r; rr = rr < rend ? rr : rend - 1;
+            int b, i; rowsplit(rr, b, i);
+            const int nloc = row0B + i;
+            tpv[k] = (use_tap && b_act) ? (tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - dil) : nloc;
+        }
+    };
+    auto fetch = [&](int rs) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int r = a_row0 + k * ARS;
+            int rr = rs + r; const bool ok = rr < rend; rr = ok ? rr : rend - 1;
+            int b, i; rowsplit(rr, b, i);
+            const size_t o = ((size_t)b * w.rowsA + row0A + i) * w.lda + a_col;
+            float4 v = *(const float4*)(A + o);
+            if (A2) { const float4 v2 = *(const float4*)(A2 + o); v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w; }
+            ra[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (b_act) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int r = b_row0 + k * BRS;
+                int rr = rs + r; const bool ok = r < RS && rr < rend && !b_pad; rr = rr < rend ? rr : rend - 1;
+                int b, i; rowsplit(rr, b, i);
+                const size_t row = (size_t)b * w.rowsB + (BMODE == 3 ? tpv[k] : row0B + i);
+                const float* ptr = bbase + row * bstride;
+                float4 v = *(const float4*)ptr;
+                if (BMODE == 2) rb2[k] = *(const float4*)(ptr + b2off);
+                rb[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    (void)ra2;
+    if (rbeg < rend) {
+        if (BMODE == 3) taps(rbeg);
+        fetch(rbeg);
+        if (BMODE == 3 && rbeg + RS < rend) taps(rbeg + RS);
+    }
+    const int g = lane >> 4, cl = lane & 15;
+    for (int rs = rbeg; rs < rend; rs += RS) {
+        // registers -> LDS
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const float4 v = ra[k];
+            cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;
+            *(float4*)(As + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
+        }
+        if (b_act) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int r = b_row0 + k * BRS;
+                if (r < RS) {
+                    float4 v = rb[k];
+                    if (BMODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    else if (BMODE == 2) { v.x *= rb2[k].x; v.y *= rb2[k].y; v.z *= rb2[k].z; v.w *= rb2[k].w; }
+                    *(float4*)(Bs + (size_t)r * ldB + b_col) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // next stage's rows fly while the matrix cores work on this one
+        if (rs + RS < rend) {
+            fetch(rs + RS);
+            if (BMODE == 3 && rs + 2 * RS < rend) taps(rs + 2 * RS);       // gather rows of the stage after next
+        }
+#pragma unroll
+        for (int ks = 0; ks < RS / 4; ++ks) {
+            float bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = Bs[(4 * ks + g) * ldB + 16 * nt + cl];
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const float a = As[(4 * ks + g) * ldA + 16 * (wave + 4 * mi) + cl];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[nt], acc[mi][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = w.slab + (size_t)ch * w.gstage;
+#pragma unroll
+    for (int mi = 0; mi < MPW; ++mi) {
+        const int mt = wave + 4 * mi;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * mt + 4 * (lane >> 4) + i, nn = 16 * nt + (lane & 15);
+                out[goff + (size_t)m * w.ldc + ncol0 + nn] = acc[mi][nt][i];
+            }
+        }
+    }
+    if (gbias >= 0) {          // bias grads: column sums of A, reduced over the ARS row groups of the staging layout
+        *(float4*)(sm + (size_t)a_row0 * Mp + a_col) = cs4;
+        __syncthreads();
+        if (tid < Mp) { float s = 0.f; for (int r = 0; r < ARS; ++r) s += sm[r * Mp + tid]; out[gbias + tid] = s; }
+    }
+}
+
+template <int BMODE, int MPW, int NT>
+static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
+    const int Ng = w.N / w.ncol_groups;
+    if (w.M != 64 * MPW || Ng != 16 * NT || w.N % w.ncol_groups || (w.Nvalid != w.N && (w.ncol_groups != 1 || w.Nvalid % 4))) return false;
+    if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4))) return false;
+    const size_t lds = (size_t)32 * (tr_ldt(64 * MPW) + tr_ldt(16 * NT)) * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    return true;
+}
+static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
+    if (getenv("QPN_WGRAD_GENERIC")) return false;
+    switch (w.bmode) {
+    case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 / 32, n_aux 33..48
+    case 2: return launch_wgrad3<2, 1, 4>(w, nch, stream) || launch_wgrad3<2, 4, 4>(w, nch, stream);       // res / skip 1x1 at C = 64
+    case 1: return launch_wgrad3<1, 4, 4>(w, nch, stream);                                                  // post-net, 64-column groups
+    default: return false;
+    }
+}
+
 static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
+    if (wgrad3_any(w, nch, stream)) return true;
     switch (w.bmode) {
     case 1: return wgrad2_mode<1>(w, nch, stream);
     case 2: return wgrad2_mode<2>(w, nch, stream);

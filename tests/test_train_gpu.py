@@ -110,3 +110,40 @@ def test_torch_adam_on_views_matches(cuda, golden_dir):
         opt.zero_grad(); loss.backward(); opt.step()
         losses.append(loss.item())
     np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+
+
+def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
+    """Two chunks per step (rows of both batch items flattened into the weight-gradient contraction): the
+    compile-time-tiled k_wgrad3 and the generic k_wgrad2 (QPN_WGRAD_GENERIC=1) both match the numpy oracle."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 21)
+    x, h, t, d, b = synth.train_inputs(cfg, 500, 61, 2500)
+    xs = np.random.RandomState(5).randint(0, cfg.n_quantize, size=x.shape[1] + 1).astype(np.int64)
+    # second row: same features (rows of a batch share the chunk geometry), another waveform
+    x = np.stack([x[0], xs[:-1]]); t = np.stack([t[0], xs[1:]])
+    h = np.concatenate([h, h]); d = np.concatenate([d, d]); b = np.concatenate([b, b])
+    BL = int(b[0])
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    _, dl = TO.ce_loss(lg, t[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    grads = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("QPN_WGRAD_GENERIC", "1")
+        m = util.build_model(cfg, flat, cuda).train()
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        logits = m(xt, ht, dt, bt)
+        loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+        loss.backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy())
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for grad in grads:
+        for k, (o, shp) in offs.items():
+            n = int(np.prod(shp))
+            a, r = grad[o:o + n], og[o:o + n]
+            assert np.abs(a - r).max() <= 2e-5 * scale + 1e-4 * np.abs(r).max(), "grad mismatch in " + k
+    assert np.abs(grads[0] - grads[1]).max() <= 1e-6 * scale
