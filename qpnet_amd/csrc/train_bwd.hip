@@ -233,12 +233,14 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 // output tiles), partial result written to its slab.  dW = A^T B with
 //   A[row][m]  : plain array, or the sum of two arrays (grad wrt a layer output = own-row + scattered part)
 //   B[row][n]  : plain | relu(array) | product of two arrays (gate = sigma*tanh) | [x_cur | x_past | aux | 0]
+//                | one-hot of the row's sample class (k_wgrad3 only)
 struct Wg2 {
     const float* A; const float* A2; size_t A_lstride; int lda, M;        // per-layer stride (floats)
     int rowsA;                                                              // rows per batch item in A's array
     int bmode; const float* B1; const float* B2; size_t B_lstride; int ldb, N, Nvalid;
     int rowsB;
     const float* hup; const int* tap; int C, Ap;
+    const int* xc;                                                          // bmode 4: B[t][q] = (xc[row] == q), one-hot of the sample class
     int nb, nlayers;
     float* slab; int gstage;
     int row0A[TR_MAXL], row0B[TR_MAXL], R[TR_MAXL];                         // window per layer
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     const int rbeg = (int)(per * ch), rend = (int)(per * ch + per < total ? per * ch + per : total);
     const float* A = w.A + (size_t)y * w.A_lstride;
     const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
-    const float* B1 = w.B1 + (size_t)y * w.B_lstride;
+    const float* B1 = BMODE == 4 ? nullptr : w.B1 + (size_t)y * w.B_lstride;
     const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
     const int* tap = (BMODE == 3 && w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
     const int row0A = w.row0A[y], row0B = w.row0B[y], dil = w.dil[y], ncol0 = zg * Np;
@@ -466,7 +468,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
         if (n < w.C) { bbase = B1 + n; bstride = w.C; }
         else if (n < 2 * w.C) { bbase = B1 + (n - w.C); bstride = w.C; use_tap = true; }
         else { bbase = w.hup + (b_pad ? 0 : n - 2 * w.C); bstride = w.Ap; }
-    } else { bbase = B1 + n; bstride = w.ldb; }
+    } else if (BMODE == 4) { bbase = nullptr; bstride = 0; }
+    else { bbase = B1 + n; bstride = w.ldb; }
     const ptrdiff_t b2off = (BMODE == 2) ? (B2 - B1) : 0;
 
     f32x4 acc[MPW][NT];
@@ -508,9 +511,15 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
                 int rr = rs + r; const bool ok = r < RS && rr < rend && !b_pad; rr = rr < rend ? rr : rend - 1;
                 int b, i; rowsplit(rr, b, i);
                 const size_t row = (size_t)b * w.rowsB + (BMODE == 3 ? tpv[k] : row0B + i);
-                const float* ptr = bbase + row * bstride;
-                float4 v = *(const float4*)ptr;
-                if (BMODE == 2) rb2[k] = *(const float4*)(ptr + b2off);
+                float4 v;
+                if (BMODE == 4) {
+                    const int dlt = w.xc[row] - n;
+                    v = make_float4(dlt == 0 ? 1.f : 0.f, dlt == 1 ? 1.f : 0.f, dlt == 2 ? 1.f : 0.f, dlt == 3 ? 1.f : 0.f);
+                } else {
+                    const float* ptr = bbase + row * bstride;
+                    v = *(const float4*)ptr;
+                    if (BMODE == 2) rb2[k] = *(const float4*)(ptr + b2off);
+                }
                 rb[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -593,6 +602,7 @@ static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     return true;
 }
 static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
+    if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream);                                        // causal table: C = 64, 128-class groups
     if (getenv("QPN_WGRAD_GENERIC")) return false;
     switch (w.bmode) {
     case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 / 32, n_aux 33..48
@@ -605,6 +615,7 @@ static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
 static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
     if (wgrad3_any(w, nch, stream)) return true;
     switch (w.bmode) {
+    case 4: return false;                       // one-hot operand: k_wgrad3 only (the launcher checks the geometry first)
     case 1: return wgrad2_mode<1>(w, nch, stream);
     case 2: return wgrad2_mode<2>(w, nch, stream);
     case 3: return wgrad2_mode<3>(w, nch, stream);
@@ -670,12 +681,12 @@ __global__ __launch_bounds__(256) void k_up_bwd(TrainParams p, TrainBwd bw, int 
     const int U = p.U, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i <= U; i += 256) accu[i] = 0.f;
     __syncthreads();
-    const int64_t total = (int64_t)p.B * p.N1;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < total ? r0 + rows_per_wg : total;
-    for (int64_t rr = r0 + wave; rr < r1; rr += 4) {
-        const int b = (int)(rr / p.N1), n = (int)(rr - (int64_t)b * p.N1);
-        const int64_t q = (int64_t)p.F * U - p.N1 + n;
-        const int64_t f = q / U; const int j = (int)(q - f * U);
+    const int total = p.B * p.N1;                  // rows and F*U fit 32 bits (checked by the forward launcher)
+    const int r0 = blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < total ? r0 + rows_per_wg : total;
+    for (int rr = r0 + wave; rr < r1; rr += 4) {
+        const int b = rr / p.N1, n = rr - b * p.N1;
+        const int q = p.F * U - p.N1 + n;
+        const int f = q / U; const int j = q - f * U;
         float dv = 0.f, pr = 0.f;
         if (lane < p.A) { dv = bw.DHUP[((size_t)b * p.N1 + n) * p.Ap + lane]; pr = dv * p.h[((size_t)b * p.A + lane) * p.F + f]; }
         for (int s = 32; s >= 1; s >>= 1) { dv += __shfl_xor(dv, s); pr += __shfl_xor(pr, s); }
@@ -760,6 +771,13 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
         ok = ok && wgrad2_any(w, nch, stream);
     }
+    if (bw.g_cw >= 0) {   // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
+        w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
+        w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
+        w.N = Q; w.Nvalid = Q; w.rowsB = N1 + 1; w.ldb = 0; w.ldc = Q;
+        for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
+        ok = ok && wgrad2_any(w, nch, stream);
+    }
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 64, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD, stream);
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
@@ -770,8 +788,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         const int CB = C < 64 ? C : 64;
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0) hipLaunchKernelGGL(k_up_bwd, dim3(nwg), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpw);
+        if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
+        if (p.U > 0) { const int nwu = 1024, rpu = (int)((total + nwu - 1) / nwu); hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpu); }
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());

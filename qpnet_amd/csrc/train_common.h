@@ -44,6 +44,7 @@ struct TrainParams {
     float* SG; float* TH;     // [L][B][N1][C]
     float* HUP;               // [B][N1][Ap]
     int* TAP;                 // [LA][B][N1]
+    int* XC;                  // [B][N1+1] sample classes of the rows (x % Q), for the causal conv's weight gradient
     float* S0; float* Y0;     // [B][BL][S] pre-relu skip sum / post1
     float* logits;            // [B][BL][Q]
     int* status;
@@ -70,6 +71,7 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     // slab offsets (floats) of every weight-grad block
     int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
     int g_p1, g_bp1, g_p2, g_bp2;
+    int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
 };
 
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)

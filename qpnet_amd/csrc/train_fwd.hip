@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     int64_t s0 = p.x[(size_t)b * p.T + xo] % Q, s1 = p.x[(size_t)b * p.T + xo + 1] % Q;
     if (s0 < 0) s0 += Q;
     if (s1 < 0) s1 += Q;
+    if (lane == 0) { p.XC[(size_t)b * (p.N1 + 1) + n] = (int)s0; if (n == p.N1 - 1) p.XC[(size_t)b * (p.N1 + 1) + p.N1] = (int)s1; }
     float* X0 = p.X + ((size_t)b * p.N1 + n) * C;
     for (int c = lane; c < C; c += 64) {
         float v = p.flat[p.causal_w + ((size_t)c * Q + s0) * 2] + p.flat[p.causal_w + ((size_t)c * Q + s1) * 2 + 1];

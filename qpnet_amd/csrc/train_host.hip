@@ -172,8 +172,19 @@ static int train_init(qpn_handle* h) {
     bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
     for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
     for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
+    // causal conv table: dW[c][q][tap] = sum_t dX0[t][c] * onehot(x[t-1+tap])[q] is one more time contraction (k_wgrad3 mode 4)
+    // when its tiles fit (C = 64, Q a multiple of 128); otherwise the LDS-histogram kernel owns it (gs stays -1)
+    bw.g_cw = bw.g_cb = -1;
+    if (C == 64 && Q % 128 == 0) {
+        bw.g_cw = gtake(2 * C * Q); bw.g_cb = gtake(C);
+        for (int c = 0; c < C; ++c) {
+            for (int q = 0; q < Q; ++q) for (int tp = 0; tp < 2; ++tp) gs[g.causal_w + ((int64_t)c * Q + q) * 2 + tp] = bw.g_cw + tp * C * Q + c * Q + q;
+            gs[g.causal_b + c] = bw.g_cb + c;
+        }
+    }
     bw.gstage = go; bw.nch = 64; bw.n_params = g.n_params;
-    // causal table / bias and the upsampling kernel are written by dedicated kernels (gs stays -1)
+    if (const char* e = getenv("QPN_WGRAD_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 512) bw.nch = v; }   // tuning knob: time chunks (= partial slabs)
+    // the upsampling kernel's gradient is written by a dedicated kernel (gs stays -1)
 
     const size_t nmap = map.size();
     QPN_HIP(hipMalloc(&t->d_wmap, nmap * sizeof(int)));
@@ -221,6 +232,9 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
                       (long long)(N0 - BL), BL, (long long)N0, (long long)T, (long long)Td, (long long)(g.U > 0 ? F * g.U : F));
         return QPN_EINVAL;
     }
+    if (T >= ((int64_t)1 << 31) || Td >= ((int64_t)1 << 31) || F * (g.U > 0 ? g.U : 1) >= ((int64_t)1 << 31) || (int64_t)B * N0 >= ((int64_t)1 << 31)) {
+        qpn_set_error("chunk too long: the training kernels index rows with 32 bits"); return QPN_EINVAL;
+    }
     TrainParams& p = t->tp;
     p.B = B; p.T = (int)T; p.F = (int)F; p.Td = (int)Td; p.BL = BL; p.N0 = (int)N0; p.N1 = (int)N0 - 1; p.maxd = maxd;
     const int C = g.C, S = g.S, L = g.L, N1 = p.N1;
@@ -234,7 +248,8 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
     TrainBwd& bw = t->bw;
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
-    size_t need = nX + 2 * nG + nH + 2 * nS + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + 4096;
+    const size_t nXC = (size_t)B * (N1 + 1);
+    size_t need = nX + 2 * nG + nH + 2 * nS + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + 4096;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -254,6 +269,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     p.X = carve(nX); p.SG = carve(nG); p.TH = carve(nG); p.HUP = carve(nH); p.S0 = carve(nS); p.Y0 = carve(nS);
     bw.DXA[0] = carve((size_t)(L + 1) * nDX); bw.DXB[0] = carve((size_t)(L + 1) * nDX); bw.DXA[1] = bw.DXB[1] = nullptr;   // DXB directly follows DXA (one memset)
     bw.DZ = carve((size_t)L * nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
+    p.XC = (int*)carve(nXC);
     p.TAP = t->d_tap; p.status = t->d_status;
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
