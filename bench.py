@@ -202,10 +202,13 @@ def run_train(args, rank, local, world):
     nchunks = 4
     host_batches = [synth.train_inputs(cfg, 20000, 5000 + 17 * (rank + world * i), 30000, f0_lo=55.0, f0_hi=300.0) for i in range(nchunks)]
     batches = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in hb] for hb in host_batches]
+    # the loader knows ceil(max d) of a chunk on the host (it built d there), so the step needs no device read-back
+    maxds = [int(np.ceil(hb[3]).max()) for hb in host_batches]
+    blens = [hb[4] for hb in host_batches]
 
     def step(i, want_loss=False):
-        x, h, t, d, b = batches[i % nchunks]
-        return tr.step(x, h, t, d, b, want_loss=want_loss)
+        x, h, t, d, _ = batches[i % nchunks]
+        return tr.step(x, h, t, d, blens[i % nchunks], want_loss=want_loss, maxd=maxds[i % nchunks])
 
     for i in range(args.warmup):
         step(i)

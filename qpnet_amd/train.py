@@ -111,7 +111,9 @@ class FusedTrainer:
         self.m = self.v = None
         self.pg, self.world = process_group, world_size
 
-    def step(self, x, h, t, d, blength, want_loss=True):
+    def step(self, x, h, t, d, blength, want_loss=True, maxd=None):
+        """One optimisation step.  maxd = ceil(max(d)) of the chunk; a loader that built d on the host (the reference's
+        train_generator does, qpnet_train.py:268-272) passes it in, otherwise it is read back from the device (one sync)."""
         model = self.model
         dev = x.device
         L, hd = model._native(dev)
@@ -120,7 +122,8 @@ class FusedTrainer:
             self.m = torch.zeros_like(flat); self.v = torch.zeros_like(flat)
             self.g = torch.empty_like(flat)
         BL = int(blength[0])
-        maxd = int(torch.max(d.ceil()))
+        if maxd is None:
+            maxd = int(torch.max(d.ceil()))
         B, T = x.shape
         if getattr(self, "_logits", None) is None or self._logits.shape != (B, BL, model.n_quantize):
             self._logits = torch.empty((B, BL, model.n_quantize), dtype=torch.float32, device=dev)
