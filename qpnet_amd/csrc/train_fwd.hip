@@ -66,42 +66,58 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     }
 }
 
-// dynamic LDS: As[TM][lda(Ktp)] | Gs[TM][lda(C)],  TM = 16*MT rows of time per workgroup
+// One gated residual block on one tile of TM = 16*MT time rows starting at row n0 of batch item b.
+// dynamic LDS: As[TM][lda(Ktp)] | Gs[TM][lda(C)]
 template <int MT>
-__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
+__device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l, const int last, const int b, const int n0, float* sm) {
     constexpr int TM = 16 * MT;
-    extern __shared__ float sm[];
     const TrLayer ly = p.layers[l];
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int lda = tr_lda(Ktp), ldg = tr_lda(C);
     float* As = sm; float* Gs = sm + TM * lda;
-    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
     const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
-    // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4)
+    // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4).
+    //      All tap rows first, then all row segments, then the LDS stores: two memory round trips per tile, not two per row.
     {
         const int K4 = Ktp / 4;                       // float4 columns per row
         const int tpr = K4 < 64 ? K4 : 64;            // threads per row (one float4 each, extra columns in a second pass)
-        const int rpp = 256 / tpr;                    // rows per pass
+        const int rpp = 256 / tpr;                    // rows per pass (>= 4)
         const int tr = tid / tpr, tc = tid - tr * tpr;
-        if (tr < rpp)
-            for (int r = tr; r < TM; r += rpp) {
-                const int n = n0 + r;
-                const int tp = n < p.N1 ? (taps ? taps[n] : n - ly.dilation) : 0;
-                for (int c4 = tc; c4 < K4; c4 += tpr) {
-                    const int k = c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (n < p.N1) {
-                        if (k < C) v = *(const float4*)(Xin + (size_t)n * C + k);
-                        else if (k < 2 * C) v = *(const float4*)(Xin + (size_t)tp * C + (k - C));
-                        else if (k < 2 * C + Ap) v = *(const float4*)(hup + (size_t)n * Ap + (k - 2 * C));
+        constexpr int NR = TM / 4;                    // passes needed at most
+        if (tr < rpp) {
+            int tp[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int n = n0 + tr + k * rpp;
+                tp[k] = (tr + k * rpp < TM && n < p.N1) ? (taps ? taps[n] : n - ly.dilation) : 0;
+            }
+            for (int c4 = tc; c4 < K4; c4 += tpr) {
+                const int k0 = c4 * 4;
+                const int kind = k0 < C ? 0 : k0 < 2 * C ? 1 : k0 < 2 * C + Ap ? 2 : 3;
+                const float* base = kind == 0 ? Xin + k0 : kind == 1 ? Xin + (k0 - C) : hup + (kind == 2 ? k0 - 2 * C : 0);
+                const int stride = kind == 2 ? Ap : C;
+                float4 v[NR];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int r = tr + k * rpp, n = n0 + r;
+                    const bool ok = r < TM && n < p.N1 && kind != 3;
+                    const int row = ok ? (kind == 1 ? tp[k] : n) : 0;
+                    const float4 t = *(const float4*)(base + (size_t)row * stride);
+                    v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int r = tr + k * rpp;
+                    if (r < TM) {
+                        float* dst = As + (size_t)r * lda + k0;
+                        *(float2*)dst = make_float2(v[k].x, v[k].y); *(float2*)(dst + 2) = make_float2(v[k].z, v[k].w);
                     }
-                    float* dst = As + (size_t)r * lda + k;
-                    *(float2*)dst = make_float2(v.x, v.y); *(float2*)(dst + 2) = make_float2(v.z, v.w);
                 }
             }
+        }
     }
     __syncthreads();
     const float4* W1 = p.wp + ly.w1_f4;
@@ -149,6 +165,14 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
                 if (n0 + r < p.N1) Xout[(size_t)(n0 + r) * C + c] = (acc[mt][0][i] + bb) + As[(size_t)r * lda + c];
             }
     }
+}
+
+// one layer per launch.  [A persistent all-layers kernel with per-tile completion flags was tried: on this multi-XCD part
+// an agent-scope release is a whole-L2 write-back (buffer_wbl2 sc1) per tile, 4x slower than the eight launches.]
+template <int MT>
+__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
+    extern __shared__ float sm[];
+    layer_fwd_tile<MT>(p, l, last, blockIdx.y, p.layers[l].s_out + blockIdx.x * 16 * MT, sm);
 }
 
 // dynamic LDS: St[TM][lda(S)] | Yt[TM][max(lda(S), 2 lda(C))]  (the two G_l staging buffers alias Yt)
@@ -327,9 +351,23 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     }
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
-    for (int l = 0; l < p.L; ++l) {
-        const int rows = p.N1 - p.layers[l].s_out;
-        hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds_layer, stream, p, l, l == p.L - 1 ? 1 : 0);
+    {
+        const char* e1 = getenv("QPN_LAYER_MT"); const char* e2 = getenv("QPN_LAYER_LDS");
+        // 16-row tiles (twice the workgroups, all co-resident) measured 8 % faster than 32-row tiles for the layer forward;
+        // QPN_LAYER_MT / QPN_LAYER_LDS (occupancy cap) are tuning knobs (tools/sweep_layer.sh)
+        const int lmt = e1 ? atoi(e1) : 1; const size_t pad = e2 ? (size_t)atoi(e2) : 0;
+        for (int l = 0; l < p.L; ++l) {
+            const int rows = p.N1 - p.layers[l].s_out;
+            if (lmt == 1) {
+                size_t lds1 = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float); if (pad > lds1) lds1 = pad;
+                if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+                hipLaunchKernelGGL((k_layer_fwd<1>), dim3((rows + 15) / 16, p.B), dim3(256), lds1, stream, p, l, l == p.L - 1 ? 1 : 0);
+            } else {
+                size_t lds2 = lds_layer; if (pad > lds2) lds2 = pad;
+                if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, l == p.L - 1 ? 1 : 0);
+            }
+        }
     }
     qpn_prof_mark(PG_LAYER_FWD, stream);
     hipLaunchKernelGGL((k_post_fwd<MT>), dim3((p.BL + TM - 1) / TM, p.B), dim3(512), lds_post, stream, p);
