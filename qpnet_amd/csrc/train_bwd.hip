@@ -710,6 +710,28 @@ __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float
     w[i] = w[i] - (lr / bc1) * (mi / denom);
 }
 
+// Zero exactly what the backward reads without having written it.  Grad wrt X[j] has two parts:
+//   DXA[j] (own-row part): layer j writes rows [s_out(j), N1); layer j-1 (or the causal backward for j = 0) reads from
+//           row s_in(j) (0 for j = 0) -> rows [s_in(j) or 0, s_out(j)) must read as zero;
+//   DXB[j] (pitch-tap scatter part): a fixed layer is the unique writer of rows [s_in(j), N1 - dilation), so only the last
+//           `dilation` rows (and, for j = 0, nothing in front) need zeros; an adaptive layer adds with atomics -> all rows.
+// X[L]'s gradient is never read (the last block's residual output is unused, qpnet.py:306-309).
+__global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
+    const int j = blockIdx.y, b = blockIdx.z, C = p.C;
+    const TrLayer ly = p.layers[j];
+    const size_t nDX = (size_t)p.B * p.N1 * C;
+    float* A = bw.DXA[0] + (size_t)j * nDX + (size_t)b * p.N1 * C;
+    float* Bq = bw.DXB[0] + (size_t)j * nDX + (size_t)b * p.N1 * C;
+    const int a0 = j == 0 ? 0 : ly.s_in, a1 = ly.s_out;
+    const int b0 = ly.adaptive ? 0 : p.N1 - ly.dilation, b1 = p.N1;
+    const size_t na = (size_t)(a1 - a0) * C / 4, nb = (size_t)(b1 > b0 ? b1 - b0 : 0) * C / 4;      // C % 16 == 0
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < na) ((float4*)(A + (size_t)a0 * C))[i] = z;
+        else ((float4*)(Bq + (size_t)(b0 > 0 ? b0 : 0) * C))[i - na] = z;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
@@ -722,8 +744,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
-    QPN_HIP(hipMemsetAsync(bw.DXA[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
-    QPN_HIP(hipMemsetAsync(bw.DXB[0], 0, (size_t)(L + 1) * nDX * sizeof(float), stream));
+    // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
+    hipLaunchKernelGGL(k_zero_dx, dim3(64, L, B), dim3(256), 0, stream, p, bw);
     hipLaunchKernelGGL((k_post_bwd<MT>), dim3((BL + TM - 1) / TM, B), dim3(512), lds_post, stream, p, bw);
     qpn_prof_mark(PG_POST_BWD, stream);
     for (int l = L - 1; l >= 0; --l) {
