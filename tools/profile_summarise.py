@@ -1,0 +1,56 @@
+"""Boil the rocprofv3 output of tools/profile_round.sh down to the small files kept under profiles/."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = "gpurun_out/prof_%s" % tag
+dst = "gpurun_out/profiles_%s" % tag
+os.makedirs(dst, exist_ok=True)
+
+
+def find(pattern):
+    f = glob.glob(os.path.join(src, pattern), recursive=True)
+    return f[0] if f else None
+
+
+for what in ("train", "decode"):
+    f = find("%s_stats/**/*kernel_stats.csv" % what)
+    if f:
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, what)), "w") as o:
+            w = csv.writer(o, quoting=csv.QUOTE_ALL)
+            for r in rows[:40]:
+                r[0] = r[0][:160]
+                w.writerow(r)
+
+traffic = {"note": "HBM bytes = 2*FETCH_SIZE + WRITE_SIZE (KB*1024; gfx950 correction of MI355X_MICROARCH.md), separate --pmc passes, summed per kernel name"}
+per = {}
+for what in ("train", "decode"):
+    agg = defaultdict(lambda: defaultdict(float)); calls = defaultdict(int)
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = find("%s_%s/**/*counter_collection.csv" % (what, c))
+        if not f:
+            continue
+        for r in csv.DictReader(open(f)):
+            name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+            name = name.split("(")[0][:80]
+            agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "FETCH_SIZE":
+                calls[name] += 1
+    per[what] = {k: {"calls": calls[k], "FETCH_SIZE_KB": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB": v.get("WRITE_SIZE", 0.0),
+                     "hbm_bytes": (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024} for k, v in agg.items()}
+json.dump(per, open(os.path.join(dst, "%s_pmc_by_kernel.json" % tag), "w"), indent=1)
+# the figures bench.py reports
+dec = [v for k, v in per.get("decode", {}).items() if "k_decode" in k]
+if dec:
+    n = 20 * (600 * 110 - 1)
+    traffic["decode"] = {"kernel": "k_decode_fast<64,256,256,16>", "workload": "batch 20 x 600 frames (20 x 65999 samples)",
+                         "hbm_bytes_per_sample": sum(v["hbm_bytes"] for v in dec) / n}
+wg = [(k, v) for k, v in per.get("train", {}).items() if "k_wgrad" in k]
+if wg:
+    steps = 3.0    # 1 warmup + 2 timed steps in the PMC runs (the profiled extra steps of bench.py are included: see calls)
+    calls = max(v["calls"] for _, v in wg)
+    traffic["train"] = {"kernel": "k_wgrad3/k_wgrad2 (5 launches per step)", "workload": "paper-size step, chunk 20680 samples",
+                        "hbm_bytes_per_step": sum(v["hbm_bytes"] / max(v["calls"], 1) * (2 if "1, 4, 4" in k else 1) for k, v in wg)}
+json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
