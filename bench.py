@@ -252,7 +252,7 @@ def run_train(args, rank, local, world):
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                      "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None,
-                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc, k_wgrad2 launches of one step)",
+                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, the weight-gradient launches of one step)",
                      "kernel": PG_NAMES[dom],
                      "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
