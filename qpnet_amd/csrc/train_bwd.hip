@@ -746,6 +746,11 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
     hipLaunchKernelGGL(k_zero_dx, dim3(64, L, B), dim3(256), 0, stream, p, bw);
+    if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
+        const size_t lds1 = lds_post / MT;
+        if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+        hipLaunchKernelGGL((k_post_bwd<1>), dim3((BL + 15) / 16, B), dim3(512), lds1, stream, p, bw);
+    } else
     hipLaunchKernelGGL((k_post_bwd<MT>), dim3((BL + TM - 1) / TM, B), dim3(512), lds_post, stream, p, bw);
     qpn_prof_mark(PG_POST_BWD, stream);
     for (int l = L - 1; l >= 0; --l) {
