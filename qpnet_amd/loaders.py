@@ -141,3 +141,53 @@ def load_checkpoint(path, model, optimizer=None, map_location="cpu"):
     if optimizer is not None and ck.get("optimizer") is not None:
         optimizer.load_state_dict(ck["optimizer"])
     return int(ck.get("iterations", 0))
+
+
+# ---------------------------------------------------------------- on-disk formats
+def samples_to_int16(samples, n_quantize=256):
+    """mu-law class ids -> int16 PCM exactly as the reference decode script writes it (qpnet_decode.py:316-319):
+    decode_mu_law, x 32768, clip to [-32768, 32767], truncate to int16."""
+    from .qpnet import decode_mu_law
+    wav = decode_mu_law(np.asarray(samples), n_quantize)
+    return np.clip(wav * 32768, -32768, 32767).astype(np.int16)
+
+
+def write_wav(path, fs, samples, n_quantize=256):
+    """Write one decoded utterance as 16-bit PCM (scipy.io.wavfile, as the reference does)."""
+    from scipy.io import wavfile
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    wavfile.write(path, fs, samples_to_int16(samples, n_quantize))
+    return path
+
+
+def _h5py():
+    try:
+        import h5py
+        return h5py
+    except ImportError as e:     # not installed in the build image; the corpus scripts that need it are out of scope
+        raise ImportError("h5py is required for the reference's .h5 feature files (utils.py:43-92); "
+                          "pass arrays to decode_generator / train_generator instead") from e
+
+
+def read_hdf5(hdf5_name, hdf5_path):
+    """reference utils.read_hdf5 (utils.py:43-68): dataset values, e.g. read_hdf5(f, "/world")."""
+    h5py = _h5py()
+    if not os.path.exists(hdf5_name):
+        raise FileNotFoundError("There is no such a hdf5 file. (%s)" % hdf5_name)
+    with h5py.File(hdf5_name, "r") as f:
+        if hdf5_path not in f:
+            raise KeyError("There is no such a data in hdf5 file. (%s)" % hdf5_path)
+        return f[hdf5_path][()]
+
+
+def write_hdf5(hdf5_name, hdf5_path, write_data, is_overwrite=True):
+    """reference utils.write_hdf5 (utils.py:71-116)."""
+    h5py = _h5py()
+    write_data = np.array(write_data)
+    os.makedirs(os.path.dirname(os.path.abspath(hdf5_name)) or ".", exist_ok=True)
+    with h5py.File(hdf5_name, "a") as f:
+        if hdf5_path in f:
+            if not is_overwrite:
+                raise KeyError("Dataset in hdf5 file already exists. (%s)" % hdf5_path)
+            del f[hdf5_path]
+        f.create_dataset(hdf5_path, data=write_data)

@@ -72,3 +72,22 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(a, b)
     pf = loaders.save_final(str(tmp_path), m)
     assert set(torch.load(pf, weights_only=False).keys()) == {"model"}
+
+
+def test_wav_writer_matches_reference_scaling(tmp_path):
+    from scipy.io import wavfile
+    ids = np.array([0, 16, 128, 239, 255], dtype=np.int64)
+    pcm = loaders.samples_to_int16(ids)
+    # decode_mu_law KATs: 0 -> -1.02207017 (clipped), 128 -> 0, 255 -> 0.97840458
+    assert pcm.dtype == np.int16 and pcm[0] == -32768 and pcm[2] == 0 and pcm[4] == int(0.97840458 * 32768)
+    p = loaders.write_wav(str(tmp_path / "out" / "a.wav"), 22050, ids)
+    fs, back = wavfile.read(p)
+    assert fs == 22050 and np.array_equal(back, pcm)
+
+
+def test_hdf5_helpers_fail_loudly_without_h5py():
+    import importlib.util, pytest
+    if importlib.util.find_spec("h5py") is not None:
+        pytest.skip("h5py present")
+    with pytest.raises(ImportError):
+        loaders.read_hdf5("nope.h5", "/world")
