@@ -821,7 +821,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0) { const int nwu = 1024, rpu = (int)((total + nwu - 1) / nwu); hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpu); }
+        if (p.U > 0) { const int nwu = 256, rpu = (int)((total + nwu - 1) / nwu); hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpu); }
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());
