@@ -753,6 +753,47 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     } else
     hipLaunchKernelGGL((k_post_bwd<MT>), dim3((BL + TM - 1) / TM, B), dim3(512), lds_post, stream, p, bw);
     qpn_prof_mark(PG_POST_BWD, stream);
+    // ---- the skip 1x1 and post-net weight gradients only need what k_post_bwd has just produced (dS0, dY0, dlogits) and
+    // saved activations: they run on a side stream UNDER the eight layer-backward launches (+2.5 % steps/s; the layer
+    // kernels are latency-bound but their workgroups still occupy every CU, so the overlap is partial).  Per-group
+    // profiling (bench roofline) and QPN_TRAIN_SERIAL=1 keep everything on the one stream.  [Per-layer dW1/dWr launches
+    // on a second side stream were tried too: 64 workgroups per launch are too few, 680 steps/s.]
+    const int nch = bw.nch;
+    Wg2 wbase; memset(&wbase, 0, sizeof(wbase));
+    wbase.slab = bw.slab; wbase.gstage = bw.gstage; wbase.nb = B; wbase.C = C; wbase.Ap = p.Ap; wbase.hup = p.HUP; wbase.tap = p.TAP; wbase.ncol_groups = 1;
+    bool ok = true;
+    auto launch_skip_post = [&](hipStream_t st) {
+        Wg2 w = wbase;
+        {   // dWs_l = dS0^T g_l over the last BL rows; the shared skip-bias grad = colsum(dS0) (layer 0's block only)
+            w.nlayers = L;
+            w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
+            w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+            for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; w.tap_off[l] = -1; }
+            ok = ok && wgrad2_any(w, nch, st);
+        }
+        {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
+            w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
+            w.row0A[0] = w.row0B[0] = 0; w.R[0] = BL; w.tap_off[0] = -1;
+            w.ncol_groups = S % 64 == 0 ? S / 64 : 1;
+            w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
+            ok = ok && wgrad2_any(w, nch, st);
+            w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
+            ok = ok && wgrad2_any(w, nch, st);
+        }
+    };
+    static hipStream_t side = nullptr; static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    const bool overlap = !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
+    if (overlap) {
+        if (!side) {
+            QPN_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            QPN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            QPN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        QPN_HIP(hipEventRecord(ev_fork, stream));
+        QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        launch_skip_post(side);
+        QPN_HIP(hipEventRecord(ev_join, side));
+    }
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
@@ -764,11 +805,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
     }
     qpn_prof_mark(PG_LAYER_BWD, stream);
-    // ---- weight gradients: 4 launches over (time chunk, layer)
-    const int nch = bw.nch;
-    Wg2 w; memset(&w, 0, sizeof(w));
-    w.slab = bw.slab; w.gstage = bw.gstage; w.nb = B; w.C = C; w.Ap = p.Ap; w.hup = p.HUP; w.tap = p.TAP; w.ncol_groups = 1;
-    bool ok = true;
+    // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
+    Wg2 w = wbase;
     {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
         w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
         w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
@@ -788,21 +826,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         }
         ok = ok && wgrad2_any(w, nch, stream);
     }
-    {   // dWs_l = dS0^T g_l over the last BL rows; the shared skip-bias grad = colsum(dS0) (layer 0's block only)
-        w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
-        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
-        for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; }
-        ok = ok && wgrad2_any(w, nch, stream);
-    }
-    {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
-        w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
-        w.row0A[0] = w.row0B[0] = 0; w.R[0] = BL; w.tap_off[0] = -1;
-        w.ncol_groups = S % 64 == 0 ? S / 64 : 1;
-        w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
-        ok = ok && wgrad2_any(w, nch, stream);
-        w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
-        ok = ok && wgrad2_any(w, nch, stream);
-    }
+    if (!overlap) launch_skip_post(stream);
     if (bw.g_cw >= 0) {   // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
         w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
         w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
@@ -811,6 +835,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         ok = ok && wgrad2_any(w, nch, stream);
     }
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 64, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
+    if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     qpn_prof_mark(PG_WGRAD, stream);
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat);

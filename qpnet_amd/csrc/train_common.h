@@ -76,7 +76,8 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
 
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)
 enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_COUNT };
-void qpn_prof_mark(int group, hipStream_t stream);   // attributes the work enqueued since the previous mark to `group`
+void qpn_prof_mark(int group, hipStream_t stream);
+bool qpn_prof_active();                              // per-group timing in progress (keeps a step on one stream)   // attributes the work enqueued since the previous mark to `group`
 
 // ---- one wave: acc[mt][j] += A_lds[16*mt.., :K] * Bfrag[:, nt_j]   (K multiple of 16)
 // A_lds row-major with leading dim lda (floats); Bp fragment order: [(ks4*NT + nt)*64 + lane] float4,

@@ -31,6 +31,7 @@ struct TrainState {
 // ---- per-group timing
 struct Prof { bool on = false; std::vector<hipEvent_t> ev; std::vector<int> grp; size_t used = 0; };
 static thread_local Prof g_prof;
+bool qpn_prof_active() { return g_prof.on; }
 void qpn_prof_mark(int group, hipStream_t stream) {
     Prof& P = g_prof;
     if (!P.on) return;
