@@ -86,3 +86,40 @@ def test_sampling_mode_bitwise_vs_oracle(cfgname, cuda, oracle):
     outs2 = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="sampling")
     assert not np.array_equal(outs[0], outs2[0])
     assert len(np.unique(outs[1])) > 32
+
+
+def test_full_size_decode_properties(cuda, oracle):
+    """BASELINE config[3]/[4] size (10 s @22.05 kHz = 2005 frames -> 220 549 samples, F0 x1.0 / x0.5 / x1.5 in one batch):
+    too long for the oracle end to end, so it is pinned by size-independent properties --
+      prefix:   an autoregressive stream does not depend on how long the utterance goes on, so the first samples of the 10 s
+                streams equal a 40-frame decode of the same features, which IS compared with the oracle bit by bit;
+      batch:    a row's stream does not depend on its batch mates (alone == in the batch of three);
+      repeat:   two launches give identical streams; ordering = ascending length, ties in input order."""
+    import torch
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 31)
+    m = util.build_model(cfg, flat, cuda)
+    F, Fs = 2005, 40
+    U = cfg.upsampling_factor
+    utts = [(700, F, 1.0), (701, F, 0.5), (702, F, 1.5)]
+    x, h, d, ns = synth.decode_batch(cfg, utts)
+    xt, ht = torch.from_numpy(x).to(cuda), torch.from_numpy(h).to(cuda)
+    ys = m.batch_fast_generate(xt, ht, list(ns), d, mode="argmax")
+    assert [len(y) for y in ys] == [F * U - 1] * 3
+    ys2 = m.batch_fast_generate(xt, ht, list(ns), d, mode="argmax")
+    for a, b in zip(ys, ys2):
+        np.testing.assert_array_equal(a, b)
+    maxd = int(np.nanmax(np.ceil(d)))                       # the batch's receptive field (reference qpnet.py:347-350)
+    for i, (seed, _, fac) in enumerate(utts):
+        assert ys[i].min() >= 0 and ys[i].max() < cfg.n_quantize
+        # prefix property: the first 40 frames' worth of every 10 s stream == the oracle run on the 40-frame prefix with the
+        # same receptive field (maxd decides the warm-up padding, so it must be the batch's)
+        xs, hs, ds, _ = synth.decode_inputs(cfg, F, seed, fac)
+        hs, ds = np.ascontiguousarray(hs[:, :Fs]), ds[:Fs * U]
+        ref = oracle.decode(cfg, flat, hs, ds, xs, Fs * U - 1, maxd=maxd)["samples"]
+        np.testing.assert_array_equal(ys[i][:Fs * U - 1], ref)
+    # batch independence: the x0.5 row alone
+    assert int(np.ceil(d[1]).max()) == maxd                 # the halved-F0 row sets the batch's maxd, so alone == in the batch
+    alone = m.batch_fast_generate(xt[1:2], ht[1:2], [ns[1]], d[1:2], mode="argmax")[0]
+    np.testing.assert_array_equal(alone, ys[1])

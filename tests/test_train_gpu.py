@@ -147,3 +147,34 @@ def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
             a, r = grad[o:o + n], og[o:o + n]
             assert np.abs(a - r).max() <= 2e-5 * scale + 1e-4 * np.abs(r).max(), "grad mismatch in " + k
     assert np.abs(grads[0] - grads[1]).max() <= 1e-6 * scale
+
+
+def test_full_size_step_vs_oracle(cuda):
+    """BASELINE config[2] size (paper-size model, batch_length 20000 -> one chunk of ~20.7 k samples): loss within the
+    north_star tolerance (1e-4) and every gradient tensor against the numpy oracle's hand-derived backward."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    x, h, t, d, b = synth.train_inputs(cfg, 20000, 5000, 30000, f0_lo=55.0, f0_hi=300.0)
+    BL = int(b[0])
+    assert x.shape[1] > 20000
+    m = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=5e-5, rtol=0)
+    og = TO.backward(cfg, flat, caches, dl)
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        a, r = grad[o:o + n], og[o:o + n]
+        # 20 k-term fp32 sums in two different orders (64 MFMA time chunks vs numpy): allow 2e-4 of the global gradient scale
+        assert np.abs(a - r).max() <= 2e-4 * scale + 2e-3 * np.abs(r).max(), "grad mismatch in " + k
