@@ -324,15 +324,15 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     }
 }
 
-// mean cross entropy + its gradient, one wave per row, 16 rows per wave (reference qpnet_train.py:430,526-528)
+// mean cross entropy + its gradient, one wave per row, rpw rows per wave (reference qpnet_train.py:430,526-528)
 __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t tgt_stride,
-                                            int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss) {
+                                            int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss, int rpw) {
     __shared__ double part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)rows;
     double lsum = 0.0;
-    for (int it = 0; it < 16; ++it) {
-        const int64_t row = ((int64_t)blockIdx.x * 16 + it) * 4 + wave;
+    for (int it = 0; it < rpw; ++it) {
+        const int64_t row = ((int64_t)blockIdx.x * rpw + it) * 4 + wave;
         if (row >= rows) break;
         const float* lg = logits + (size_t)row * Q;
         const int64_t b = row / BL, t = row - b * BL;
@@ -413,7 +413,8 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream) {
     const int64_t rows = (int64_t)B * BL;
     QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
-    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss);
+    const int rpw = 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
+    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw);
     qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

@@ -18,4 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/decode_$c -o decode -- $DEC > $OUT/decode_$c.log 2>&1
   echo "decode $c done"
 done
+# matrix-core busy cycles per kernel (MFMA utilisation = busy / (duration x 2.4 GHz x 1024 SIMDs))
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/train_MFMA -o train -- python3 bench.py --mode train --steps 2 --warmup 1 --no-cpu > $OUT/train_MFMA.log 2>&1
+echo "train MFMA done"
 python3 tools/profile_summarise.py $TAG

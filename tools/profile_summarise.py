@@ -39,6 +39,25 @@ for what in ("train", "decode"):
                 calls[name] += 1
     per[what] = {k: {"calls": calls[k], "FETCH_SIZE_KB": v.get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB": v.get("WRITE_SIZE", 0.0),
                      "hbm_bytes": (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024} for k, v in agg.items()}
+# matrix-core utilisation: SQ_VALU_MFMA_BUSY_CYCLES summed over a dispatch / (its duration x clock x SIMDs)
+f = find("train_MFMA/**/*counter_collection.csv")
+fs = find("train_stats/**/*kernel_stats.csv")
+if f and fs:
+    avg_ns = {}
+    for r in csv.DictReader(open(fs)):
+        avg_ns[r["Name"].split("(")[0][:80]] = float(r["AverageNs"])
+    busy = defaultdict(float); n = defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != "SQ_VALU_MFMA_BUSY_CYCLES":
+            continue
+        name = (r.get("Kernel_Name") or "").split("(")[0][:80]
+        busy[name] += float(r["Counter_Value"]); n[name] += 1
+    for name in busy:
+        if name in avg_ns and name in per.get("train", {}):
+            per_call = busy[name] / n[name]
+            per["train"][name]["mfma_busy_cycles_per_call"] = per_call
+            per["train"][name]["avg_us"] = avg_ns[name] / 1e3
+            per["train"][name]["mfma_util"] = per_call / (avg_ns[name] * 2.4 * 1024)
 json.dump(per, open(os.path.join(dst, "%s_pmc_by_kernel.json" % tag), "w"), indent=1)
 # the figures bench.py reports
 dec = [v for k, v in per.get("decode", {}).items() if "k_decode" in k]
