@@ -144,6 +144,12 @@ def run_decode(args, rank, local, world):
                      "note": "algorithmic bytes = (172 + 4*params touched) B/sample = %d B/sample (SURVEY 8d, weights re-streamed "
                              "every sample; they are L2-resident so this is L2->CU traffic, not HBM)" % bps},
     }
+    if world == 1 and not args.no_cpu:
+        # the reference decode script's default mode (softmax + draw, qpnet_decode.py:312-314): one untimed-in-`value` launch
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        m.batch_fast_generate(xb, hb, list(ns), bd, mode="sampling")
+        torch.cuda.synchronize()
+        out["sampling_mode"] = {"value": sum(ns) / (time.perf_counter() - t1), "unit": "samples/s", "kernel_ms": m.last_decode_kernel_ms}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_decode(cfg, flat)
     return out
