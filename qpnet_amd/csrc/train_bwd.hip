@@ -139,10 +139,9 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int ldx = tr_lda(C), ldz = tr_lda(2 * C);
     float* Dx = sm; float* Dz = sm + TM * ldx;
-    const int b = blockIdx.y, n0 = ly.s_out + blockIdx.x * TM;
+    const int b = blockIdx.y, n0 = ly.s_out + tr_xcd_tile(blockIdx.x, gridDim.x, pp) * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)b * p.N1;
-    (void)pp;
     const size_t nDX = (size_t)p.B * p.N1 * C;     // grads wrt X[j] live at DXA/DXB[0] + j*nDX
     const float* DAin = bw.DXA[0] + (size_t)(l + 1) * nDX + rb * C; const float* DBin = bw.DXB[0] + (size_t)(l + 1) * nDX + rb * C;
     float* DAout = bw.DXA[0] + (size_t)l * nDX + rb * C; float* DBout = bw.DXB[0] + (size_t)l * nDX + rb * C;
@@ -800,9 +799,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         if (!getenv("QPN_LAYER_BWD_MT") || atoi(getenv("QPN_LAYER_BWD_MT")) == 1) {      // 16-row tiles measured 11 % faster than 32
             const size_t lds1 = lds_layer / MT;
             if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            hipLaunchKernelGGL((k_layer_bwd<1>), dim3((rows + 15) / 16, B), dim3(256), lds1, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
+            hipLaunchKernelGGL((k_layer_bwd<1>), dim3((rows + 15) / 16, B), dim3(256), lds1, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
         } else
-        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, 0);
+        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
     }
     qpn_prof_mark(PG_LAYER_BWD, stream);
     // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table

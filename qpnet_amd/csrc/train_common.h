@@ -79,6 +79,15 @@ enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_
 void qpn_prof_mark(int group, hipStream_t stream);
 bool qpn_prof_active();                              // per-group timing in progress (keeps a step on one stream)   // attributes the work enqueued since the previous mark to `group`
 
+// XCD-aware tile index: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); remapped so that the
+// workgroups sharing an XCD own a CONTIGUOUS range of time tiles -- a tile's pitch-tap rows are then the rows a neighbour on the
+// same L2 fetched a moment ago (bijective form for any grid size; QPN_NO_XCD_SWIZZLE=1 at launch passes swz = 0).
+__device__ __forceinline__ int tr_xcd_tile(int orig, int nwg, int swz) {
+    if (!swz || nwg <= 8) return orig;
+    const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+}
+
 // ---- one wave: acc[mt][j] += A_lds[16*mt.., :K] * Bfrag[:, nt_j]   (K multiple of 16)
 // A_lds row-major with leading dim lda (floats); Bp fragment order: [(ks4*NT + nt)*64 + lane] float4,
 // element e of the float4 = B[4*(4*ks4+e) + (lane>>4)][16*nt + (lane&15)].

@@ -172,7 +172,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 template <int MT>
 __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
     extern __shared__ float sm[];
-    layer_fwd_tile<MT>(p, l, last, blockIdx.y, p.layers[l].s_out + blockIdx.x * 16 * MT, sm);
+    layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2) * 16 * MT, sm);
 }
 
 // dynamic LDS: St[TM][lda(S)] | Yt[TM][max(lda(S), 2 lda(C))]  (the two G_l staging buffers alias Yt)
@@ -390,11 +390,11 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
             if (lmt == 1) {
                 size_t lds1 = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float); if (pad > lds1) lds1 = pad;
                 if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                hipLaunchKernelGGL((k_layer_fwd<1>), dim3((rows + 15) / 16, p.B), dim3(256), lds1, stream, p, l, l == p.L - 1 ? 1 : 0);
+                hipLaunchKernelGGL((k_layer_fwd<1>), dim3((rows + 15) / 16, p.B), dim3(256), lds1, stream, p, l, (l == p.L - 1 ? 1 : 0) | (getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2));
             } else {
                 size_t lds2 = lds_layer; if (pad > lds2) lds2 = pad;
                 if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, l == p.L - 1 ? 1 : 0);
+                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, (l == p.L - 1 ? 1 : 0) | (getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2));
             }
         }
     }
