@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
         f32x4 acc[MT][1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
-        if (!last) { const int nts[1] = {nt}; wave_gemm<MT, 1>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane); }
+        if (!last) { const int nts[1] = {nt}; wave_gemm_deep<MT, 1, 4>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane); }
         const int c = 16 * nt + (lane & 15);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm<MT, 1>(acc, Dz, ldz, p.wp + ly.w1t_f4, NTK, nts, 2 * C, lane);
+        wave_gemm_deep<MT, 1, 8>(acc, Dz, ldz, p.wp + ly.w1t_f4, NTK, nts, 2 * C, lane);
         const int k = 16 * nt + (lane & 15);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)

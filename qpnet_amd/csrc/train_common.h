@@ -121,3 +121,47 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __r
         }
     }
 }
+
+// Variant for the narrow GEMMs (one n-tile per wave): the weight fragments come from L2 (~1 k cycles away) and are requested PD
+// 16-deep steps ahead through a ring of PD register sets.  [With one step of lookahead a 16-row tile's step has only 4-8 MFMAs (128-256 cycles) to hide that latency
+// behind: in-kernel stamps showed ~1.2 k cycles per step, 10 k cycles for a 32-MFMA GEMM.  For the two-n-tile GEMMs the
+// extra registers cost more than the latency they hide (measured), so those keep wave_gemm.]
+template <int MT, int NJ, int PD>
+__device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
+                                          const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
+    const int arow = lane & 15, ak = lane >> 4;
+    const int nk = K / 16;
+    float4 bq[PD][NJ];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) {
+        const int kd = d < nk ? d : nk - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kd * NT + nts[j]) * 64 + lane];
+    }
+    for (int ks0 = 0; ks0 < nk; ks0 += PD) {
+        const bool more = ks0 + PD < nk;               // a later pass of the ring needs refills (wave-uniform)
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const int ks4 = ks0 + d;
+            if (ks4 < nk) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float* ap = A_lds + (size_t)(16 * mt + arow) * lda + 16 * ks4 + ak;
+                    const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bq[d][j].x, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bq[d][j].y, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bq[d][j].z, acc[mt][j], 0, 0, 0);
+                        acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bq[d][j].w, acc[mt][j], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) {
+                const int kn = ks4 + PD < nk ? ks4 + PD : nk - 1;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
+            }
+        }
+    }
+}

@@ -154,7 +154,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm<MT, 1>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
+        wave_gemm_deep<MT, 1, 4>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
         const int c = 16 * nt + (lane & 15);
         const float bb = br[c];
 #pragma unroll

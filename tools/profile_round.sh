@@ -6,6 +6,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
+# one stream, as in the per-group roofline measurement of bench.py (the timed loop overlaps the skip/post weight gradients with
+# the layer backward on a side stream, which stretches the individual kernel durations)
+export QPN_TRAIN_SERIAL=1
 TRAIN="python3 bench.py --mode train --steps 20 --warmup 3 --no-cpu"
 DEC="python3 bench.py --mode decode --batch 20 --frames 600 --steps 1 --warmup 0 --no-cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_stats -o train -- $TRAIN > $OUT/train_stats.log 2>&1
