@@ -197,17 +197,31 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
                 Dz[(size_t)r * ldz + c] = dzs; Dz[(size_t)r * ldz + C + c] = dzt;
             }
     }
-    __syncthreads();
-    // ---- d[x_cur | x_past | aux] = dZ . W1
+    // ---- d[x_cur | x_past | aux] = dZ . W1.  A wave's n-tiles run back to back; the weight fragments of the NEXT n-tile and the
+    //      scatter rows are requested before the barrier / under the previous tile's epilogue (K = 2C <= 128: all 8 steps fit the ring)
     const int NTK = Ktp / 16;
     const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
     float* DH = bw.DHUP + rb * Ap;
+    constexpr int PD3 = 8;
+    const float4* W1t = p.wp + ly.w1t_f4;
+    float4 bq[PD3][1];
+    int tprow[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 16 * mt + 4 * (lane >> 4) + i;
+            tprow[mt][i] = n < p.N1 ? (taps ? taps[n] : n - ly.dilation) : 0;
+        }
+    if (wave < NTK) { const int nts0[1] = {wave}; wave_b_preload<1, PD3>(bq, W1t, NTK, nts0, 2 * C, lane); }
+    __syncthreads();
     for (int nt = wave; nt < NTK; nt += 4) {
         f32x4 acc[MT][1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm_deep<MT, 1, 8>(acc, Dz, ldz, p.wp + ly.w1t_f4, NTK, nts, 2 * C, lane);
+        wave_gemm_run<MT, 1, PD3>(acc, Dz, ldz, bq, W1t, NTK, nts, 2 * C, lane);
+        if (2 * C <= 16 * PD3 && nt + 4 < NTK) { const int ntn[1] = {nt + 4}; wave_b_preload<1, PD3>(bq, W1t, NTK, ntn, 2 * C, lane); }
         const int k = 16 * nt + (lane & 15);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -218,10 +232,11 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
                 const float v = acc[mt][0][i];
                 if (k < C) DAout[(size_t)n * C + k] = v + Dx[(size_t)r * ldx + k];              // + residual path
                 else if (k < 2 * C) {
-                    if (taps) atomicAdd(&DBout[(size_t)taps[n] * C + (k - C)], v);               // gather backward (collisions)
-                    else DBout[(size_t)(n - ly.dilation) * C + (k - C)] = v;                      // unique writer
-                } else if (k < 2 * C + Ap) DH[(size_t)n * Ap + (k - 2 * C)] += v;
+                    if (taps) atomicAdd(&DBout[(size_t)tprow[mt][i] * C + (k - C)], v);          // gather backward (collisions)
+                    else DBout[(size_t)tprow[mt][i] * C + (k - C)] = v;                           // unique writer
+                } else if (k < 2 * C + Ap) atomicAdd(&DH[(size_t)n * Ap + (k - 2 * C)], v);      // unique writer per layer, layers in order: fire-and-forget add
             }
+        if (!(2 * C <= 16 * PD3) && nt + 4 < NTK) { const int ntn[1] = {nt + 4}; wave_b_preload<1, PD3>(bq, W1t, NTK, ntn, 2 * C, lane); }
     }
 }
 

@@ -126,18 +126,23 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __r
 // 16-deep steps ahead through a ring of PD register sets.  [With one step of lookahead a 16-row tile's step has only 4-8 MFMAs (128-256 cycles) to hide that latency
 // behind: in-kernel stamps showed ~1.2 k cycles per step, 10 k cycles for a 32-MFMA GEMM.  For the two-n-tile GEMMs the
 // extra registers cost more than the latency they hide (measured), so those keep wave_gemm.]
-template <int MT, int NJ, int PD>
-__device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
-                                          const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
-    const int arow = lane & 15, ak = lane >> 4;
+// split form: wave_b_preload requests the first PD steps' fragments (callable long before the A tile is ready, e.g. under an
+// epilogue or a barrier), wave_gemm_run consumes them and refills the ring only when K needs more than PD steps
+template <int NJ, int PD>
+__device__ __forceinline__ void wave_b_preload(float4 (&bq)[PD][NJ], const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
     const int nk = K / 16;
-    float4 bq[PD][NJ];
 #pragma unroll
     for (int d = 0; d < PD; ++d) {
         const int kd = d < nk ? d : nk - 1;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kd * NT + nts[j]) * 64 + lane];
     }
+}
+template <int MT, int NJ, int PD>
+__device__ __forceinline__ void wave_gemm_run(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda, float4 (&bq)[PD][NJ],
+                                              const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
+    const int arow = lane & 15, ak = lane >> 4;
+    const int nk = K / 16;
     for (int ks0 = 0; ks0 < nk; ks0 += PD) {
         const bool more = ks0 + PD < nk;               // a later pass of the ring needs refills (wave-uniform)
 #pragma unroll
@@ -164,4 +169,11 @@ __device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float
             }
         }
     }
+}
+template <int MT, int NJ, int PD>
+__device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
+                                               const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
+    float4 bq[PD][NJ];
+    wave_b_preload<NJ, PD>(bq, Bp, NT, nts, K, lane);
+    wave_gemm_run<MT, NJ, PD>(acc, A_lds, lda, bq, Bp, NT, nts, K, lane);
 }
