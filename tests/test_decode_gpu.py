@@ -123,3 +123,18 @@ def test_full_size_decode_properties(cuda, oracle):
     assert int(np.ceil(d[1]).max()) == maxd                 # the halved-F0 row sets the batch's maxd, so alone == in the batch
     alone = m.batch_fast_generate(xt[1:2], ht[1:2], [ns[1]], d[1:2], mode="argmax")[0]
     np.testing.assert_array_equal(alone, ys[1])
+
+
+@pytest.mark.parametrize("geo", [(128, 128, 2, 1, 2, 1), (96, 256, 2, 1, 1, 1), (64, 128, 3, 2, 2, 1)], ids=["C128", "C96", "F3x2"])
+def test_other_geometries_bitwise_vs_oracle(geo, cuda, oracle):
+    """Depth/repeat/width combinations outside the BASELINE configs (the repo default uses repeat 3): interpreter kernel for
+    n_resch 96 / 128, specialised kernel with another skip width and a repeated fixed stack for n_resch 64."""
+    import torch
+    from qpnet_amd.config import QPNetConfig
+    C, S, fd, fr, ad, ar = geo
+    cfg = QPNetConfig(n_resch=C, n_skipch=S, dilationF_depth=fd, dilationF_repeat=fr, dilationA_depth=ad, dilationA_repeat=ar)
+    flat = synth.make_weights(cfg, 7)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, d, n = synth.decode_inputs(cfg, 5, 11, 1.5)
+    y = m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode="argmax")[0]
+    np.testing.assert_array_equal(y, oracle.decode(cfg, flat, h, d, x, n)["samples"])

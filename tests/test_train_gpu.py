@@ -178,3 +178,27 @@ def test_full_size_step_vs_oracle(cuda):
         a, r = grad[o:o + n], og[o:o + n]
         # 20 k-term fp32 sums in two different orders (64 MFMA time chunks vs numpy): allow 2e-4 of the global gradient scale
         assert np.abs(a - r).max() <= 2e-4 * scale + 2e-3 * np.abs(r).max(), "grad mismatch in " + k
+
+
+def test_other_geometry_train_vs_oracle(cuda):
+    """n_resch 64 with another skip width and a repeated fixed stack (3 x 2 fixed + 2 adaptive layers): the weight-gradient
+    launches the templated kernel does not cover take the generic one."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import QPNetConfig
+    cfg = QPNetConfig(n_resch=64, n_skipch=128, dilationF_depth=3, dilationF_repeat=2, dilationA_depth=2, dilationA_repeat=1)
+    flat = synth.make_weights(cfg, 7)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 5, 4000)
+    BL = int(b[0])
+    m = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=2e-5, rtol=0)
+    assert np.abs(grad - og).max() <= 2e-5 * np.abs(og).max()
