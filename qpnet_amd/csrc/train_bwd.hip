@@ -439,6 +439,7 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
     if (launch_wgrad2<BMODE, 1, 4>(w, nch, stream) == 0) return true;
     if (launch_wgrad2<BMODE, 4, 4>(w, nch, stream) == 0) return true;
     if (launch_wgrad2<BMODE, 2, 12>(w, nch, stream) == 0) return true;
+    if (launch_wgrad2<BMODE, 4, 8>(w, nch, stream) == 0) return true;       // 256 x 128 blocks (n_resch up to 128 with column groups)
     return false;
 }
 // ------------------------------------------------------------------------------------------ weight gradients, v3
@@ -626,6 +627,14 @@ static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
     }
 }
 
+// smallest number of column groups g (N % g == 0, 4-column granularity kept) such that an M x N/g block fits a kernel's tile budget
+static int wgrad_col_groups(int M, int N) {
+    const int nt_max = M <= 64 ? 4 : M <= 128 ? 12 : 8;          // <1,4>, <2,12>, <4,8> / <4,4>
+    for (int g = 1; g <= N / 16; ++g)
+        if (N % g == 0 && (N / g) % 4 == 0 && (N / g + 15) / 16 <= nt_max) return g;
+    return 1;
+}
+
 static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
     if (wgrad3_any(w, nch, stream)) return true;
     switch (w.bmode) {
@@ -656,9 +665,10 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
     const int64_t total = (int64_t)p.B * p.N1;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < total ? r0 + rows_per_wg : total;
     for (int cb = 0; cb < C; cb += CB) {
+        const int cbv = C - cb < CB ? C - cb : CB;          // channels of this block (the last one is partial when C % 64 != 0)
         for (int i = tid; i < 2 * Q * CB; i += 256) tab[i] = 0.f;
         __syncthreads();
-        const int cpr = CB;                          // channels per row handled by consecutive threads
+        const int cpr = cbv;                         // channels per row handled by consecutive threads
         for (int64_t idx = r0 * cpr + tid; idx < r1 * cpr; idx += 256) {
             const int64_t rr = idx / cpr; const int c = (int)(idx - rr * cpr);
             const int b = (int)(rr / p.N1), n = (int)(rr - (int64_t)b * p.N1);
@@ -673,14 +683,13 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
         }
         __syncthreads();
         // flush: flat index ((c*Q + q)*2 + tap); iterate (q,tap) fastest for contiguous atomics
-        for (int i = tid; i < 2 * Q * CB; i += 256) {
+        for (int i = tid; i < 2 * Q * cbv; i += 256) {
             const int c = i / (2 * Q), qt = i - c * 2 * Q, q = qt >> 1, tp = qt & 1;
             const float v = tab[(tp * Q + q) * CB + c];
             if (v != 0.f) atomicAdd(&bw.gflat[p.causal_w + ((size_t)(cb + c) * Q + q) * 2 + tp], v);
-            if (tp == 0) { /* bias: sum over q of tap-0 table == sum over rows */ }
         }
         // bias grad = sum over all rows = sum over q of the tap-0 table
-        for (int c = tid; c < CB; c += 256) {
+        for (int c = tid; c < cbv; c += 256) {
             float s = 0.f;
             for (int q = 0; q < Q; ++q) s += tab[(0 * Q + q) * CB + c];
             atomicAdd(&bw.gflat[p.causal_b + cb + c], s);
@@ -782,6 +791,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
             w.nlayers = L;
             w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
             w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+            w.ncol_groups = wgrad_col_groups(w.M, w.N);
             for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; w.tap_off[l] = -1; }
             ok = ok && wgrad2_any(w, nch, st);
         }
@@ -824,7 +834,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
         w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
         w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
-        w.nlayers = L; w.ldc = p.Ktp;
+        w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
         for (int l = 0; l < L; ++l) {
             const TrLayer& ly = p.layers[l];
             w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
@@ -835,6 +845,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
         w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
         w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+        w.ncol_groups = wgrad_col_groups(w.M, w.N);
         for (int l = 0; l < L; ++l) {
             w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1;
         }
@@ -848,7 +859,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
         ok = ok && wgrad2_any(w, nch, stream);
     }
-    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 64, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
+    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     qpn_prof_mark(PG_WGRAD, stream);
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
