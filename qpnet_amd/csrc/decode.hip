@@ -553,7 +553,7 @@ struct FastGeo {
     }
 };
 
-template <int C, int S, int Q, int NWV, int W0>
+template <int C, int S, int Q, int NWV, bool RESL, int W0>
 __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastParams& f, const UttView& u,
                                            const int wave, const int lane0, const int tid0, const int Ttot) {
     using G = FastGeo<C, S, Q, NWV>;
@@ -566,8 +566,8 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
     int stamp_i = 0;
 #ifdef QPN_ENABLE_STAMPS   // dev aid (-DQPN_ENABLE_STAMPS + QPN_STAMPS=1): s_memtime at every phase boundary of step 3000,
                            // parked in LDS behind the kernel's own state (no global stores in the timed code), dumped after the step
-#define QPN_STAMP() do { if (p.stamps && t == 3000 && lane == 0 && stamp_i < 120) smi[p.lds_floats + stamp_i * QPN_NW + (wave < QPN_NW ? wave : 0)] = (int)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
-#define QPN_STAMP_DUMP() do { if (p.stamps && t == 3000 && lane == 0) for (int k = 0; k < stamp_i && k < 120; ++k) p.stamps[(size_t)k * QPN_NW + (wave < QPN_NW ? wave : 0)] = (long long)(unsigned)smi[p.lds_floats + k * QPN_NW + (wave < QPN_NW ? wave : 0)]; } while (0)
+#define QPN_STAMP() do { if (p.stamps && t == 3000 && lane == 0 && stamp_i < 120) smi[p.o_stamp + stamp_i * QPN_NW + (wave < QPN_NW ? wave : 0)] = (int)__builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#define QPN_STAMP_DUMP() do { if (p.stamps && t == 3000 && lane == 0) for (int k = 0; k < stamp_i && k < 120; ++k) p.stamps[(size_t)k * QPN_NW + (wave < QPN_NW ? wave : 0)] = (long long)(unsigned)smi[p.o_stamp + k * QPN_NW + (wave < QPN_NW ? wave : 0)]; } while (0)
 #else
 #define QPN_STAMP() do { (void)stamp_i; } while (0)
 #define QPN_STAMP_DUMP() do { } while (0)
@@ -578,7 +578,7 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
 #define QPN_ZPTR(wl, l, id) ((wl) + ((id) < NZ ? f.w_cur[l] + (id) * 256 : f.w_past[l] + ((id) - NZ) * 256))
 #define QPN_RPTR(wl, l, id) ((wl) + ((id) < NRES ? f.w_res[l] + (id) * 256 : f.w_skip[l] + ((id) - NRES) * 256))
 #define QPN_ZINIT(wl, i) if constexpr ((i) < ZT && G::zkind(W0 + (i) * NWV) != 0) tile_load(wz[(i) < ZT ? (i) : 0], QPN_ZPTR(wl, 0, wave + (i) * NWV));
-#define QPN_RINIT(wl, i) if constexpr ((i) < RT && G::rkind(W0 + (i) * NWV) != 0) tile_load(wr[(i) < RT ? (i) : 0], QPN_RPTR(wl, 0, wave + (i) * NWV));
+#define QPN_RINIT(wl, i) if constexpr ((i) < RT && G::rkind(W0 + (i) * NWV) != 0 && !(RESL && G::rkind(W0 + (i) * NWV) == 1)) tile_load(wr[(i) < RT ? (i) : 0], QPN_RPTR(wl, 0, wave + (i) * NWV));
     QPN_ZINIT(wl0, 0) QPN_ZINIT(wl0, 1) QPN_ZINIT(wl0, 2) QPN_ZINIT(wl0, 3)
     QPN_RINIT(wl0, 0) QPN_RINIT(wl0, 1) QPN_RINIT(wl0, 2) QPN_RINIT(wl0, 3)
 
@@ -618,17 +618,24 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
 #define QPN_RDOT(i, LAST)                                                                                         \
             if constexpr ((i) < RT) {                                                                             \
                 constexpr int rk = G::rkind(W0 + (i) * NWV);                                                      \
-                if constexpr (rk != 0) {                                                                          \
+                if constexpr (RESL && rk == 1) {                                                                  \
+                    if constexpr (!(LAST)) {              /* resident tile: four 1 KiB LDS reads, no global request */ \
+                        const float4* tp = (const float4*)(sm + p.o_wres) + (l * NRES + wave + (i) * NWV) * 256 + lane; \
+                        /* the slot's register set is idle in this mode (the post-net borrows it later): use it as the landing zone */ \
+                        _Pragma("unroll") for (int j = 0; j < 4; ++j) wr[(i) < RT ? (i) : 0][j] = tp[j * 64];       \
+                        racc[(i) < RT ? (i) : 0] = tree_reduce_c<LOGR>(chunk16(wr[(i) < RT ? (i) : 0], xg));      \
+                    }                                                                                             \
+                } else if constexpr (rk != 0) {                                                                   \
                     if constexpr (LAST) racc[(i) < RT ? (i) : 0] = tree_reduce_c<LOGR>(chunk16(wr[(i) < RT ? (i) : 0], xg)); \
                     else racc[(i) < RT ? (i) : 0] = tree_reduce_c<LOGR>(chunk16_reload(wr[(i) < RT ? (i) : 0], xg, QPN_RPTR(wl, l + 1, wave + (i) * NWV))); \
                 }                                                                                                 \
-                if constexpr (LAST && (i) == 0) { QPN_TLOAD(2) }                                                     \
+                if constexpr (LAST && (i) == 0) { QPN_TLOAD(2) }                                                  \
             }
-#define QPN_RPUT(i)                                                                                               \
+#define QPN_RPUT(i, LASTL)                                                                                            \
             if constexpr ((i) < RT) {                                                                             \
                 constexpr int rk = G::rkind(W0 + (i) * NWV);                                                      \
                 const int id = wave + (i) * NWV;                                                                  \
-                if constexpr (rk == 1) {                                                                          \
+                if constexpr (rk == 1 && !(RESL && LASTL)) {                                                      \
                     const int row = id * RPT + grp;                                                               \
                     /* x_{l+1}; its ring row is written once per step at the end (no stores in the load queue here) */ \
                     sm[p.o_xbuf + (l + 1) * p.Cp + row] = (racc[(i) < RT ? (i) : 0] + sm[f.b_res[l] + row]) + sm[p.o_xbuf + l * p.Cp + row]; \
@@ -650,7 +657,7 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
                 float4 xg[4]; read_x(xg, p.o_gl + l * p.Cp + 16 * q);                                             \
                 float racc[RT];                                                                                   \
                 QPN_RDOT(0, LAST) QPN_RDOT(1, LAST) QPN_RDOT(2, LAST) QPN_RDOT(3, LAST)                           \
-                if (q == 0) { QPN_RPUT(0) QPN_RPUT(1) QPN_RPUT(2) QPN_RPUT(3) }                                   \
+                if (q == 0) { QPN_RPUT(0, LAST) QPN_RPUT(1, LAST) QPN_RPUT(2, LAST) QPN_RPUT(3, LAST) }                                   \
             } else if constexpr (LAST) { QPN_TLOAD(2) }
 
     for (int t = 1; t + 1 < Ttot; ++t) {
@@ -758,18 +765,21 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
 #undef QPN_LAYER
 }
 
-template <int C, int S, int Q, int NWV, int W0>
+template <int C, int S, int Q, int NWV, bool RESL, int W0>
 __device__ __forceinline__ void fast_dispatch(const DecodeParams& p, const FastParams& f, const UttView& u,
                                               const int wave, const int lane, const int tid, const int Ttot) {
     constexpr int NB = FastGeo<C, S, Q, NWV>::next_boundary(W0);
-    if constexpr (NB >= NWV) fast_steps<C, S, Q, NWV, W0>(p, f, u, wave, lane, tid, Ttot);
+    if constexpr (NB >= NWV) fast_steps<C, S, Q, NWV, RESL, W0>(p, f, u, wave, lane, tid, Ttot);
     else {
-        if (wave < NB) fast_steps<C, S, Q, NWV, W0>(p, f, u, wave, lane, tid, Ttot);
-        else fast_dispatch<C, S, Q, NWV, NB>(p, f, u, wave, lane, tid, Ttot);
+        if (wave < NB) fast_steps<C, S, Q, NWV, RESL, W0>(p, f, u, wave, lane, tid, Ttot);
+        else fast_dispatch<C, S, Q, NWV, RESL, NB>(p, f, u, wave, lane, tid, Ttot);
     }
 }
 
-template <int C, int S, int Q, int NWV>
+// RESL: the residual-1x1 tiles of layers 0..L-2 (the ones on the critical path of every R phase) live in LDS for the whole
+// launch: 16 fewer 1 KiB requests per layer through the serial vector-memory front end, and the waves that own them never
+// block on it.  The host picks RESL when the tiles fit beside the step state (paper-size: 112 KiB + 38 KiB).
+template <int C, int S, int Q, int NWV, bool RESL>
 __global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastParams f) {
     using G = FastGeo<C, S, Q, NWV>;
     static_assert(G::R <= 8 && G::RS <= 32 && G::ZT >= 1 && G::RT >= 1, "geometry not covered by the fast kernel");
@@ -792,7 +802,13 @@ __global__ __launch_bounds__(NWV * 64) void k_decode_fast(DecodeParams p, FastPa
     __syncthreads();
     if (Ttot > 3) stage_taps(p, u, 2, tid, NTH, p.status);
     __syncthreads();
-    fast_dispatch<C, S, Q, NWV, 0>(p, f, u, wave, lane, tid, Ttot);
+    if constexpr (RESL) {
+        const int per = G::NRES * 256;                                   // float4s per layer
+        float4* dst = (float4*)(sm + p.o_wres);
+        for (int i = tid; i < (p.L - 1) * per; i += NTH) { const int l = i / per; dst[i] = p.wpk[f.w_res[l] + (i - l * per)]; }
+        __syncthreads();
+    }
+    fast_dispatch<C, S, Q, NWV, RESL, 0>(p, f, u, wave, lane, tid, Ttot);
 }
 
 // ================================================================== host side
@@ -1151,20 +1167,29 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
     p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
-    if ((size_t)p.lds_floats * sizeof(float) > 48 * 1024) {
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode, hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_floats * (int)sizeof(float)));
-        const int lb = p.lds_floats * (int)sizeof(float);
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<64, 256, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        QPN_HIP(hipFuncSetAttribute((const void*)k_decode_fast<32, 32, 256, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-    }
     QPN_HIP(hipEventRecord(h->ev0, stream));
     const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
-    const size_t lds_bytes = ((size_t)p.lds_floats + (p.stamps ? 120 * QPN_NW : 0)) * sizeof(float);
-    if (!generic && g.C == 64 && g.S == 256 && g.Q == 256)
-        hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-    else if (!generic && g.C == 32 && g.S == 32 && g.Q == 256)
-        hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-    else
+    const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;
+    // the specialised kernel does not use the task table: the residual-1x1 tiles of layers 0..L-2 take its place (and more) when they fit
+    const int stamp_floats = p.stamps ? 120 * QPN_NW : 0;
+    const int nres_tiles = (g.C * g.C / 1024) * (g.L - 1);
+    p.o_wres = (p.o_tasks + 3) & ~3;
+    const bool resl = (fast64 || fast32) && g.L >= 2 && !getenv("QPN_DECODE_NO_RESL") &&
+                      ((size_t)p.o_wres + (size_t)nres_tiles * 1024 + stamp_floats) * sizeof(float) <= 160 * 1024;
+    const int use_floats = resl ? p.o_wres + nres_tiles * 1024 : p.lds_floats;
+    p.o_stamp = use_floats;
+    const size_t lds_bytes = ((size_t)use_floats + stamp_floats) * sizeof(float);
+    const void* kfn = fast64 ? (resl ? (const void*)k_decode_fast<64, 256, 256, 16, true> : (const void*)k_decode_fast<64, 256, 256, 16, false>)
+                    : fast32 ? (resl ? (const void*)k_decode_fast<32, 32, 256, 16, true> : (const void*)k_decode_fast<32, 32, 256, 16, false>)
+                    : (const void*)k_decode;
+    if (lds_bytes > 48 * 1024) QPN_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (fast64) {
+        if (resl) hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, true>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+    } else if (fast32) {
+        if (resl) hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, true>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
+    } else
         hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), lds_bytes, stream, p);
     QPN_HIP(hipGetLastError());
     QPN_HIP(hipEventRecord(h->ev1, stream));
