@@ -500,8 +500,7 @@ __global__ __launch_bounds__(QPN_NT) void k_decode(DecodeParams p) {
 //   Z phase (per layer)  waves [0,NZ): this step's z tiles + gate      waves [NZ,2NZ): next step's past-tap dots
 //   R phase              residual 1x1 tiles first (-> next layer input), then the skip 1x1 tiles
 //   tail                 skip total/relu -> post 1x1 #1 -> post 1x1 #2 -> argmax/causal/staging
-// With 8 waves (256 VGPRs each) every wave keeps the NEXT layer's tiles in a second register set, requested a full
-// layer ahead with plain loads (hipcc's counted waits work in this straight-line code).
+// What bounds a step and why the kernel looks the way it does: DESIGN.md §4, profiles/r01_decode_fast_phase_timeline.txt.
 template <int V> struct ILog2 { static constexpr int v = 1 + ILog2<V / 2>::v; };
 template <> struct ILog2<1> { static constexpr int v = 0; };
 
@@ -919,7 +918,7 @@ static int build_program(qpn_handle* h) {
     auto take = [&](int n) { int r = o; o += (n + 3) & ~3; return r; };
     p.o_xbuf = take((L + 1) * g.Cp); p.o_xp = take(L * g.Cp); p.o_pd = take(2 * L * 2 * C); p.o_auxv = take(L * 2 * C);
     p.o_g = take(g.Cp); p.o_skf = take(S); p.o_ska = take(S); p.o_y1 = take(g.Sp); p.o_y2 = take(g.Sp); p.o_lg = take(Q);
-    p.o_samp = take(4); p.o_sel = take(L); p.o_gl = take(L * g.Cp); p.o_sdef = take(L * 64); p.state_floats = o;
+    p.o_samp = take(4); p.o_sel = take(L); p.o_gl = take(L * g.Cp); p.state_floats = o;
     // ... then the biases the epilogues add (so no global load sits behind the weight prefetch queue)
     std::vector<int>& bsrc = h->h_bias_src; bsrc.clear();
     auto bias_block = [&](int64_t flat_off, int n) { int r = p.o_bias + (int)bsrc.size(); for (int i = 0; i < n; ++i) bsrc.push_back((int)(flat_off + i)); return r; };

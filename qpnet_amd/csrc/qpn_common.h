@@ -101,7 +101,7 @@ struct DecodeParams {
     int64_t causal_w, causal_b, up_w;
     int o_xbuf, o_xp, o_pd, o_auxv, o_g, o_skf, o_ska, o_y1, o_y2, o_lg, o_samp, o_sel, state_floats;
     int o_bias, n_bias, o_tasks, lds_floats;
-    int o_gl, o_sdef;       // specialised kernel: per-layer gate vectors [L][Cp], deferred skip dots [L][64]
+    int o_gl;               // specialised kernel: per-layer gate vectors [L][Cp]
     int o_stamp;            // dev stamps: first LDS float behind everything the launched kernel uses
     int o_wres;             // specialised kernel: residual-1x1 tiles of layers 0..L-2 resident in LDS (float offset, 16-byte aligned)
     const int* bias_src;    // [n_bias] flat indices of the biases mirrored in LDS

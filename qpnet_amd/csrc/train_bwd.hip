@@ -838,7 +838,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         for (int l = 0; l < L; ++l) {
             const TrLayer& ly = p.layers[l];
             w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
-            w.tap_off[l] = (ly.adaptive && !getenv("QPN_EXP_NOTAP")) ? ly.tap_off : -1; w.dil[l] = ly.dilation;
+            w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
         }
         ok = ok && wgrad2_any(w, nch, stream);
     }
