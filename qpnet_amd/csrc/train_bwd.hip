@@ -699,22 +699,27 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
 }
 
 // upsampling kernel grad: dw[j] = sum_{a,f} dH[a, U f + j] h[a,f];  db = sum dH   (qpnet.py:134-158)
-__global__ __launch_bounds__(256) void k_up_bwd(TrainParams p, TrainBwd bw, int rows_per_wg) {
+// one thread per (row, feature) element with independent loads (a wave per row was one memory round trip per row: 25 us)
+__global__ __launch_bounds__(256) void k_up_bwd(TrainParams p, TrainBwd bw, int elems_per_wg) {
     extern __shared__ float accu[];                // [U + 1]
-    const int U = p.U, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int U = p.U, Ap = p.Ap, tid = threadIdx.x;
     for (int i = tid; i <= U; i += 256) accu[i] = 0.f;
     __syncthreads();
-    const int total = p.B * p.N1;                  // rows and F*U fit 32 bits (checked by the forward launcher)
-    const int r0 = blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < total ? r0 + rows_per_wg : total;
-    for (int rr = r0 + wave; rr < r1; rr += 4) {
+    const int total = p.B * p.N1 * Ap;             // fits 32 bits (checked by the forward launcher)
+    const int e0 = blockIdx.x * elems_per_wg, e1 = e0 + elems_per_wg < total ? e0 + elems_per_wg : total;
+    float bsum = 0.f;
+    for (int e = e0 + tid; e < e1; e += 256) {
+        const int rr = e / Ap, a = e - rr * Ap;
+        if (a >= p.A) continue;
         const int b = rr / p.N1, n = rr - b * p.N1;
         const int q = p.F * U - p.N1 + n;
-        const int f = q / U; const int j = q - f * U;
-        float dv = 0.f, pr = 0.f;
-        if (lane < p.A) { dv = bw.DHUP[((size_t)b * p.N1 + n) * p.Ap + lane]; pr = dv * p.h[((size_t)b * p.A + lane) * p.F + f]; }
-        for (int s = 32; s >= 1; s >>= 1) { dv += __shfl_xor(dv, s); pr += __shfl_xor(pr, s); }
-        if (lane == 0) { atomicAdd(&accu[j], pr); atomicAdd(&accu[U], dv); }
+        const int f = q / U, j = q - f * U;
+        const float dv = bw.DHUP[e];
+        atomicAdd(&accu[j], dv * p.h[((size_t)b * p.A + a) * p.F + f]);
+        bsum += dv;
     }
+    for (int s = 32; s >= 1; s >>= 1) bsum += __shfl_xor(bsum, s);
+    if ((tid & 63) == 0) atomicAdd(&accu[U], bsum);
     __syncthreads();
     for (int i = tid; i <= U; i += 256) atomicAdd(&bw.gflat[i < U ? p.up_w + i : p.up_b], accu[i]);
 }
@@ -871,7 +876,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0) { const int nwu = 256, rpu = (int)((total + nwu - 1) / nwu); hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, rpu); }
+        if (p.U > 0) { const int nwu = 512, tot = B * N1 * p.Ap, epw = (tot + nwu - 1) / nwu; hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, epw); }
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());
