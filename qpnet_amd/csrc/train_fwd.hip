@@ -190,6 +190,53 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     const int NTS = S / 16, NTQ = Q / 16, NCG = C / 16;
     // ---------- skip sum: K = L*C over the saved gates
     const int npairs = (NTS + 1) / 2;
+    const int LC = L * C, ldall = tr_lda(LC);
+    if (npairs <= 8 && (size_t)TM * ldall <= (size_t)TM * (lds + (lds > 2 * ldg ? lds : 2 * ldg))) {
+        // All L gate tiles fit the workgroup's LDS at once (they alias St / Yt, which are written only afterwards): every load of
+        // the tile is in flight together and the sum over layers is ONE K = L*C contraction -- one exposed memory round trip and
+        // two barriers instead of L of each.
+        float* Gall = sm;
+        const int per_row = LC / 2;                              // float2 pairs per row
+        for (int idx = tid; idx < TM * per_row; idx += 512) {
+            const int r = idx / per_row, kk = (idx - r * per_row) * 2;
+            const int l = kk / C, k = kk - l * C;
+            float2 g = make_float2(0.f, 0.f);
+            if (t0 + r < p.BL) {
+                const size_t o = ((size_t)(l * p.B + b) * p.N1 + nbase + r) * C + k;
+                const float2 a = *(const float2*)(p.SG + o), t = *(const float2*)(p.TH + o);
+                g = make_float2(a.x * t.x, a.y * t.y);
+            }
+            *(float2*)(Gall + (size_t)r * ldall + kk) = g;
+        }
+        __syncthreads();
+        const int np = wave;
+        const bool active = np < npairs;
+        const int nt0 = 2 * np, nt1 = (2 * np + 1 < NTS) ? 2 * np + 1 : 2 * np;
+        f32x4 acc[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        if (active) { const int nts[2] = {nt0, nt1}; wave_gemm<MT, 2>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
+        __syncthreads();                                         // every wave is done reading Gall before St overwrites it
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nt = j ? nt1 : nt0;
+                if (j && nt1 == nt0) break;
+                const int c = 16 * nt + (lane & 15);
+                const float bs = p.bp[p.bias_s + c];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * mt + 4 * (lane >> 4) + i;
+                        const float v = acc[mt][j][i] + bs;
+                        if (t0 + r < p.BL) p.S0[((size_t)b * p.BL + t0 + r) * S + c] = v;
+                        St[(size_t)r * lds + c] = v > 0.f ? v : 0.f;
+                    }
+            }
+        }
+        __syncthreads();
+    } else
     for (int pb = 0; pb < npairs; pb += 8) {                // pair batch (one batch when S <= 256)
         const int np = pb + wave;
         const bool active = np < npairs;
