@@ -97,6 +97,62 @@ def qpnet_forward(model, x, h, dilated_factors, blength):
     return QPNetFunction.apply(model, x, h, d, BL, maxd, *list(model.parameters()))
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) as ONE kernel over the model's flat parameter
+    buffer -- a one-line swap for `torch.optim.Adam(model.parameters(), lr=...)` in the reference loop
+    (src/bin/qpnet_train.py:426-429,531), whose ~50-tensor foreach update costs 0.9 ms per step on this GPU.
+    Gradients are read from `p.grad` (the autograd backward hands out views of one flat gradient buffer, so no gather
+    happens on the usual path).  State (`exp_avg`, `exp_avg_sq`, `step`) lives in flat tensors; its state_dict is its own
+    format, not torch.optim.Adam's."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model
+        super().__init__(list(model.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._m = self._v = None
+        self._steps = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        model = self.model
+        flat = getattr(model, "_flat", None)
+        if flat is None:
+            raise RuntimeError("FlatAdam.step before the first forward/backward of the model")
+        dev = flat.device
+        L, hd = model._native(dev)
+        params = list(model.parameters())
+        g = getattr(model, "_gflat", None)
+        ok = g is not None
+        if ok:
+            o = 0
+            for p in params:
+                if p.grad is None or p.grad.data_ptr() != g.data_ptr() + 4 * o:
+                    ok = False
+                    break
+                o += p.numel()
+        if not ok:                                   # grads came from elsewhere (or some are None): gather them
+            g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+        if self._m is None or self._m.numel() != flat.numel() or self._m.device != dev:
+            self._m = torch.zeros_like(flat); self._v = torch.zeros_like(flat)
+        grp = self.param_groups[0]
+        self._steps += 1
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(L.qpn_adam_step(hd, flat.data_ptr(), g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), flat.numel(),
+                                       self._steps, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], stream))
+        return loss
+
+    def state_dict(self):
+        return {"flat_adam": {"exp_avg": self._m, "exp_avg_sq": self._v, "step": self._steps}, "param_groups": [
+            {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        st = sd["flat_adam"]
+        self._m, self._v, self._steps = st["exp_avg"], st["exp_avg_sq"], int(st["step"])
+        for k, v in sd["param_groups"][0].items():
+            self.param_groups[0][k] = v
+
+
 class FusedTrainer:
     """forward + mean CE + backward + Adam entirely behind the C ABI (flat fp32 buffers).
 

@@ -207,3 +207,26 @@ def test_other_geometry_train_vs_oracle(geo, cuda):
     assert abs(loss.item() - float(oloss)) < 1e-4
     np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=2e-5, rtol=0)
     assert np.abs(grad - og).max() <= 2e-5 * np.abs(og).max()
+
+
+def test_flat_adam_matches_torch_adam(cuda):
+    """FlatAdam (one kernel over the flat parameter buffer) == torch.optim.Adam on the same loop, three steps."""
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import FlatAdam
+    cfg = TINY
+    flat = synth.make_weights(cfg, 11)
+    ws = []
+    for kind in ("torch", "flat"):
+        m = util.build_model(cfg, flat, cuda).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3) if kind == "torch" else FlatAdam(m, lr=1e-3)
+        for step in range(3):
+            x, h, t, d, b = synth.train_inputs(cfg, 700, 80 + step, 30000)
+            xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+            out = m(xt, ht, dt, bt)
+            loss = torch.nn.CrossEntropyLoss()(out.reshape(-1, cfg.n_quantize), tt[:, -out.shape[1]:].reshape(-1))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        ws.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy())
+    np.testing.assert_allclose(ws[0], ws[1], atol=2e-6, rtol=0)
