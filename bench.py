@@ -25,20 +25,39 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU, RCCL
+    rendezvous on 127.0.0.1) BEFORE this process touches the GPU, relay their output and exit with their status."""
+    if n_gpus <= 1 or "RANK" in os.environ:
+        return
+    import subprocess
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+BACKEND = "none"
+
+
 def dist_setup(n_gpus):
+    global BACKEND
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        if os.environ.get("QPN_BENCH_ONE_GPU"):      # dev aid: rehearse the N>1 code path with every rank on GPU 0 (gloo collectives)
+    if world > 1 or os.environ.get("QPN_BENCH_FORCE_PG"):
+        if os.environ.get("QPN_BENCH_ONE_GPU"):      # dev aid: rehearse the N>1 code path with every rank on GPU 0
             local = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
+        torch.cuda.set_device(local)
+        # every rank on one card cannot form an RCCL communicator (duplicate device): the one-GPU rehearsal uses gloo
+        BACKEND = os.environ.get("QPN_DIST_BACKEND", "gloo" if (os.environ.get("QPN_BENCH_ONE_GPU") and world > 1) else "nccl")
+        if BACKEND == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(BACKEND)
+        assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
     return rank, local, world
@@ -64,11 +83,15 @@ def max_over_ranks(v, world, dev):
 
 def measured_traffic():
     """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (committed under profiles/)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return json.load(f)
-    except Exception:
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            d["_file"] = "profiles/" + name
+            return d
+        except Exception:
+            continue
+    return None
 
 
 def decode_weight_bytes_per_sample(cfg):
@@ -79,18 +102,36 @@ def decode_weight_bytes_per_sample(cfg):
     return 172 + 4 * touched
 
 
-def cpu_baseline_decode(cfg, flat, n_frames=600):
-    """The CPU oracle (a single-threaded C port of the reference algorithm, validated against
-    the reference's own streams) timed on this box's host cores on a bounded sample."""
+def cpu_baseline_decode(cfg, flat, n_frames):
+    """The CPU oracle (a C port of the reference algorithm, validated against the reference's own streams) timed on this
+    box's host cores as SURVEY §8d asks: B = 1 and B = 20 utterances of the bench length, greedy, threads over utterances
+    (rows are independent; the port is scalar within an utterance) with all host cores and with 8 threads."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import cpu_oracle
     from qpnet_amd import synth
-    x, h, d, n = synth.decode_inputs(cfg, n_frames, 1, 1.0)
     cpu_oracle.lib()
-    t0 = time.time()
-    cpu_oracle.decode(cfg, flat, h, d, x, n)
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-            "sample": "greedy decode of one %d-frame utterance (%d samples), same synthetic features/weights" % (n_frames, n)}
+    ncores = os.cpu_count() or 1
+    utts = [synth.decode_inputs(cfg, n_frames, 100 + b, 1.0) for b in range(20)]
+
+    def one(u):
+        x, h, d, n = u
+        cpu_oracle.decode(cfg, flat, h, d, x, n)      # ctypes releases the GIL for the duration of the C call
+        return n
+
+    def timed(batch, threads):
+        t0 = time.time()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            total = sum(ex.map(one, batch))
+        return total / (time.time() - t0)
+
+    b1 = timed(utts[:1], 1)
+    b20_all = timed(utts, min(20, ncores))
+    b20_8 = timed(utts, min(8, ncores))
+    return {"value": b20_all, "unit": "samples/s", "cores": min(20, ncores), "kind": "port",
+            "sample": "greedy decode of 20 x %d-frame utterances (%d samples each), one thread per utterance on %d host cores; same "
+                      "synthetic features/weights as the GPU run" % (n_frames, utts[0][3], ncores),
+            "batch1_one_core": b1, "batch20_8_threads": b20_8, "host_cores": ncores,
+            "note": "reference code itself (torch CPU, 8 threads, survey container): 273 samples/s (BASELINE.md section 2)"}
 
 
 def run_decode(args, rank, local, world):
@@ -125,8 +166,10 @@ def run_decode(args, rank, local, world):
     total_samples = sum(ns) * args.steps * world
     value = total_samples / dt
     k_ms = float(np.mean(kms))
-    bps = decode_weight_bytes_per_sample(cfg)
-    achieved = bps * sum(ns) / (k_ms * 1e-3) / 1e9
+    tr = (measured_traffic() or {})
+    hbm_meas = tr.get("decode", {}).get("hbm_bytes_per_sample")
+    us = k_ms * 1e3 / max(ns)                      # device time per generated sample of one utterance (rows run concurrently)
+    floor = 11.65                                  # profiles/r01_l2_stream_floor.txt: one CU re-streaming the 1.7 MB of tiles from L2
     out = {
         "metric": "AR decode samples/sec/GPU @22.05kHz (greedy)" if world == 1 else "AR decode samples/sec @22.05kHz (greedy), all GPUs",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -134,15 +177,19 @@ def run_decode(args, rank, local, world):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "config[3]: batch_fast_generate(argmax) of %d x %.1f s utterances per GPU, paper-size QPNet "
                                "(C=64,S=256,4F+4A), F=%d frames -> %d samples each" % (B, ns[0] / 22050.0, F, ns[0]),
-                   "batch_per_gpu": B, "parallelism": "replicas x%d (no collective)" % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": (measured_traffic() or {}).get("decode", {}).get("hbm_bytes_per_sample", 0) * sum(ns) or None,
-                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per sample x samples of this launch)",
+                   "batch_per_gpu": B, "parallelism": "replicas x%d (no collective)" % world, "backend": BACKEND, "world_size": world},
+        # the decode loop is a serial chain of L+2 dependent matvec stages per sample: its bound is latency, not HBM
+        # (SURVEY 8d).  achieved / floor are microseconds per sample per utterance; frac = floor / achieved.
+        "roofline": {"bound": "latency(L2 port)", "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance",
+                     "frac": floor / us if us > 0 else 0.0,
+                     "hbm_algorithmic": 172, "hbm_bytes_per_sample": hbm_meas,
+                     "hbm_achieved_GBps": 172.0 * sum(ns) / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
+                     "traffic": hbm_meas * sum(ns) if hbm_meas else None,
+                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per sample x samples of this launch)" % tr.get("_file"),
+                     "cus_busy": min(B, 256) / 256.0,
                      "kernel": "k_decode_fast" if cfg.n_resch <= 64 else "k_decode", "kernel_ms": k_ms,
-                     "l2_stream_floor_us_per_sample": 11.65,
-                     "note": "algorithmic bytes = (172 + 4*params touched) B/sample = %d B/sample (SURVEY 8d, weights re-streamed "
-                             "every sample; they are L2-resident so this is L2->CU traffic, not HBM)" % bps},
+                     "note": "one persistent workgroup (one CU) per utterance; weights (1.7 MB of tiles per sample) are re-streamed from "
+                             "L2 every sample, HBM sees only the per-sample inputs/outputs (172 B algorithmic)"},
     }
     if world == 1 and not args.no_cpu:
         # the reference decode script's default mode (softmax + draw, qpnet_decode.py:312-314): one untimed-in-`value` launch
@@ -151,11 +198,11 @@ def run_decode(args, rank, local, world):
         torch.cuda.synchronize()
         out["sampling_mode"] = {"value": sum(ns) / (time.perf_counter() - t1), "unit": "samples/s", "kernel_ms": m.last_decode_kernel_ms}
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline_decode(cfg, flat)
+        out["cpu_baseline"] = cpu_baseline_decode(cfg, flat, F)
     return out
 
 
-PG_NAMES = ["prep+pack", "k_layer_fwd", "k_post_fwd", "k_ce", "k_post_bwd", "k_wgrad", "k_layer_bwd", "grad_tail", "k_adam"]
+PG_NAMES = ["prep+pack", "k_layer_fwd", "k_post_fwd", "k_ce", "k_post_bwd", "k_wgrad", "k_layer_bwd", "grad_tail", "k_adam", "allreduce"]
 
 
 def train_flops(cfg, N1, BL, starts_out):
@@ -191,7 +238,34 @@ def cpu_baseline_train(cfg, flat, batch):
     except Exception:
         cores = os.cpu_count()
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "one full-size step (forward+CE+backward+Adam, chunk of %d samples) of the numpy float32 oracle" % x.shape[1]}
+            "sample": "one full-size step (forward+CE+backward+Adam, chunk of %d samples) of the numpy float32 oracle" % x.shape[1],
+            "note": "numpy port (BLAS threads); slower than the reference's own torch-CPU step, 1.20 s/step on 8 threads in the "
+                    "survey container (BASELINE.md section 2)"}
+
+
+def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=30):
+    """The reference trainer's loop, unchanged, on the drop-in module (src/bin/qpnet_train.py:517-531):
+    model(x,h,d,b) -> nn.CrossEntropyLoss -> zero_grad -> backward -> Adam.step."""
+    import torch
+    from qpnet_amd.train import FlatAdam
+    opt = FlatAdam(m, lr=1e-4) if flat_adam else torch.optim.Adam(m.parameters(), lr=1e-4)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def step(i):
+        x, h, t, d, b = batches[i % nchunks]
+        out = m(x, h, d, b)
+        BL = out.shape[1]
+        loss = crit(out.view(-1, cfg.n_quantize), t[:, -BL:].reshape(-1))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    return steps / (time.perf_counter() - t0)
 
 
 def run_train(args, rank, local, world):
@@ -209,6 +283,10 @@ def run_train(args, rank, local, world):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
     m = m.to(dev).train()
     tr = FusedTrainer(m, lr=1e-4, world_size=world)
+    if world > 1:
+        from qpnet_amd import parallel
+        from qpnet_amd.train import ensure_flat
+        parallel.broadcast_parameters(ensure_flat(m, dev))          # every rank starts from rank 0's parameters
     # utterance-sharded synthetic chunks: rank r consumes chunks r, r+world, ...
     nchunks = 4
     host_batches = [synth.train_inputs(cfg, 20000, 5000 + 17 * (rank + world * i), 30000, f0_lo=55.0, f0_hi=300.0) for i in range(nchunks)]
@@ -248,7 +326,7 @@ def run_train(args, rank, local, world):
     for dil in cfg.dilationsA:
         s_ += dil * maxd; starts.append(s_)
     fl = train_flops(cfg, N1, BL, starts)
-    dom = int(np.argmax(ms))
+    dom = int(np.argmax(ms[:9]))                  # dominant COMPUTE group (the all-reduce is reported beside it)
     achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
     total_flops = sum(fl)
     value = args.steps * world / dt
@@ -259,11 +337,12 @@ def run_train(args, rank, local, world):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "config[1]: paper-size SI-QPNet (C=64,S=256,4F+4A) training step, forward+CE+backward+Adam on one chunk "
                                "of %d samples (RF %d + batch_length %d), batch 1 per GPU" % (x0.shape[1], N1 + 1 - BL, BL),
-                   "global_batch": world, "parallelism": "dp%d (utterance-sharded chunks, one flat-gradient all-reduce per step)" % world},
+                   "global_batch": world, "parallelism": "dp%d (utterance-sharded chunks, one flat-gradient all-reduce per step)" % world,
+                   "backend": BACKEND, "world_size": (dist.get_world_size() if dist.is_initialized() else 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / F32_MFMA_PEAK_TFLOPS,
                      "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None,
-                     "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, the weight-gradient launches of one step)",
+                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, the weight-gradient launches of one step)" % (measured_traffic() or {}).get("_file"),
                      "kernel": PG_NAMES[dom],
                      "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
@@ -271,6 +350,10 @@ def run_train(args, rank, local, world):
                      "note": "achieved = algorithmic FLOPs of the dominant kernel group (all its launches in one step) / its summed "
                              "device time from HIP events on the launch stream; step_tflops = whole step"},
     }
+    if world == 1 and not args.no_cpu:
+        # the drop-in path north_star describes: the reference's own loop on this module (weights keep training; timing only)
+        out["dropin_loop_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=False)
+        out["dropin_loop_flat_adam_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=True)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_train(cfg, flat, host_batches[0])
     return out
@@ -291,7 +374,10 @@ def main():
         args.steps = 3 if args.mode == "decode" else 50
     if args.warmup is None:
         args.warmup = 1 if args.mode == "decode" else 5
+    self_launch(args.gpus)
     rank, local, world = dist_setup(args.gpus)
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: measuring %d rank(s)" % (args.gpus, world, world), file=sys.stderr)
     if args.mode == "decode":
         out = run_decode(args, rank, local, world)
     else:
@@ -307,8 +393,8 @@ def main():
                                        "kernel_ms": d1["roofline"]["kernel_ms"]}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -116,12 +116,24 @@ int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int64_t T, int6
  * d_dlogits (B x BL x n_quantize) -> d_flatgrad (n_params, overwritten), same layout as d_flat. */
 int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, void* stream);
 
+/* Same with the data-parallel hooks of the one gradient exchange per step (replaces the reference's dead DataParallel wrapper,
+ * src/bin/qpnet_train.py:416-423): the flat gradient is multiplied by grad_scale (the rank's row count B*BL) inside the
+ * reduction kernel; with append_scale != 0, d_flatgrad must hold n_params + 4 floats and receives {grad_scale, 0, 0, 0} behind
+ * the gradient, so ONE all-reduce(SUM) carries both sum_r n_r g_r and sum_r n_r. */
+int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, float grad_scale, int append_scale, void* stream);
+
+/* Number of qpn_train_forward calls on this handle so far.  The activations backward needs live in the handle's workspace
+ * (one outstanding forward per handle): a caller that defers backward (torch autograd) records the value after forward and
+ * compares before backward (reference: autograd keeps per-call activations, src/bin/qpnet_train.py:520-530). */
+int64_t qpn_train_generation(qpn_handle* h);
+
 /* Synchronise and report the device-side status of the last training call (QPN_ERANGE when a
  * pitch-dependent tap left its layer input: reference assert qpnet.py:294). */
 int qpn_train_status(qpn_handle* h, void* stream);
 
 /* torch.nn.CrossEntropyLoss() (mean) on the logits above and, optionally, its gradient
- * (reference src/bin/qpnet_train.py:430,526-528).  d_targets is the (B x tgt_stride) int64 target
+ * (reference src/bin/qpnet_train.py:430,526-528; a target outside [0, n_quantize) is clamped and flagged: qpn_train_status
+ * returns QPN_ERANGE, the reference asserts at :525).  d_targets is the (B x tgt_stride) int64 target
  * tensor whose LAST BL columns are used (batch_t[:, -batch_length:]).  h_loss (optional, host)
  * receives the loss (synchronises); d_dlogits (optional) receives dL/dlogits. */
 int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,
@@ -131,6 +143,12 @@ int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, 
  * d_flat, d_m, d_v (n floats each) updated from d_grad; `step` is the 1-based step count. */
 int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
                   int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
+
+/* Same, reading the gradient as d_grad[i] / d_grad_denominator[0] (device scalar, e.g. the summed row count behind an
+ * all-reduced gradient; NULL = 1): no host read-back and no extra elementwise launch in a data-parallel step. */
+int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
+                     int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     const float* d_grad_denominator, void* stream);
 
 /* Per-kernel-group device timings of the training calls issued between begin and end (HIP events on
  * `stream`; used by bench.py for the roofline).  h_ms[QPN_PG_*] receives milliseconds. */
@@ -143,8 +161,10 @@ int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m,
 #define QPN_PG_LAYER_BWD 6
 #define QPN_PG_GRAD_TAIL 7
 #define QPN_PG_ADAM 8
-#define QPN_PG_COUNT 9
+#define QPN_PG_ALLREDUCE 9     /* marked by the caller after its gradient all-reduce (qpn_train_profile_mark) */
+#define QPN_PG_COUNT 10
 int qpn_train_profile_begin(qpn_handle* h, void* stream);
+int qpn_train_profile_mark(qpn_handle* h, int group, void* stream);   /* attribute the work enqueued since the previous mark to `group` */
 int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);
 
 /* _dilated_index (src/nets/qpnet.py:592-604, tensor path) and _generate_dilated_index

@@ -36,10 +36,14 @@ SYMBOLS = [
     ("qpn_last_decode_kernel_ms", C.c_float, [_vp]),
     ("qpn_train_forward", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("qpn_train_backward", _i, [_vp, _vp, _vp, _vp]),
+    ("qpn_train_backward_ex", _i, [_vp, _vp, _vp, C.c_float, _i, _vp]),
+    ("qpn_train_generation", _i64, [_vp]),
     ("qpn_train_status", _i, [_vp, _vp]),
     ("qpn_ce_loss", _i, [_vp, _vp, _vp, _i64, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("qpn_adam_step", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
+    ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     ("qpn_train_profile_begin", _i, [_vp, _vp]),
+    ("qpn_train_profile_mark", _i, [_vp, _i, _vp]),
     ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),
     ("qpn_dilated_index_train", _i, [_vp, _i, _i64, _i, _vp, _vp]),
     ("qpn_dilated_index_gen_f32", _i, [_vp, _i64, _i, _vp, _vp]),

@@ -276,22 +276,30 @@ __device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDes
 }
 
 // pitch-dependent tap distance of ring `r` at (padded) time t  (qpnet.py:613-624)
-__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int ut) {
+// `widx` != 0: warm-up step over the known prefix -- the reference takes those taps from _dilated_index (qpnet.py:416,
+// 592-611: rint(-d*dil + idx), idx = position from the end of the prefix), not from _generate_dilated_index
+__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int ut, int widx) {
     if (!r.adaptive) return r.mult;
     if (ut < 0) return r.mult;                       // d := 1.0 in the left padding (qpnet.py:361-364)
     if (u.d_is_f32) {
         float d = ((const float*)u.dfac)[ut];
+        if (widx) return widx - (int)rintf(__fadd_rn(-d * (float)r.mult, (float)widx));
         return -(int)rintf(-d * (float)r.mult);
     }
     double d = ((const double*)u.dfac)[ut];
+    if (widx) return widx - (int)rint(__dadd_rn(-d * (double)r.mult, (double)widx));
     return -(int)rint(-d * (double)r.mult);
 }
+// un-padded time whose aux features / dilated factor step t uses: the newest sample's own in the generation loop
+// (qpnet.py:450-452); one EARLIER during the warm-up over the known prefix, where the reference pairs layer output p with
+// h[p-1], d[p-1] (h_ = h[:, :, :causal_output.size(-1)], qpnet.py:366-368; visible only with seeds of >= 3 samples)
+__device__ __forceinline__ int aux_time(const UttView& u, int t) { return t - u.n_pad - (t < u.n0 - 1 ? 1 : 0); }
 
 // aux terms a[t1] of every layer -> LDS (needs only the frame-rate projections)
 __device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& u, int64_t t1, int tid, int nthreads) {
     float* sm = SM;
     const int n = p.L * 2 * p.C;
-    const int ut = (int)t1 - u.n_pad;                // 32-bit: n0 + n_samples < 2^31 is checked on the host
+    const int ut = aux_time(u, (int)t1);             // 32-bit: n0 + n_samples < 2^31 is checked on the host
     int f, j;
     if (ut < 0) { f = 0; j = 0; }                    // replicate pad of the upsampled h (qpnet.py:359)
     else if (p.U > 0) { f = (int)((unsigned)ut / (unsigned)p.U); j = ut - f * p.U; }
@@ -305,11 +313,12 @@ __device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& 
 __device__ __forceinline__ void stage_taps(const DecodeParams& p, const UttView& u, int64_t t2, int tid, int nthreads, int* status) {
     const int L = p.L, C = p.C;
     float* sm = SM; int* smi = SMI;
-    const int ut = (int)t2 - u.n_pad;
+    const int ut = aux_time(u, (int)t2);
+    const int widx = (int)t2 < u.n0 - 1 ? (int)t2 - (u.n0 - 1) : 0;
     for (int i = tid; i < L * C; i += nthreads) {
         const int l = i / C, c = i - l * C;
         const RingDesc r = p.rings[l];
-        int off = tap_offset(r, u, ut);
+        int off = tap_offset(r, u, ut, widx);
         if (off < 1 || off >= r.len) { if (c == 0) atomicOr(status, 1); off = off < 1 ? 1 : r.len - 1; }
         if (c == 0) smi[p.o_sel + l] = off == 1;
         if (off > 1) {

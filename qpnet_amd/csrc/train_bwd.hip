@@ -647,13 +647,15 @@ static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------ small backward kernels
-__global__ void k_reduce_grad(const float* __restrict__ slab, const int* __restrict__ gsrc, int nch, int gstage, int64_t n, float* __restrict__ g) {
+__global__ void k_reduce_grad(const float* __restrict__ slab, const int* __restrict__ gsrc, int nch, int gstage, int64_t n, float* __restrict__ g,
+                              float scale, int append_scale) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (append_scale && i >= n && i < n + 4) { g[i] = i == n ? scale : 0.f; return; }
     if (i >= n) return;
     const int s = gsrc[i];
     float a = 0.f;
     if (s >= 0) for (int c = 0; c < nch; ++c) a += slab[(size_t)c * gstage + s];
-    g[i] = a;
+    g[i] = a * scale;
 }
 
 // causal conv weight grad: dW[c][q][tap] = sum over rows whose sample == q; LDS table per channel block
@@ -686,13 +688,13 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
         for (int i = tid; i < 2 * Q * cbv; i += 256) {
             const int c = i / (2 * Q), qt = i - c * 2 * Q, q = qt >> 1, tp = qt & 1;
             const float v = tab[(tp * Q + q) * CB + c];
-            if (v != 0.f) atomicAdd(&bw.gflat[p.causal_w + ((size_t)(cb + c) * Q + q) * 2 + tp], v);
+            if (v != 0.f) atomicAdd(&bw.gflat[p.causal_w + ((size_t)(cb + c) * Q + q) * 2 + tp], v * bw.gscale);
         }
         // bias grad = sum over all rows = sum over q of the tap-0 table
         for (int c = tid; c < cbv; c += 256) {
             float s = 0.f;
             for (int q = 0; q < Q; ++q) s += tab[(0 * Q + q) * CB + c];
-            atomicAdd(&bw.gflat[p.causal_b + cb + c], s);
+            atomicAdd(&bw.gflat[p.causal_b + cb + c], s * bw.gscale);
         }
         __syncthreads();
     }
@@ -721,15 +723,16 @@ __global__ __launch_bounds__(256) void k_up_bwd(TrainParams p, TrainBwd bw, int 
     for (int s = 32; s >= 1; s >>= 1) bsum += __shfl_xor(bsum, s);
     if ((tid & 63) == 0) atomicAdd(&accu[U], bsum);
     __syncthreads();
-    for (int i = tid; i <= U; i += 256) atomicAdd(&bw.gflat[i < U ? p.up_w + i : p.up_b], accu[i]);
+    for (int i = tid; i <= U; i += 256) atomicAdd(&bw.gflat[i < U ? p.up_w + i : p.up_b], accu[i] * bw.gscale);
 }
 
 // torch.optim.Adam (single tensor semantics, fp32)
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float gi = g[i];
+    if (den) gi = gi / den[0];                                  // data-parallel: summed row-weighted gradients / summed row count
     if (wd != 0.f) gi += wd * w[i];
     const float mi = m[i] + (gi - m[i]) * (1.0f - b1);          // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
@@ -810,14 +813,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
             ok = ok && wgrad2_any(w, nch, st);
         }
     };
-    static hipStream_t side = nullptr; static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    const bool overlap = !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
+    hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
+    const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
     if (overlap) {
-        if (!side) {
-            QPN_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            QPN_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            QPN_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        }
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
@@ -868,7 +866,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     qpn_prof_mark(PG_WGRAD, stream);
     // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
-    hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat);
+    hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
     {
         const int64_t total = (int64_t)B * N1;
         const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
@@ -883,9 +881,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     return QPN_OK;
 }
 
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, hipStream_t stream) {
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), den);
     qpn_prof_mark(PG_ADAM, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

@@ -72,10 +72,13 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
     int g_p1, g_bp1, g_p2, g_bp2;
     int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
+    float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
+    int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
+    hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream of the skip / post-net weight gradients (owned by TrainState)
 };
 
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)
-enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_COUNT };
+enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE, PG_COUNT };
 void qpn_prof_mark(int group, hipStream_t stream);
 bool qpn_prof_active();                              // per-group timing in progress (keeps a step on one stream)   // attributes the work enqueued since the previous mark to `group`
 

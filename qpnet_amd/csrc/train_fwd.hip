@@ -38,18 +38,18 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     }
     // upsampled aux features, aligned at the END of h_up (negative hindex, qpnet.py:269-276)
     float* hu = p.HUP + ((size_t)b * p.N1 + n) * p.Ap;
-    if (lane < p.Ap) {
+    for (int a = lane; a < p.Ap; a += 64) {                  // any n_aux (one pass for the usual 39)
         float v = 0.0f;
-        if (lane < p.A) {
+        if (a < p.A) {
             if (p.U > 0) {
                 const int64_t q = (int64_t)p.F * p.U - p.N1 + n;
                 const int64_t f = q / p.U; const int j = (int)(q - f * p.U);
-                v = p.h[((size_t)b * p.A + lane) * p.F + f] * p.flat[p.up_w + j] + p.flat[p.up_b];
+                v = p.h[((size_t)b * p.A + a) * p.F + f] * p.flat[p.up_w + j] + p.flat[p.up_b];
             } else {
-                v = p.h[((size_t)b * p.A + lane) * p.F + (p.F - p.N1 + n)];
+                v = p.h[((size_t)b * p.A + a) * p.F + (p.F - p.N1 + n)];
             }
         }
-        hu[lane] = v;
+        hu[a] = v;
     }
     // pitch-dependent taps: N1 + rint(float32(-d*dil) + float32(idx)), idx = n - N1 (qpnet.py:595-600)
     if (lane < p.L) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 
 // mean cross entropy + its gradient, one wave per row, rpw rows per wave (reference qpnet_train.py:430,526-528)
 __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t tgt_stride,
-                                            int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss, int rpw) {
+                                            int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss, int rpw, int* __restrict__ status) {
     __shared__ double part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv = 1.0f / (float)rows;
@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
         if (row >= rows) break;
         const float* lg = logits + (size_t)row * Q;
         const int64_t b = row / BL, t = row - b * BL;
-        const int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
+        int64_t tg = tgt[(size_t)b * tgt_stride + (tgt_stride - BL) + t];
+        if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(status, 2); tg = tg < 0 ? 0 : Q - 1; }     // reference: assert max(batch_t) < n_quantize
         float m = -INFINITY;
         const bool vec = (Q & 255) == 0;             // 4 contiguous logits per lane per pass (16-byte accesses)
         if (vec) for (int q = lane * 4; q < Q; q += 256) { const float4 v = *(const float4*)(lg + q); m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
@@ -457,11 +458,11 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     return QPN_OK;
 }
 
-int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream) {
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, hipStream_t stream) {
     const int64_t rows = (int64_t)B * BL;
     QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
     const int rpw = 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
-    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw);
+    hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw, status);
     qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

@@ -8,9 +8,9 @@
 #include <string.h>
 
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
-int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, hipStream_t stream);
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, hipStream_t stream);
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, hipStream_t stream);
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
 
 
 struct TrainState {
@@ -26,6 +26,8 @@ struct TrainState {
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
     bool fwd_valid;
+    int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
+    hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream for the weight gradients that overlap the layer backward
 };
 
 // ---- per-group timing
@@ -43,6 +45,9 @@ extern "C" int qpn_train_profile_begin(qpn_handle* h, void* stream) {
     (void)h; g_prof.on = true; g_prof.used = 0;
     qpn_prof_mark(-1, (hipStream_t)stream);
     return QPN_OK;
+}
+extern "C" int qpn_train_profile_mark(qpn_handle* h, int group, void* stream) {
+    (void)h; qpn_prof_mark(group, (hipStream_t)stream); return QPN_OK;
 }
 extern "C" int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream) {
     (void)h;
@@ -93,6 +98,7 @@ static int train_init(qpn_handle* h) {
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
+    t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = nullptr;
     TrainParams& p = t->tp;
     const int Ap = (A + 3) / 4 * 4;               // aux columns padded to the MFMA k-step
     p.C = C; p.S = S; p.Q = Q; p.A = A; p.Ap = Ap; p.L = L; p.U = g.U;
@@ -202,6 +208,9 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc2, gs2.data(), gs2.size() * sizeof(int), hipMemcpyHostToDevice));
+    QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     h->train = t;
     return QPN_OK;
 }
@@ -210,6 +219,9 @@ void qpn_train_destroy(TrainState* t) {
     if (!t) return;
     void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (t->side) (void)hipStreamDestroy(t->side);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     delete t;
 }
 
@@ -279,6 +291,8 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
     QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
     qpn_prof_mark(PG_PREP, stream);
+    t->fwd_valid = false;
+    ++t->generation;
     rc = qpn_launch_fwd(p, stream); if (rc) return rc;
     t->fwd_valid = true;
     return QPN_OK;
@@ -291,6 +305,7 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
+    if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;
 }
 
@@ -300,7 +315,7 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
     rc = train_init(h); if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_logits || !d_targets || B < 1 || BL < 1 || tgt_stride < BL) { qpn_set_error("bad ce_loss arguments"); return QPN_EINVAL; }
-    rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, stream); if (rc) return rc;
+    rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, h->train->d_status, stream); if (rc) return rc;
     if (h_loss) {
         QPN_HIP(hipMemcpyAsync(h_loss, h->train->d_loss, sizeof(double), hipMemcpyDeviceToHost, stream));
         QPN_HIP(hipStreamSynchronize(stream));
@@ -308,19 +323,33 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
     return QPN_OK;
 }
 
+extern "C" int64_t qpn_train_generation(qpn_handle* h) { return (h && h->train) ? h->train->generation : 0; }
+
 extern "C" int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, void* stream_) {
+    return qpn_train_backward_ex(h, d_dlogits, d_flatgrad, 1.0f, 0, stream_);
+}
+
+extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, float grad_scale, int append_scale, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!h->train || !h->train->fwd_valid) { qpn_set_error("qpn_train_backward needs a preceding qpn_train_forward"); return QPN_ESTATE; }
     if (!d_dlogits || !d_flatgrad) { qpn_set_error("bad train_backward arguments"); return QPN_EINVAL; }
     TrainState* t = h->train;
     TrainBwd& bw = t->bw;
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
+    bw.gscale = grad_scale; bw.append_scale = append_scale;
+    bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join;
     return qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
                              int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
+    return qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream_);
+}
+
+extern "C" int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
+                                int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                const float* d_grad_denominator, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
-    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, (hipStream_t)stream_);
+    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, (hipStream_t)stream_);
 }

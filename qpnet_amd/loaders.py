@@ -1,7 +1,7 @@
 """In-memory counterparts of the reference's batch generators and checkpoint helpers.
 
 Same batching / chunking semantics as the reference task scripts, but over arrays instead of .wav/.h5 files
-(file formats are rank 4 and stay out of scope; h5py is not even installed here):
+(the file formats of rank 4 are at the end of this module):
 
   decode_generator  <- src/bin/qpnet_decode.py:122-209  (sort by length, array_split batching, F0 scaling,
                        d = fs/(f0*dense) extended x U, scaler, zero pad_list, n_samples = F*U - 1)
@@ -55,60 +55,96 @@ def decode_generator(feats, fs, feat_ids=None, wav_transform=None, feat_transfor
         yield ids, batch_x, batch_h, ns, batch_d
 
 
+class _SampleWindow:
+    """The trainer's running window over the concatenated utterance stream: one waveform-rate array pair (samples,
+    dilated factors) and one frame-rate array (features), consumed from the front by explicit offsets.  Storage is
+    compacted only when the consumed prefix outweighs the live part, so appending an utterance costs its own length."""
+
+    def __init__(self, n_feat, feat_dtype):
+        self.x = np.empty(0, dtype=np.float32)
+        self.d = np.empty(0, dtype=np.float64)          # float32 buffer + float64 factors promote to float64 upstream too
+        self.h = np.empty((0, n_feat), dtype=np.result_type(np.float32, feat_dtype))
+        self.s0 = 0                                     # first live sample
+        self.f0 = 0                                     # first live frame
+
+    def append(self, x, h, d):
+        if self.s0 > len(self.x) - self.s0:             # drop the consumed prefix
+            self.x, self.d, self.h = self.x[self.s0:], self.d[self.s0:], self.h[self.f0:]
+            self.s0 = self.f0 = 0
+        self.x = np.concatenate([self.x, np.asarray(x, dtype=np.float32)])
+        self.d = np.concatenate([self.d, np.asarray(d, dtype=np.float64)])
+        self.h = np.concatenate([self.h, h.astype(self.h.dtype, copy=False)])
+
+    @property
+    def n_samples(self):
+        return len(self.x) - self.s0
+
+    @property
+    def n_frames(self):
+        return len(self.h) - self.f0
+
+    def max_factor(self):
+        return self.d[self.s0:]
+
+    def front(self, frames, samples):
+        return (self.x[self.s0:self.s0 + samples], self.h[self.f0:self.f0 + frames], self.d[self.s0:self.s0 + samples])
+
+    def advance(self, frames, samples):
+        self.f0 += frames
+        self.s0 += samples
+
+
 def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_receptiveA, fs, wav_transform=None,
                     feat_transform=None, dense_factor=8, batch_length=20000, batch_size=1, max_length=23070,
                     f0_threshold=0, upsampling_factor=80, shuffle=True, device=None, epochs=None):
-    """utterances: list of (x float waveform in [-1,1], h (F, n_aux)) pairs.  Yields (batch_x, batch_h, batch_t, batch_d,
-    batch_b) like the reference generator; endless unless `epochs` is given."""
+    """Chunked teacher-forcing batches over a stream of utterances (reference generator: src/bin/qpnet_train.py:200-335).
+
+    utterances: list of (x float waveform in [-1,1], h (F, n_aux)) pairs, or zero-argument callables returning such a
+    pair (lazy file loading).  Yields (batch_x, batch_h, batch_t, batch_d, batch_b); endless unless `epochs` is given.
+
+    Behaviour kept from the reference (pinned by tests/test_loaders_cpu.py): utterances are concatenated into one stream
+    that survives epoch boundaries; after each appended utterance the receptive field is taken from the largest dilated
+    factor still in the window, the batch length is cut to fit max_length and a whole number of frames, and chunks of
+    RF + BL (+1 sample for the input/target shift) are cut while MORE than `slots_left` chunks' worth of frames and
+    samples remain, each advancing the window by BL (so consecutive chunks overlap by RF)."""
+    U = int(upsampling_factor)
     n_files = len(utterances)
-    order = list(np.random.permutation(n_files)) if shuffle else list(range(n_files))
-    x_buffer = h_buffer = d_buffer = None
+    order = np.random.permutation(n_files) if shuffle else np.arange(n_files)
+    win = None
     epoch = 0
     while epochs is None or epoch < epochs:
-        bx, bh, bt, bd, bb = [], [], [], [], []
-        batch_count = batch_size
+        rows = []                                       # (x, h, t, d, bl) of the batch being filled
+        slots_left = batch_size
         for i in order:
-            x, h = utterances[i]
-            x = np.array(x, dtype=np.float32)
-            x, h = harness.validate_length(x, np.asarray(h), upsampling_factor)
+            item = utterances[int(i)]
+            x, h = item() if callable(item) else item
+            x, h = harness.validate_length(np.array(x, dtype=np.float32), np.asarray(h), U)
             d = harness.dilated_factor(harness.batch_f0(h, f0_threshold), fs, dense_factor)
-            d = np.squeeze(harness.extend_time(np.expand_dims(d, -1), upsampling_factor), -1)
-            if x_buffer is None:
-                x_buffer = np.empty((0), dtype=np.float32)
-                h_buffer = np.empty((0, h.shape[1]), dtype=np.float32)
-                d_buffer = np.empty((0), dtype=np.float32)
-            x_buffer = np.concatenate([x_buffer, x], axis=0)
-            h_buffer = np.concatenate([h_buffer, h], axis=0)
-            d_buffer = np.concatenate([d_buffer, d], axis=0)
-            rf = harness.receptive_field(model_receptiveCausal, model_receptiveF, model_receptiveA, d_buffer)
-            mod1 = max(rf + batch_length - max_length, 0)                  # avoid out-of-memory (:273-275)
-            bl = batch_length - mod1
-            bl -= (rf + bl) % upsampling_factor                            # meet the upsampling ratio (:276-278)
-            h_bs = (rf + bl) // upsampling_factor
-            x_bs = h_bs * upsampling_factor + 1
-            while len(h_buffer) > (batch_count * h_bs) and len(x_buffer) > (batch_count * x_bs):
-                h_, x_, d_ = h_buffer[:h_bs, :], x_buffer[:x_bs], d_buffer[:x_bs]
+            if win is None:
+                win = _SampleWindow(h.shape[1], h.dtype)
+            win.append(x, h, np.repeat(d, U))
+            rf = harness.receptive_field(model_receptiveCausal, model_receptiveF, model_receptiveA, win.max_factor())
+            bl, frames, samples = harness.chunk_plan(rf, batch_length, max_length, U)
+            hop_frames = bl // U
+            while win.n_frames > slots_left * frames and win.n_samples > slots_left * samples:
+                xs, hs, ds = win.front(frames, samples)
                 if wav_transform is not None:
-                    x_ = wav_transform(x_)
+                    xs = wav_transform(xs)
                 if feat_transform is not None:
-                    h_ = feat_transform(h_)
-                x_ = torch.from_numpy(np.asarray(x_)).long()
-                h_ = torch.from_numpy(np.asarray(h_)).float()
-                d_ = torch.from_numpy(np.asarray(d_)).float()
-                bh.append(h_.transpose(0, 1)); bx.append(x_[:-1]); bt.append(x_[1:]); bd.append(d_[:-1]); bb.append(bl)
-                batch_count -= 1
-                h_ss = bl // upsampling_factor                              # shift = batch_length: chunks overlap by RF
-                x_ss = h_ss * upsampling_factor
-                h_buffer, x_buffer, d_buffer = h_buffer[h_ss:, :], x_buffer[x_ss:], d_buffer[x_ss:]
-                if len(bx) == batch_size:
-                    out = (torch.stack(bx), torch.stack(bh), torch.stack(bt), torch.stack(bd), torch.tensor(bb))
+                    hs = feat_transform(hs)
+                xs = torch.from_numpy(np.asarray(xs)).long()
+                rows.append((xs[:-1], torch.from_numpy(np.asarray(hs)).float().transpose(0, 1), xs[1:],
+                             torch.from_numpy(np.asarray(ds)).float()[:-1], bl))
+                slots_left -= 1
+                win.advance(hop_frames, hop_frames * U)
+                if len(rows) == batch_size:
+                    out = tuple(torch.stack([r[k] for r in rows]) for k in range(4)) + (torch.tensor([r[4] for r in rows]),)
                     if device is not None:
                         out = tuple(o.to(device) for o in out)
                     yield out
-                    bx, bh, bt, bd, bb = [], [], [], [], []
-                    batch_count = batch_size
+                    rows, slots_left = [], batch_size
         if shuffle:
-            order = list(np.random.permutation(n_files))
+            order = np.random.permutation(n_files)
         epoch += 1
 
 
@@ -160,13 +196,20 @@ def write_wav(path, fs, samples, n_quantize=256):
     return path
 
 
+def read_wav(path):
+    """(fs, float32 waveform in [-1, 1)) the way the trainer reads it (qpnet_train.py:250-251: int16 / 32768)."""
+    from scipy.io import wavfile
+    fs, x = wavfile.read(path)
+    return fs, np.array(x, dtype=np.float32) / 32768
+
+
 def _h5py():
     try:
         import h5py
         return h5py
-    except ImportError as e:     # not installed in the build image; the corpus scripts that need it are out of scope
+    except ImportError as e:     # not installed in the build image
         raise ImportError("h5py is required for the reference's .h5 feature files (utils.py:43-92); "
-                          "pass arrays to decode_generator / train_generator instead") from e
+                          "use feature_format 'npy' or pass arrays to decode_generator / train_generator instead") from e
 
 
 def read_hdf5(hdf5_name, hdf5_path):
@@ -191,3 +234,96 @@ def write_hdf5(hdf5_name, hdf5_path, write_data, is_overwrite=True):
                 raise KeyError("Dataset in hdf5 file already exists. (%s)" % hdf5_path)
             del f[hdf5_path]
         f.create_dataset(hdf5_path, data=write_data)
+
+
+def read_features(path, feature_type="world"):
+    """(F, n_aux) acoustic features of one utterance: the `/world` dataset of an .h5 file (layout
+    [uv, cont_f0, mcep.., codeap..], feature_extract.py:337-343), or a plain .npy array of the same layout."""
+    if path.endswith(".npy"):
+        return np.load(path)
+    return read_hdf5(path, "/%s" % feature_type)
+
+
+class FeatureScaler:
+    """The StandardScaler the task scripts rebuild from the stats file (qpnet_train.py:433-440): transform = (x - mean) / scale."""
+
+    def __init__(self, mean, scale):
+        self.mean_ = np.asarray(mean, dtype=np.float64)
+        self.scale_ = np.asarray(scale, dtype=np.float64)
+        self.n_features_in_ = self.mean_.shape[0]
+
+    def transform(self, x):
+        return (np.asarray(x) - self.mean_) / self.scale_
+
+    __call__ = transform
+
+
+def read_scaler_stats(path, feature_type="world"):
+    """`/world/mean`, `/world/scale` of the stats file calc_stats.py writes (:19-37; the uv dimension has mean 0 / scale 1),
+    or an .npz with arrays `mean` and `scale`."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        return FeatureScaler(z["mean"], z["scale"])
+    return FeatureScaler(read_hdf5(path, "/%s/mean" % feature_type), read_hdf5(path, "/%s/scale" % feature_type))
+
+
+def calc_stats(feature_arrays):
+    """mean / scale over a list of (F, n_aux) feature arrays the way calc_stats.py does: population statistics of every
+    dimension but the first (uv), which keeps mean 0 / scale 1; zero variance -> scale 1 (sklearn's rule)."""
+    n, s1, s2 = 0, 0.0, 0.0
+    for f in feature_arrays:
+        f = np.asarray(f, dtype=np.float64)[:, 1:]
+        n += f.shape[0]; s1 = s1 + f.sum(0); s2 = s2 + (f * f).sum(0)
+    mean = s1 / n
+    var = np.maximum(s2 / n - mean * mean, 0.0)
+    scale = np.sqrt(var)
+    scale[scale < 10 * np.finfo(np.float64).eps] = 1.0
+    return FeatureScaler(np.concatenate([[0.0], mean]), np.concatenate([[1.0], scale]))
+
+
+def save_model_conf(path, args):
+    """the trainer pickles its argparse.Namespace as the model config (qpnet_train.py:389)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)) or ".", exist_ok=True)
+    torch.save(args, path)
+    return path
+
+
+def load_model_conf(path):
+    """model.conf = a pickled argparse.Namespace (read with a bare torch.load at qpnet_decode.py:245; torch >= 2.6 needs
+    weights_only=False for it).  Returns the Namespace."""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
+_MODEL_KEYS = ("n_quantize", "n_aux", "n_resch", "n_skipch", "dilationF_depth", "dilationF_repeat",
+               "dilationA_depth", "dilationA_repeat", "kernel_size", "upsampling_factor")
+
+
+def model_kwargs(conf):
+    """QPNet constructor kwargs out of a model config Namespace (qpnet_decode.py:275-285)."""
+    return {k: getattr(conf, k) for k in _MODEL_KEYS}
+
+
+def read_txt(path):
+    """one entry per line (utils.read_txt, utils.py:151-162)."""
+    with open(path) as f:
+        return [ln.strip() for ln in f if ln.strip()]
+
+
+def find_files(directory, pattern="*.wav"):
+    import fnmatch
+    out = []
+    for root, _, names in os.walk(directory, followlinks=True):
+        out += [os.path.join(root, n) for n in fnmatch.filter(names, pattern)]
+    return sorted(out)
+
+
+def file_lists(waveforms, feats, feature_format="h5"):
+    """(wav_list, feat_list) from a directory pair or a pair of list files (qpnet_train.py:442-455)."""
+    if os.path.isdir(waveforms):
+        wavs = find_files(waveforms, "*.wav")
+        return wavs, [os.path.join(feats, os.path.basename(w).replace(".wav", "." + feature_format)) for w in wavs]
+    if os.path.isfile(waveforms):
+        wavs, fts = read_txt(waveforms), read_txt(feats)
+        assert len(wavs) == len(fts)
+        return wavs, fts
+    raise FileNotFoundError("--waveforms should be directory or list: %s" % waveforms)

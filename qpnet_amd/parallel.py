@@ -17,18 +17,28 @@ def shard_indices(n_items, rank, world_size):
     return list(range(rank, n_items, world_size))
 
 
-def allreduce_mean_gradient(gflat, n_rows_local, group=None):
-    """In place: g <- sum_r(n_r * g_r) / sum_r(n_r), i.e. the gradient of the mean CE over ALL ranks' rows.
+TRAILER = 4      # floats behind the gradient in the exchange buffer: {row count, 0, 0, 0} (keeps the payload 16-byte sized)
 
-    `gflat` is the rank's gradient of ITS mean loss (what qpn_train_backward returns), `n_rows_local` = B*BL.
-    One all-reduce of n_params+1 floats."""
+
+def exchange(buf, group=None):
+    """THE gradient exchange of a step: one all-reduce(SUM) of the flat buffer [n_r * g_r | n_r, 0, 0, 0] (RCCL over xGMI on
+    MI355X; 2.0 MB for the paper-size model, so one unbucketed call).  In the fused step the HIP kernels produce the weighted
+    buffer (qpn_train_backward_ex) and consume the sum (qpn_adam_step_ex divides by the summed row count on the device)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
+def allreduce_mean_gradient(gflat, n_rows_local, group=None):
+    """In place: g <- sum_r(n_r * g_r) / sum_r(n_r), i.e. the gradient of the mean CE over ALL ranks' rows, for callers
+    that hold a plain gradient tensor (the reference-style autograd loop).  Same exchange, weighting done with torch ops."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return gflat
-    buf = torch.empty(gflat.numel() + 1, dtype=gflat.dtype, device=gflat.device)
-    buf[:-1] = gflat * float(n_rows_local)
-    buf[-1] = float(n_rows_local)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    gflat.copy_(buf[:-1] / buf[-1])
+    buf = torch.zeros(gflat.numel() + TRAILER, dtype=gflat.dtype, device=gflat.device)
+    buf[:gflat.numel()] = gflat * float(n_rows_local)
+    buf[gflat.numel()] = float(n_rows_local)
+    exchange(buf, group)
+    gflat.copy_(buf[:gflat.numel()] / buf[gflat.numel()])
     return gflat
 
 

@@ -13,6 +13,7 @@ without the built library or without a GPU raises.
 """
 import logging
 import sys
+import time
 
 import numpy as np
 import torch
@@ -199,6 +200,7 @@ class QPNet(nn.Module):
         seed = self.sampling_seed if self.sampling_seed is not None else (torch.initial_seed() + self._n_generate_calls) % (1 << 64)
         self._n_generate_calls += 1
         self.last_sampling_seed = seed
+        t_start = time.time()
         with torch.cuda.device(dev):
             _lib.check(L.qpn_set_weights(hd, flat.data_ptr(), flat.numel(), stream))
             arr = (C.c_int64 * B)(*ns)
@@ -207,6 +209,13 @@ class QPNet(nn.Module):
                                     arr, maxd, 1 if mode == "sampling" else 0, seed, None, out.data_ptr(), None, stream))
             self.last_decode_kernel_ms = float(L.qpn_last_decode_kernel_ms(hd))
         out_np = out.cpu().numpy()
+        if intervals is not None and intervals > 0 and max_n > 0:
+            # progress lines of the reference loop (qpnet.py:519-524).  The whole call is one persistent launch, so they are
+            # written once it has returned, with the measured mean time per sample (the estimate the reference prints is
+            # the same quantity taken over the last `intervals` samples)
+            per = (time.time() - t_start) / max_n
+            for i in range(intervals, max_n + 1, intervals):
+                logging.info("%d/%d estimated time = %.3f sec (%.3f sec / sample)" % (i, max_n, (max_n - i) * per, per))
         # completion order + in-place consumption of n_samples_list (reference qpnet.py:527-557)
         order = sorted(range(B), key=lambda i: ns[i])
         result = [out_np[i, :ns[i]].copy() for i in order]

@@ -1,7 +1,13 @@
 """Training-side plumbing over the C ABI: autograd.Function for QPNet.forward and a fused
 train step (forward + CE + backward + Adam) that never leaves libqpnet_hip for compute.
 
-torch is used for device buffers, streams and the autograd graph only."""
+torch is used for device buffers, streams and the autograd graph only.
+
+One outstanding forward per model: the activations backward needs live in the native handle's
+workspace (sized for 288 GB of HBM: whole-chunk activations stay resident), so a second forward of
+the same model before the first one's backward would replace them.  Every forward gets a generation
+number from the library; a backward whose forward is no longer the current one raises instead of
+using the wrong activations."""
 import ctypes as C
 
 import numpy as np
@@ -33,7 +39,6 @@ def ensure_flat(model, dev):
             p.data = flat[o:o + n].view(p.shape)
             o += n
         model._flat = flat
-        model._gflat = None
     return model._flat
 
 
@@ -44,6 +49,21 @@ def _split_like(model, gflat):
         out.append(gflat[o:o + n].view(p.shape))
         o += n
     return out
+
+
+def _flat_grad_of(params):
+    """The flat gradient buffer the parameters' .grad tensors are consecutive views of, or None."""
+    if not params or params[0].grad is None:
+        return None
+    base = params[0].grad.data_ptr()
+    o = 0
+    for p in params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * o:
+            return None
+        o += p.numel()
+    g0 = params[0].grad
+    return torch.as_strided(g0, (o,), (1,), g0.storage_offset()) if g0.untyped_storage().nbytes() >= 4 * (g0.storage_offset() + o) else None
 
 
 class QPNetFunction(torch.autograd.Function):
@@ -62,6 +82,7 @@ class QPNetFunction(torch.autograd.Function):
                                            x.data_ptr(), h.data_ptr(), d.data_ptr(), logits.data_ptr(), stream))
             _lib.check(L.qpn_train_status(hd, stream))       # reference asserts on the gather bounds (qpnet.py:294)
         ctx.model = model
+        ctx.generation = int(L.qpn_train_generation(hd))
         ctx.keep = (x, h, d)                                  # inputs must outlive backward (the workspace points into them)
         return logits
 
@@ -70,16 +91,18 @@ class QPNetFunction(torch.autograd.Function):
         model = ctx.model
         dev = dlogits.device
         L, hd = model._native(dev)
+        if int(L.qpn_train_generation(hd)) != ctx.generation:
+            raise RuntimeError("qpnet_amd: backward of a forward whose activations have been replaced by a later forward of the "
+                               "same model (one outstanding forward per model; run validation forwards after backward)")
         flat = model._flat
-        if getattr(model, "_gflat", None) is None:
-            model._gflat = torch.empty_like(flat)
-        g = model._gflat
+        # a FRESH buffer per backward: autograd keeps (or accumulates into) the views it is handed, so they must not
+        # alias memory a later backward writes
+        g = torch.empty_like(flat)
         dl = dlogits.contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _lib.check(L.qpn_train_backward(hd, dl.data_ptr(), g.data_ptr(), stream))
-        grads = _split_like(model, g)
-        return (None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None) + tuple(_split_like(model, g))
 
 
 def qpnet_forward(model, x, h, dilated_factors, blength):
@@ -97,13 +120,58 @@ def qpnet_forward(model, x, h, dilated_factors, blength):
     return QPNetFunction.apply(model, x, h, d, BL, maxd, *list(model.parameters()))
 
 
+# ---------------------------------------------------------------- Adam state in torch.optim.Adam's state_dict layout
+_ADAM_GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+
+
+def adam_state_to_torch(model, m, v, steps, hyper):
+    """{"state": {i: {"step","exp_avg","exp_avg_sq"}}, "param_groups": [...]}: what torch.optim.Adam(model.parameters())
+    .state_dict() holds after `steps` steps, built from the flat moment buffers (reference checkpoints store exactly this,
+    src/bin/qpnet_train.py:346-352), so either side can resume the other's checkpoint."""
+    params = list(model.parameters())
+    state, o = {}, 0
+    for i, p in enumerate(params):
+        n = p.numel()
+        if steps > 0 and m is not None:
+            state[i] = {"step": torch.tensor(float(steps)), "exp_avg": m[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": v[o:o + n].view(p.shape).clone()}
+        o += n
+    group = dict(lr=hyper["lr"], betas=tuple(hyper["betas"]), eps=hyper["eps"], weight_decay=hyper["weight_decay"])
+    group.update(_ADAM_GROUP_DEFAULTS)
+    group["params"] = list(range(len(params)))
+    return {"state": state, "param_groups": [group]}
+
+
+def adam_state_from_torch(model, sd, flat):
+    """inverse of adam_state_to_torch; also accepts the previous round's {"flat_adam": ...} format."""
+    if "flat_adam" in sd:
+        st = sd["flat_adam"]
+        return st["exp_avg"].to(flat.device).clone(), st["exp_avg_sq"].to(flat.device).clone(), int(st["step"]), dict(sd["param_groups"][0])
+    params = list(model.parameters())
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    steps, o = 0, 0
+    index = sd["param_groups"][0].get("params", list(range(len(params))))
+    for pos, p in enumerate(params):
+        n = p.numel()
+        st = sd["state"].get(index[pos]) if pos < len(index) else None
+        if st is not None:
+            m[o:o + n] = st["exp_avg"].reshape(-1).to(flat.device, torch.float32)
+            v[o:o + n] = st["exp_avg_sq"].reshape(-1).to(flat.device, torch.float32)
+            steps = max(steps, int(float(st["step"])))
+        o += n
+    hyper = {k: sd["param_groups"][0][k] for k in ("lr", "betas", "eps", "weight_decay") if k in sd["param_groups"][0]}
+    if sd["param_groups"][0].get("amsgrad"):
+        raise ValueError("amsgrad Adam state cannot be resumed by the fused Adam kernel")
+    return m, v, steps, hyper
+
+
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) as ONE kernel over the model's flat parameter
     buffer -- a one-line swap for `torch.optim.Adam(model.parameters(), lr=...)` in the reference loop
     (src/bin/qpnet_train.py:426-429,531), whose ~50-tensor foreach update costs 0.9 ms per step on this GPU.
-    Gradients are read from `p.grad` (the autograd backward hands out views of one flat gradient buffer, so no gather
-    happens on the usual path).  State (`exp_avg`, `exp_avg_sq`, `step`) lives in flat tensors; its state_dict is its own
-    format, not torch.optim.Adam's."""
+    Gradients are read from `p.grad`: when they are consecutive views of one flat buffer (what the autograd backward hands
+    out) no gather happens.  state_dict()/load_state_dict() use torch.optim.Adam's own layout, so checkpoints written by
+    the reference trainer resume here and vice versa."""
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.model = model
@@ -121,19 +189,14 @@ class FlatAdam(torch.optim.Optimizer):
         dev = flat.device
         L, hd = model._native(dev)
         params = list(model.parameters())
-        g = getattr(model, "_gflat", None)
-        ok = g is not None
-        if ok:
-            o = 0
-            for p in params:
-                if p.grad is None or p.grad.data_ptr() != g.data_ptr() + 4 * o:
-                    ok = False
-                    break
-                o += p.numel()
-        if not ok:                                   # grads came from elsewhere (or some are None): gather them
+        g = _flat_grad_of(params)
+        if g is None:                                # grads came from elsewhere (or some are None): gather them
             g = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
         if self._m is None or self._m.numel() != flat.numel() or self._m.device != dev:
+            m0, v0 = self._m, self._v
             self._m = torch.zeros_like(flat); self._v = torch.zeros_like(flat)
+            if m0 is not None and m0.numel() == flat.numel():
+                self._m.copy_(m0); self._v.copy_(v0)
         grp = self.param_groups[0]
         self._steps += 1
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -142,15 +205,21 @@ class FlatAdam(torch.optim.Optimizer):
                                        self._steps, grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], stream))
         return loss
 
+    def _hyper(self):
+        return {k: self.param_groups[0][k] for k in ("lr", "betas", "eps", "weight_decay")}
+
     def state_dict(self):
-        return {"flat_adam": {"exp_avg": self._m, "exp_avg_sq": self._v, "step": self._steps}, "param_groups": [
-            {k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        return adam_state_to_torch(self.model, self._m, self._v, self._steps, self._hyper())
 
     def load_state_dict(self, sd):
-        st = sd["flat_adam"]
-        self._m, self._v, self._steps = st["exp_avg"], st["exp_avg_sq"], int(st["step"])
-        for k, v in sd["param_groups"][0].items():
-            self.param_groups[0][k] = v
+        params = list(self.model.parameters())
+        flat = getattr(self.model, "_flat", None)
+        if flat is None:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        self._m, self._v, self._steps, hyper = adam_state_from_torch(self.model, sd, flat)
+        for k, v in hyper.items():
+            if k != "params":
+                self.param_groups[0][k] = v
 
 
 class FusedTrainer:
@@ -158,44 +227,114 @@ class FusedTrainer:
 
     Mirrors the loop body of the reference trainer (src/bin/qpnet_train.py:517-531) with
     torch.optim.Adam(lr=1e-4, betas=(0.9,0.999), eps=1e-8, weight_decay=0) semantics.
-    With world_size > 1 the flat gradient is all-reduced (one RCCL call) before the update."""
+    With world_size > 1 every rank's gradient is weighted by its row count inside the gradient-reduction kernel, summed
+    over ranks with ONE RCCL all-reduce of the flat buffer (the row counts ride in its last element) and divided by the
+    global row count inside the Adam kernel: the update is the gradient of the mean CE over ALL ranks' rows, with no
+    extra elementwise launch or allocation in the step.
+    state_dict()/load_state_dict() use torch.optim.Adam's layout (resume of reference-made checkpoints and vice versa)."""
+
+    STATUS_EVERY = 100          # steps between checks of the device-side status word (bad taps / targets; reference asserts)
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.step_count = 0
-        self.m = self.v = None
+        self.m = self.v = self.g = None
         self.pg, self.world = process_group, world_size
+        self._logits = None
+
+    def _buffers(self, flat):
+        if self.m is None or self.m.device != flat.device or self.m.numel() != flat.numel():
+            m0, v0 = self.m, self.v
+            self.m = torch.zeros_like(flat); self.v = torch.zeros_like(flat)
+            if m0 is not None and m0.numel() == flat.numel():
+                self.m.copy_(m0); self.v.copy_(v0)
+        if self.g is None or self.g.device != flat.device or self.g.numel() != flat.numel() + 4:
+            self.g = torch.empty(flat.numel() + 4, dtype=torch.float32, device=flat.device)   # gradient + trailer (row count)
+
+    @staticmethod
+    def _norm(t, dtype, dev):
+        return t if (t.dtype == dtype and t.device == dev and t.is_contiguous()) else t.to(dev, dtype).contiguous()
 
     def step(self, x, h, t, d, blength, want_loss=True, maxd=None):
         """One optimisation step.  maxd = ceil(max(d)) of the chunk; a loader that built d on the host (the reference's
-        train_generator does, qpnet_train.py:268-272) passes it in, otherwise it is read back from the device (one sync)."""
+        train_generator does, qpnet_train.py:268-272) passes it in, otherwise it is read back from the device (one sync).
+        Inputs are normalised like QPNet.forward does (int64 samples/targets, float32 features/factors, contiguous)."""
         model = self.model
         dev = x.device
+        if dev.type != "cuda":
+            raise RuntimeError("qpnet_amd.FusedTrainer runs on an AMD GPU only (tensors are on %s)" % dev)
         L, hd = model._native(dev)
         flat = ensure_flat(model, dev)
-        if self.m is None:
-            self.m = torch.zeros_like(flat); self.v = torch.zeros_like(flat)
-            self.g = torch.empty_like(flat)
+        self._buffers(flat)
+        x = self._norm(x, torch.int64, dev); t = self._norm(t, torch.int64, dev)
+        h = self._norm(h, torch.float32, dev); d = self._norm(d, torch.float32, dev)
+        assert x.dim() == 2 and t.shape[0] == x.shape[0] and h.dim() == 3 and h.shape[1] == model.n_aux and d.dim() == 2
         BL = int(blength[0])
         if maxd is None:
             maxd = int(torch.max(d.ceil()))
         B, T = x.shape
-        if getattr(self, "_logits", None) is None or self._logits.shape != (B, BL, model.n_quantize):
+        if self._logits is None or self._logits.shape != (B, BL, model.n_quantize) or self._logits.device != dev:
             self._logits = torch.empty((B, BL, model.n_quantize), dtype=torch.float32, device=dev)
             self._dlogits = torch.empty_like(self._logits)
         stream = torch.cuda.current_stream(dev).cuda_stream
         loss = C.c_double(0.0)
+        multi = self.world > 1
         with torch.cuda.device(dev):
             _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                            x.data_ptr(), h.data_ptr(), d.data_ptr(), self._logits.data_ptr(), stream))
             _lib.check(L.qpn_ce_loss(hd, self._logits.data_ptr(), t.data_ptr(), t.shape[1], B, BL,
                                      self._dlogits.data_ptr(), C.byref(loss) if want_loss else None, stream))
-            _lib.check(L.qpn_train_backward(hd, self._dlogits.data_ptr(), self.g.data_ptr(), stream))
-            if self.world > 1:
-                from .parallel import allreduce_mean_gradient
-                allreduce_mean_gradient(self.g, B * BL, group=self.pg)
+            if multi:
+                # g <- n_r * grad_r with n_r appended; SUM over ranks; Adam divides by the summed row count on the device
+                _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 1, stream))
+                from .parallel import exchange
+                exchange(self.g, self.pg)
+                L.qpn_train_profile_mark(hd, 9, stream)      # QPN_PG_ALLREDUCE (no-op unless a profile is being taken)
+            else:
+                _lib.check(L.qpn_train_backward(hd, self._dlogits.data_ptr(), self.g.data_ptr(), stream))
             self.step_count += 1
-            _lib.check(L.qpn_adam_step(hd, flat.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), flat.numel(),
-                                       self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, stream))
+            _lib.check(L.qpn_adam_step_ex(hd, flat.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), flat.numel(),
+                                          self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                          self.g.data_ptr() + 4 * flat.numel() if multi else None, stream))
+            if want_loss or self.step_count % self.STATUS_EVERY == 1:
+                _lib.check(L.qpn_train_status(hd, stream))
         return loss.value if want_loss else None
+
+    def forward_loss(self, x, h, t, d, blength, maxd=None):
+        """forward + mean CE only (validation, reference qpnet_validate.py:409-430)."""
+        model = self.model
+        dev = x.device
+        L, hd = model._native(dev)
+        flat = ensure_flat(model, dev)
+        x = self._norm(x, torch.int64, dev); t = self._norm(t, torch.int64, dev)
+        h = self._norm(h, torch.float32, dev); d = self._norm(d, torch.float32, dev)
+        BL = int(blength[0])
+        if maxd is None:
+            maxd = int(torch.max(d.ceil()))
+        B, T = x.shape
+        logits = torch.empty((B, BL, model.n_quantize), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        loss = C.c_double(0.0)
+        with torch.cuda.device(dev):
+            _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
+                                           x.data_ptr(), h.data_ptr(), d.data_ptr(), logits.data_ptr(), stream))
+            _lib.check(L.qpn_ce_loss(hd, logits.data_ptr(), t.data_ptr(), t.shape[1], B, BL, None, C.byref(loss), stream))
+            _lib.check(L.qpn_train_status(hd, stream))
+        return loss.value
+
+    # ---- optimizer-state interface (checkpoints: loaders.save_checkpoint(dir, model, trainer, it))
+    def _hyper(self):
+        return dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd)
+
+    def state_dict(self):
+        return adam_state_to_torch(self.model, self.m, self.v, self.step_count, self._hyper())
+
+    def load_state_dict(self, sd):
+        params = list(self.model.parameters())
+        flat = getattr(self.model, "_flat", None)
+        if flat is None or flat.device != params[0].device:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        self.m, self.v, self.step_count, hyper = adam_state_from_torch(self.model, sd, flat)
+        self.lr = hyper.get("lr", self.lr); self.betas = tuple(hyper.get("betas", self.betas))
+        self.eps = hyper.get("eps", self.eps); self.wd = hyper.get("weight_decay", self.wd)

@@ -6,7 +6,7 @@ data (seeds, small inputs, expected outputs) and are what travels to the GPU box
 Inputs are regenerated from seeds by qpnet_amd.synth (np.random.RandomState: frozen streams),
 so fixtures store only what cannot be regenerated: the reference's outputs.
 
-    python tests/golden/make_golden.py [--only decode|forward|train|kat]
+    python tests/golden/make_golden.py [--only decode|decode2|forward|train|kat]
 """
 import argparse
 import os
@@ -27,7 +27,7 @@ import qpnet as ref  # noqa: E402  (the reference module)
 from qpnet_amd import synth  # noqa: E402
 from qpnet_amd.config import TINY, PAPER, QPNetConfig  # noqa: E402
 sys.path.insert(0, HERE)
-from cases import DECODE_CASES, FORWARD_CASES, TRAIN_CASES  # noqa: E402
+from cases import DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, decode2_inputs  # noqa: E402
 
 torch.set_num_threads(8)
 torch.set_grad_enabled(False)
@@ -101,6 +101,25 @@ def gen_decode():
 
 
 
+def gen_decode2():
+    out = {}
+    for case in DECODE_CASES2:
+        cfg, name = case["cfg"], case["name"]
+        m = build_ref(cfg, synth.make_weights(cfg, case["wseed"]))
+        bx, bh, bd, ns = decode2_inputs(case)
+        bd_ = torch.from_numpy(bd).float() if case["extra"] else bd
+        nlist = list(ns)
+        streams = m.batch_fast_generate(torch.from_numpy(bx).long(), torch.from_numpy(bh).float(), nlist, bd_, intervals=None,
+                                        mode="argmax", extra_memory=case["extra"])
+        for i, s in enumerate(streams):
+            out["%s_out%d" % (name, i)] = np.asarray(s).astype(np.int16)
+        out[name + "_nleft"] = np.array(nlist, dtype=np.int64)
+        out[name + "_maxd"] = np.int64(np.nanmax(np.ceil(bd)))
+        print(name, [len(s) for s in streams], "maxd", out[name + "_maxd"], "n_samples_list after:", nlist)
+    np.savez_compressed(os.path.join(HERE, "decode2.npz"), **out)
+    print("decode2.npz written")
+
+
 def gen_forward():
     out = {}
     for name, cfg, wseed, dseed, bl, ml in FORWARD_CASES:
@@ -162,6 +181,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = [a.only] if a.only else ["kat", "decode", "forward", "train"]
+    todo = [a.only] if a.only else ["kat", "decode", "decode2", "forward", "train"]
     for t in todo:
-        {"kat": gen_kat, "decode": gen_decode, "forward": gen_forward, "train": gen_train}[t]()
+        {"kat": gen_kat, "decode": gen_decode, "decode2": gen_decode2, "forward": gen_forward, "train": gen_train}[t]()

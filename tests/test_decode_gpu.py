@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from cases import DECODE_CASES
+from cases import DECODE_CASES, DECODE_CASES2, decode2_inputs
 from qpnet_amd import synth
 import util
 
@@ -138,3 +138,81 @@ def test_other_geometries_bitwise_vs_oracle(geo, cuda, oracle):
     x, h, d, n = synth.decode_inputs(cfg, 5, 11, 1.5)
     y = m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode="argmax")[0]
     np.testing.assert_array_equal(y, oracle.decode(cfg, flat, h, d, x, n)["samples"])
+
+
+@pytest.mark.parametrize("case", DECODE_CASES2, ids=[c["name"] for c in DECODE_CASES2])
+def test_decode_worst_case_pitch_and_long_seeds(case, cuda, golden_dir, oracle):
+    """Reference streams at the corpus pitch floor with 0.5x F0 scaling (maxd ~ 123: the deepest rings the path meets,
+    > 5 k samples) and with seeds of several samples per row (n_x > 1): bit-exact vs the reference and the oracle."""
+    import torch
+    cfg, name, extra = case["cfg"], case["name"], case["extra"]
+    g = np.load(golden_dir + "/decode2.npz")
+    flat = synth.make_weights(cfg, case["wseed"])
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = decode2_inputs(case)
+    assert int(np.nanmax(np.ceil(bd))) == int(g[name + "_maxd"])
+    nlist = list(ns)
+    d_arg = torch.from_numpy(bd).float().to(cuda) if extra else bd
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, d_arg, mode="argmax", extra_memory=extra)
+    assert nlist == list(g[name + "_nleft"])
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd.astype(np.float32) if extra else bd)
+    for i, s in enumerate(outs):
+        ref = g["%s_out%d" % (name, i)].astype(np.int64)
+        np.testing.assert_array_equal(s, o_outs[i], err_msg="HIP vs oracle, row %d" % i)
+        np.testing.assert_array_equal(s, ref, err_msg="HIP vs reference stream, row %d" % i)
+
+
+def test_decode_more_rows_than_cus(cuda, oracle):
+    """B = 300 utterances in one call (more workgroups than the chip has CUs: the tail waits for a free CU):
+    unequal lengths, every row equals its single-row oracle stream, completion order kept."""
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    flat = synth.make_weights(cfg, 5)
+    m = util.build_model(cfg, flat, cuda)
+    utts = [(300 + (b % 7), 3 + (b % 3), 1.0) for b in range(300)]
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    assert [len(o) for o in outs] == sorted(ns)
+    order = sorted(range(300), key=lambda i: ns[i])
+    maxd = int(np.nanmax(np.ceil(bd)))
+    cache = {}
+    for pos in (0, 1, 57, 150, 151, 298, 299):
+        i = order[pos]
+        key = utts[i]
+        if key not in cache:
+            cache[key] = oracle.decode(cfg, flat, bh[i], bd[i], bx[i], ns[i], maxd=maxd)["samples"]
+        np.testing.assert_array_equal(outs[pos], cache[key])
+    # rows with identical inputs give identical streams wherever they ran
+    for pos in range(300):
+        i = order[pos]
+        j = order.index(next(k for k in order if utts[k] == utts[i]))
+        np.testing.assert_array_equal(outs[pos], outs[j])
+
+
+@pytest.mark.parametrize("tag", ["h", "1", "x"])
+def test_dilated_index_exports_vs_reference_kat(tag, cuda, golden_dir):
+    """qpn_dilated_index_{train,gen_f32,gen_f64} (the exported _dilated_index / _generate_dilated_index) on the GPU
+    against the reference's own index tensors, incl. the |idx| > 16384 float32 rounding case."""
+    import torch
+    from qpnet_amd import _lib
+    L = _lib.lib()
+    g = np.load(golden_dir + "/kat.npz")
+    d64 = g["didx_d64_" + tag]
+    d32 = d64.astype(np.float32)
+    B, n = d32.shape
+    t32 = torch.from_numpy(d32).to(cuda); t64 = torch.from_numpy(d64).to(cuda)
+    for k in range(4):
+        o = torch.empty((B, n), dtype=torch.int64, device=cuda)
+        _lib.check(L.qpn_dilated_index_train(t32.data_ptr(), B, n, 2 ** k, o.data_ptr(), None))
+        np.testing.assert_array_equal(o.cpu().numpy(), g["didx_train_f32_%s_%d" % (tag, k)])
+        _lib.check(L.qpn_dilated_index_gen_f32(t32.data_ptr(), B * n, 2 ** k, o.data_ptr(), None))
+        np.testing.assert_array_equal(o.cpu().numpy(), g["didx_gen_f32_%s_%d" % (tag, k)])
+        o32 = torch.empty((B, n), dtype=torch.int32, device=cuda)
+        _lib.check(L.qpn_dilated_index_gen_f64(t64.data_ptr(), B * n, 2 ** k, o32.data_ptr(), None))
+        np.testing.assert_array_equal(o32.cpu().numpy(), g["didx_gen_f64_%s_%d" % (tag, k)])
+    if tag == "h":
+        dl = torch.from_numpy(g["didx_long_d32"]).to(cuda)
+        o = torch.empty(dl.shape, dtype=torch.int64, device=cuda)
+        _lib.check(L.qpn_dilated_index_train(dl.data_ptr(), dl.shape[0], dl.shape[1], 8, o.data_ptr(), None))
+        np.testing.assert_array_equal(o.cpu().numpy(), g["didx_long_train_f32_3"])

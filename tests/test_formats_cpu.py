@@ -1,0 +1,126 @@
+"""CPU: on-disk formats and optimizer-state layout either side of the hot path: HDF5 wrappers
+(through a stand-in h5py module), scaler statistics, pickled model.conf, Adam state in torch.optim.Adam's layout, the
+weighted gradient-exchange protocol."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from qpnet_amd import loaders
+from qpnet_amd.config import TINY
+
+STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
+
+
+@pytest.fixture
+def h5stub(monkeypatch):
+    try:
+        import h5py  # noqa: F401  (a real h5py, if present, is what gets tested)
+    except ImportError:
+        monkeypatch.syspath_prepend(STUBS)
+        monkeypatch.delitem(sys.modules, "h5py", raising=False)
+    yield
+    sys.modules.pop("h5py", None) if "stubs" in getattr(sys.modules.get("h5py"), "__file__", "") else None
+
+
+def test_hdf5_roundtrip_and_errors(h5stub, tmp_path):
+    f = str(tmp_path / "sub" / "a.h5")
+    w = np.arange(12, dtype=np.float32).reshape(4, 3)
+    loaders.write_hdf5(f, "/world", w)
+    np.testing.assert_array_equal(loaders.read_hdf5(f, "/world"), w)
+    loaders.write_hdf5(f, "/world", w * 2)                                  # overwrite is the default (utils.py:94-98)
+    np.testing.assert_array_equal(loaders.read_hdf5(f, "/world"), w * 2)
+    with pytest.raises(KeyError):
+        loaders.write_hdf5(f, "/world", w, is_overwrite=False)
+    with pytest.raises(KeyError):
+        loaders.read_hdf5(f, "/nothing")
+    with pytest.raises(FileNotFoundError):
+        loaders.read_hdf5(str(tmp_path / "missing.h5"), "/world")
+    np.testing.assert_array_equal(loaders.read_features(f), w * 2)
+    np.save(str(tmp_path / "b.npy"), w)
+    np.testing.assert_array_equal(loaders.read_features(str(tmp_path / "b.npy")), w)
+
+
+def test_scaler_stats_like_calc_stats(h5stub, tmp_path):
+    """calc_stats.py:19-37: StandardScaler.partial_fit over dims 1.., uv dim keeps mean 0 / scale 1; read back the way
+    the task scripts rebuild their scaler (qpnet_train.py:433-436)."""
+    from sklearn.preprocessing import StandardScaler
+    rs = np.random.RandomState(0)
+    feats = [rs.randn(30 + 7 * i, 39) * 3 + 1 for i in range(4)]
+    sc = StandardScaler()
+    for f in feats:
+        sc.partial_fit(f[:, 1:])
+    mine = loaders.calc_stats(feats)
+    np.testing.assert_allclose(mine.mean_[1:], sc.mean_, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(mine.scale_[1:], sc.scale_, rtol=1e-12)
+    assert mine.mean_[0] == 0.0 and mine.scale_[0] == 1.0
+    stats = str(tmp_path / "stats.h5")
+    loaders.write_hdf5(stats, "/world/mean", mine.mean_)
+    loaders.write_hdf5(stats, "/world/scale", mine.scale_)
+    back = loaders.read_scaler_stats(stats)
+    ref = StandardScaler(); ref.mean_ = mine.mean_; ref.scale_ = mine.scale_; ref.n_features_in_ = 39
+    np.testing.assert_allclose(back.transform(feats[0]), ref.transform(feats[0]), rtol=1e-14)
+    np.savez(str(tmp_path / "stats.npz"), mean=mine.mean_, scale=mine.scale_)
+    np.testing.assert_array_equal(loaders.read_scaler_stats(str(tmp_path / "stats.npz")).scale_, mine.scale_)
+
+
+def test_model_conf_is_a_pickled_namespace(tmp_path):
+    """the trainer torch.save()s its argparse.Namespace (qpnet_train.py:389); decode torch.load()s it (qpnet_decode.py:245)"""
+    ns = argparse.Namespace(feature_type="world", feature_format="h5", dense_factor=8, **TINY.kwargs())
+    path = loaders.save_model_conf(str(tmp_path / "model.conf"), ns)
+    conf = loaders.load_model_conf(path)
+    assert isinstance(conf, argparse.Namespace) and conf.n_resch == 32 and conf.feature_format == "h5"
+    assert loaders.model_kwargs(conf) == TINY.kwargs()
+
+
+def test_adam_state_uses_torch_adam_layout():
+    """FusedTrainer / FlatAdam checkpoints == torch.optim.Adam.state_dict(): a torch Adam loads ours and continues, and
+    ours loads a torch Adam's (what a reference-made checkpoint holds, qpnet_train.py:346-352)."""
+    from qpnet_amd.qpnet import QPNet
+    from qpnet_amd.train import adam_state_to_torch, adam_state_from_torch
+    torch.manual_seed(0)
+    m = QPNet(**TINY.kwargs())
+    n = sum(p.numel() for p in m.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    mom, var = torch.randn(n), torch.rand(n)
+    sd = adam_state_to_torch(m, mom, var, 7, dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt.load_state_dict(sd)                                  # torch accepts the layout ...
+    assert opt.param_groups[0]["lr"] == 2e-4
+    st = opt.state[next(iter(m.parameters()))]
+    assert float(st["step"]) == 7.0
+    for p in m.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()                                               # ... and can continue from it
+    sd2 = opt.state_dict()
+    m2, v2, steps, hyper = adam_state_from_torch(m, sd2, flat)
+    assert steps == 8 and hyper["lr"] == 2e-4
+    # one Adam step by hand on the flat buffers equals what torch did
+    g = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    np.testing.assert_allclose(m2.numpy(), (mom + (g - mom) * 0.1).numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(v2.numpy(), (var * 0.999 + 0.001 * g * g).numpy(), rtol=1e-6, atol=1e-7)
+    # a fresh torch Adam (no state yet) and an old-style int step both load
+    m3, v3, s3, _ = adam_state_from_torch(m, torch.optim.Adam(m.parameters()).state_dict(), flat)
+    assert s3 == 0 and float(m3.abs().max()) == 0.0
+    for k in sd2["state"]:
+        sd2["state"][k]["step"] = 8                          # PyTorch 1.3 stored python ints
+    assert adam_state_from_torch(m, sd2, flat)[2] == 8
+
+
+def test_weighted_exchange_protocol_single_process():
+    """[n_r g_r | n_r, 0, 0, 0] summed over ranks, divided by the summed count == gradient of the global mean loss."""
+    from qpnet_amd import parallel
+    rs = np.random.RandomState(1)
+    g = [torch.from_numpy(rs.randn(50).astype(np.float32)) for _ in range(3)]
+    n = [1200.0, 900.0, 1500.0]
+    bufs = []
+    for gi, ni in zip(g, n):
+        b = torch.zeros(50 + parallel.TRAILER); b[:50] = gi * ni; b[50] = ni
+        bufs.append(b)
+    tot = sum(bufs)
+    np.testing.assert_allclose((tot[:50] / tot[50]).numpy(), (sum(gi * ni for gi, ni in zip(g, n)) / sum(n)).numpy(), rtol=1e-6)
+    assert float(tot[51:].abs().max()) == 0.0
+    assert parallel.exchange(bufs[0]) is bufs[0]             # no process group: identity

@@ -3,7 +3,7 @@ reference (tests/golden/make_golden.py).  This is what pins the oracle (SURVEY.m
 import numpy as np
 import pytest
 
-from cases import DECODE_CASES, FORWARD_CASES
+from cases import DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, decode2_inputs
 from qpnet_amd import synth
 import util
 
@@ -124,3 +124,58 @@ def test_sampling_spec_is_softmax_distributed(oracle):
     chi2 = ((cnt[mask] - pm[mask] * draws.size) ** 2 / (pm[mask] * draws.size)).sum()
     dof = mask.sum() - 1
     assert chi2 < dof + 5 * np.sqrt(2 * dof), (chi2, dof)
+
+
+@pytest.mark.parametrize("case", DECODE_CASES2, ids=[c["name"] for c in DECODE_CASES2])
+def test_oracle_decode_worst_case_pitch_and_long_seeds(case, oracle, golden_dir):
+    """the oracle against reference streams at maxd ~ 123 (45 Hz x 0.5, > 5 k samples) and with n_x > 1 seeds"""
+    cfg, name, extra = case["cfg"], case["name"], case["extra"]
+    g = np.load(golden_dir + "/decode2.npz")
+    flat = synth.make_weights(cfg, case["wseed"])
+    bx, bh, bd, ns = decode2_inputs(case)
+    nlist = list(ns)
+    outs = oracle.batch_fast_generate(cfg, flat, bx, bh, nlist, bd.astype(np.float32) if extra else bd)
+    assert nlist == list(g[name + "_nleft"])
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64))
+
+
+def test_train_oracle_pinned_to_reference_autograd(golden_dir):
+    """oracle/train_oracle.py (numpy forward + hand-derived backward + Adam) against the fixture the imported reference
+    produced with torch autograd + torch.optim.Adam: loss of every step, the FULL gradient of step 0, final weights."""
+    from oracle import train_oracle as TO
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES[0]          # tiny: the fixture holds the whole gradient
+    g = np.load(golden_dir + "/train.npz")
+    flat = synth.make_weights(cfg, wseed)
+    opt = TO.Adam(flat.size)
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+        loss, grad = TO.train_step(cfg, flat, opt, x, h, t, d, b)
+        losses.append(loss)
+        if step == 0:
+            ref = g[name + "_grad0"]
+            assert np.abs(grad - ref).max() <= 2e-5 * np.abs(ref).max()
+            offs, _ = cfg.param_offsets()
+            norms = g[name + "_grad0_norms"]
+            for (k, (o, shp)), nr in zip(offs.items(), norms):
+                n = int(np.prod(shp))
+                assert abs(np.linalg.norm(grad[o:o + n]) - nr) <= 1e-4 * max(nr, 1e-6) + 1e-7, k
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)        # north_star tolerance
+    np.testing.assert_allclose(flat[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
+def test_train_oracle_paper_loss_and_grad_sample(golden_dir):
+    """paper-size: first-step loss and the strided gradient sample of the reference fixture"""
+    from oracle import train_oracle as TO
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES[1]
+    g = np.load(golden_dir + "/train.npz")
+    flat = synth.make_weights(cfg, wseed)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, 30000)
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    BL = int(b[0])
+    loss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss - g[name + "_losses"][0]) < 1e-4
+    grad = TO.backward(cfg, flat, caches, dl)
+    ref = g[name + "_grad0_sample"]
+    assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()

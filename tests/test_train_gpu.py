@@ -230,3 +230,113 @@ def test_flat_adam_matches_torch_adam(cuda):
             opt.step()
         ws.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy())
     np.testing.assert_allclose(ws[0], ws[1], atol=2e-6, rtol=0)
+
+
+def test_grad_accumulation_and_zero_grad_in_place(cuda):
+    """The autograd backward hands out views of a FRESH flat buffer: two backwards before a step accumulate (g1 + g2, not
+    2 * g2), and zero_grad(set_to_none=False) followed by a backward gives exactly the new gradient."""
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 21), cuda).train()
+    crit = torch.nn.CrossEntropyLoss()
+
+    def loss_of(seed):
+        x, h, t, d, b = synth.train_inputs(cfg, 500, seed, 30000)
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        BL = int(b[0])
+        return crit(m(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+
+    def flat_grad():
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    m.zero_grad(set_to_none=True); loss_of(71).backward(); g1 = flat_grad()
+    m.zero_grad(set_to_none=True); loss_of(72).backward(); g2 = flat_grad()
+    m.zero_grad(set_to_none=True); loss_of(71).backward(); loss_of(72).backward(); acc = flat_grad()
+    scale = float(g1.abs().max())
+    assert float((acc - (g1 + g2)).abs().max()) <= 1e-5 * scale
+    m.zero_grad(set_to_none=False); loss_of(72).backward(); again = flat_grad()
+    assert float((again - g2).abs().max()) <= 1e-5 * scale
+    # FlatAdam finds the flat buffer behind consecutive p.grad views, and gathers when they are not
+    from qpnet_amd.train import _flat_grad_of
+    params = list(m.parameters())
+    assert _flat_grad_of(params) is not None
+    params[3].grad = params[3].grad.clone()
+    assert _flat_grad_of(params) is None
+
+
+def test_backward_of_a_replaced_forward_raises(cuda):
+    """one outstanding forward per model: a validation forward between forward and backward must not silently feed the
+    wrong activations to the backward kernels"""
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 22), cuda).train()
+    x, h, t, d, b = synth.train_inputs(cfg, 400, 81, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    out = m(xt, ht, dt, bt)
+    with torch.no_grad():
+        m(xt, ht, dt, bt)                      # e.g. a validation pass
+    with pytest.raises(RuntimeError, match="one outstanding forward"):
+        out.sum().backward()
+    out2 = m(xt, ht, dt, bt)
+    out2.sum().backward()                      # the current forward is fine
+
+
+def test_fused_step_normalises_inputs_and_flags_bad_targets(cuda):
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import FusedTrainer
+    from qpnet_amd import _lib
+    cfg = TINY
+    flat = synth.make_weights(cfg, 23)
+    x, h, t, d, b = synth.train_inputs(cfg, 400, 91, 30000)
+    ma = util.build_model(cfg, flat, cuda).train(); mb = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    la = FusedTrainer(ma).step(xt, ht, tt, dt, bt)
+    # int32 samples, float64 factors, a non-contiguous feature tensor: same step
+    hT = ht.transpose(1, 2).contiguous().transpose(1, 2)
+    lb = FusedTrainer(mb).step(xt.int(), hT, tt.int(), dt.double(), bt)
+    assert la == lb
+    assert torch.equal(ma.flat_parameters(), mb.flat_parameters())
+    bad = tt.clone(); bad[0, -5] = cfg.n_quantize + 3
+    with pytest.raises(_lib.QpnError) as e:
+        FusedTrainer(ma).step(xt, ht, bad, dt, bt)
+    assert e.value.code == -4
+
+
+def test_trainer_checkpoint_resumes_like_torch_adam(cuda, tmp_path):
+    """FusedTrainer state -> checkpoint in the reference's {"model","optimizer","iterations"} format -> (a) a fresh
+    FusedTrainer continues bit-identically, (b) torch.optim.Adam on the drop-in module continues within fp32 noise."""
+    import torch
+    from qpnet_amd import loaders
+    from qpnet_amd.config import TINY
+    from qpnet_amd.qpnet import QPNet
+    from qpnet_amd.train import FusedTrainer
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 24), cuda).train()
+    tr = FusedTrainer(m, lr=1e-3)
+    data = [_to(cuda, *synth.train_inputs(cfg, 400, 95 + i, 30000)) for i in range(4)]
+    for i in range(2):
+        tr.step(*data[i])
+    path = loaders.save_checkpoint(str(tmp_path), m, tr, 2)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"model", "optimizer", "iterations"} and set(ck["optimizer"]) == {"state", "param_groups"}
+    ref_losses = [tr.step(*data[i]) for i in (2, 3)]
+    w_ref = m.flat_parameters().clone()
+    # (a)
+    m2 = QPNet(**cfg.kwargs()); tr2 = FusedTrainer(m2.to(cuda).train())
+    assert loaders.load_checkpoint(path, tr2.model, tr2) == 2 and tr2.lr == 1e-3 and tr2.step_count == 2
+    assert [tr2.step(*data[i]) for i in (2, 3)] == ref_losses
+    assert torch.equal(tr2.model.flat_parameters(), w_ref)
+    # (b)
+    m3 = QPNet(**cfg.kwargs()).to(cuda).train()
+    opt = torch.optim.Adam(m3.parameters(), lr=1e-4)
+    loaders.load_checkpoint(path, m3, opt)
+    crit = torch.nn.CrossEntropyLoss()
+    for i in (2, 3):
+        xt, ht, tt, dt, bt = data[i]
+        BL = int(bt[0])
+        loss = crit(m3(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+        opt.zero_grad(); loss.backward(); opt.step()
+    np.testing.assert_allclose(m3.flat_parameters().cpu().numpy(), w_ref.cpu().numpy(), atol=5e-6, rtol=0)
