@@ -48,6 +48,8 @@ def dist_setup(n_gpus):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or os.environ.get("QPN_BENCH_FORCE_PG"):
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(29500 + os.getpid() % 2000))):
+            os.environ.setdefault(k, v)                # QPN_BENCH_FORCE_PG: one-rank process group (rehearses the RCCL calls on one GPU)
         if os.environ.get("QPN_BENCH_ONE_GPU"):      # dev aid: rehearse the N>1 code path with every rank on GPU 0
             local = 0
         torch.cuda.set_device(local)
@@ -282,7 +284,7 @@ def run_train(args, rank, local, world):
     m = QPNet(**cfg.kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
     m = m.to(dev).train()
-    tr = FusedTrainer(m, lr=1e-4, world_size=world)
+    tr = FusedTrainer(m, lr=1e-4, world_size=2 if (world == 1 and os.environ.get("QPN_EXCHANGE_ALWAYS")) else world)
     if world > 1:
         from qpnet_amd import parallel
         from qpnet_amd.train import ensure_flat

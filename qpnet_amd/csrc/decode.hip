@@ -1034,7 +1034,8 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
     h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
     rc = build_program(h);
-    if (rc != QPN_OK) { delete h; return rc; }
+    h->decode_ok = rc == QPN_OK;
+    if (rc != QPN_OK) h->decode_err = g_err;            // reported by the decode entry points; the training path has its own limits
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
         // geometry-only handle: usable for qpn_param_count-style queries, every compute call fails loudly
@@ -1065,6 +1066,7 @@ static int need_device(qpn_handle* h) {
 
 extern "C" int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream_) {
     int rc = need_device(h); if (rc) return rc;
+    if (!h->decode_ok) { qpn_set_error("%s", h->decode_err.c_str()); return QPN_EINVAL; }
     if (!d_flat || (int64_t)n != h->g.n_params) { qpn_set_error("flat parameter vector must have %lld floats, got %zu", (long long)h->g.n_params, n); return QPN_EINVAL; }
     hipStream_t stream = (hipStream_t)stream_;
     const Geom& g = h->g;

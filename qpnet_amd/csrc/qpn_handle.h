@@ -26,5 +26,6 @@ struct qpn_handle {
     UttDesc* d_utts; size_t utts_cap;
     hipEvent_t ev0, ev1; float last_ms;
     bool pending;
+    bool decode_ok; std::string decode_err;   // geometries the decode kernels do not cover still train (and report why on decode calls)
     struct TrainState* train;        // lazily created by the training entry points (train_host.hip)
 };

@@ -764,6 +764,29 @@ __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
 }
 
 // ------------------------------------------------------------------------------------------ launchers
+void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+    hipLaunchKernelGGL(k_zero_dx, dim3(64, p.L, p.B), dim3(256), 0, stream, p, bw);
+}
+
+// slabs -> flat gradient (writes every entry), then the histogram-style gradients on top (causal table when no
+// contraction owns it, upsampling kernel)
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+    const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
+    hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
+    {
+        const int64_t total = (int64_t)B * N1;
+        const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
+        const int CB = C < 64 ? C : 64;
+        const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
+        if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
+        if (p.U > 0) { const int nwu = 512, tot = B * N1 * p.Ap, epw = (tot + nwu - 1) / nwu; hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, epw); }
+    }
+    qpn_prof_mark(PG_GRAD_TAIL, stream);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}
+
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
@@ -776,7 +799,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
-    hipLaunchKernelGGL(k_zero_dx, dim3(64, L, B), dim3(256), 0, stream, p, bw);
+    qpn_launch_zero_dx(p, bw, stream);
     if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
         const size_t lds1 = lds_post / MT;
         if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
@@ -865,20 +888,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));
     qpn_prof_mark(PG_WGRAD, stream);
-    // flat gradient: slabs first (writes every entry), then the histogram-style grads on top
-    hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
-    {
-        const int64_t total = (int64_t)B * N1;
-        const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
-        const int CB = C < 64 ? C : 64;
-        const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
-        if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0) { const int nwu = 512, tot = B * N1 * p.Ap, epw = (tot + nwu - 1) / nwu; hipLaunchKernelGGL(k_up_bwd, dim3(nwu), dim3(256), (size_t)(p.U + 1) * sizeof(float), stream, p, bw, epw); }
-    }
-    qpn_prof_mark(PG_GRAD_TAIL, stream);
-    QPN_HIP(hipGetLastError());
-    return QPN_OK;
+    return qpn_launch_grad_tail(p, bw, stream);
 }
 
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {

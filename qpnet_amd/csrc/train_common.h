@@ -77,6 +77,16 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream of the skip / post-net weight gradients (owned by TrainState)
 };
 
+// K-major, zero-padded weight blocks of the GEMM path (train_gemm.hip; n_resch > 128): float offsets into `wp`
+struct TrainGemm {
+    const float* wp;                  // packed weights (refreshed from the flat parameters every step)
+    float* G;                         // [L][B][N1][C] gate outputs sigma*tanh (A operand of the residual / skip contractions)
+    int K1;                           // 2C + n_aux padded to 32: K of the gate GEMM
+    int N1g, Cg, Sg, Qg, LCg, Ktg;    // column counts padded to 128: gate tiles, C, S, Q, L*C, 2C + n_aux
+    long w1[TR_MAXL], w1t[TR_MAXL], wr[TR_MAXL], wrt[TR_MAXL];
+    long ws, wst, p1, p1t, p2, p2t;
+};
+
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)
 enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE, PG_COUNT };
 void qpn_prof_mark(int group, hipStream_t stream);

@@ -415,9 +415,13 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
 }
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
+void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
+}
+
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     const int C = p.C, S = p.S;
-    hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
+    qpn_launch_prep(p, stream);
     qpn_prof_mark(PG_PREP, stream);
     constexpr int MT = TR_MT, TM = 16 * MT;
     const size_t lds_layer = (size_t)TM * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);

@@ -10,6 +10,8 @@
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, hipStream_t stream);
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
+int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
+int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
 
 
@@ -26,6 +28,9 @@ struct TrainState {
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
     bool fwd_valid;
+    bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
+    std::vector<int> h_gmap; int* d_gmap; float* d_gwp;   // its K-major weight blocks
+    TrainGemm gm;
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream for the weight gradients that overlap the layer backward
 };
@@ -72,6 +77,18 @@ __global__ void k_bias_pack(const float* __restrict__ flat, const int* __restric
     if (i < n) { float a = 0.f; for (int j = start[i]; j < start[i + 1]; ++j) a += flat[list[j]]; out[i] = a; }
 }
 
+// B[k][n] (K x N valid) -> K-major block [Kp][Np], zero padded; returns the float offset
+template <class F>
+static long kmajor_pack(std::vector<int>& map, int K, int Kp, int N, int Np, F src) {
+    const long off = (long)map.size();
+    map.resize(map.size() + (size_t)Kp * Np, -1);
+    int* m = map.data() + off;
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) m[(size_t)k * Np + n] = (int)src(k, n);
+    return off;
+}
+static inline int pad_to(int v, int q) { return (v + q - 1) / q * q; }
+
 // B[k][n] (K x N, both multiples of 16) -> fragment order; returns float4 offset
 template <class F>
 static int frag_pack(std::vector<int>& map, int K, int N, F src) {
@@ -99,6 +116,9 @@ static int train_init(qpn_handle* h) {
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = nullptr;
+    t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
+    t->d_gmap = nullptr; t->d_gwp = nullptr; memset(&t->gm, 0, sizeof(t->gm));
+    if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
     TrainParams& p = t->tp;
     const int Ap = (A + 3) / 4 * 4;               // aux columns padded to the MFMA k-step
     p.C = C; p.S = S; p.Q = Q; p.A = A; p.Ap = Ap; p.L = L; p.U = g.U;
@@ -141,6 +161,36 @@ static int train_init(qpn_handle* h) {
     p.bias_s = add_bias(S, [&](int n) { std::vector<int> v; for (int l = 0; l < L; ++l) v.push_back((int)(g.layers[l].skipb + n)); return v; });
     p.bias_p1 = add_bias(S, [&](int n) { return std::vector<int>{(int)(g.post1_b + n)}; });
     p.bias_p2 = add_bias(Q, [&](int n) { return std::vector<int>{(int)(g.post2_b + n)}; });
+    if (t->use_gemm) {
+        TrainGemm& gm = t->gm;
+        std::vector<int>& gmap = t->h_gmap;
+        const int Apad = pad_to(Ap, 32);
+        gm.K1 = 2 * C + Apad; gm.N1g = pad_to(C, 64) * 2; gm.Cg = pad_to(C, 128); gm.Sg = pad_to(S, 128); gm.Qg = pad_to(Q, 128);
+        gm.LCg = pad_to(L * C, 128); gm.Ktg = pad_to(2 * C + Ap, 128);
+        for (int l = 0; l < L; ++l) {
+            const LayerGeom y = g.layers[l];
+            auto w1src = [&](int k, int n) -> int64_t {        // z column n (natural: half*C + r), input column k of [x_cur | x_past | aux]
+                const int half = n / C, r = n % C;
+                if (k < C) return y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
+                if (k < 2 * C) { const int kk = k - C; return y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2; }
+                if (k < 2 * C + A) return (half ? y.auxT : y.auxS) + (int64_t)r * A + (k - 2 * C);
+                return -1;
+            };
+            // gate GEMM: rows k = [x_cur C | x_past C | aux (n_aux, padded to 32)], columns in 128-wide tiles [sigma c0..c0+63 | tanh c0..c0+63]
+            gm.w1[l] = kmajor_pack(gmap, 2 * C + A, gm.K1, gm.N1g, gm.N1g, [&](int k, int q) -> int64_t {
+                const int tile = q / 128, w = q % 128, half = w / 64, c = 64 * tile + w % 64;
+                return c < C ? w1src(k, half * C + c) : -1; });
+            gm.w1t[l] = kmajor_pack(gmap, 2 * C, 2 * C, 2 * C + A, gm.Ktg, [&](int k, int n) { return w1src(n, k); });
+            gm.wr[l] = kmajor_pack(gmap, C, C, C, gm.Cg, [&](int k, int n) { return y.res + (int64_t)n * C + k; });
+            gm.wrt[l] = kmajor_pack(gmap, C, C, C, gm.Cg, [&](int k, int n) { return y.res + (int64_t)k * C + n; });
+        }
+        gm.ws = kmajor_pack(gmap, L * C, L * C, S, gm.Sg, [&](int k, int n) { return g.layers[k / C].skip + (int64_t)n * C + (k % C); });
+        gm.wst = kmajor_pack(gmap, S, S, L * C, gm.LCg, [&](int k, int n) { return g.layers[n / C].skip + (int64_t)k * C + (n % C); });
+        gm.p1 = kmajor_pack(gmap, S, S, S, gm.Sg, [&](int k, int n) { return g.post1_w + (int64_t)n * S + k; });
+        gm.p1t = kmajor_pack(gmap, S, S, S, gm.Sg, [&](int k, int n) { return g.post1_w + (int64_t)k * S + n; });
+        gm.p2 = kmajor_pack(gmap, S, S, Q, gm.Qg, [&](int k, int n) { return g.post2_w + (int64_t)n * S + k; });
+        gm.p2t = kmajor_pack(gmap, Q, Q, S, gm.Sg, [&](int k, int n) { return g.post2_w + (int64_t)k * S + n; });
+    }
     t->n_bias = (int)biases.size();
     t->h_bstart.assign(1, 0);
     for (auto& v : biases) { for (int x : v) t->h_blist.push_back(x); t->h_bstart.push_back((int)t->h_blist.size()); }
@@ -182,18 +232,18 @@ static int train_init(qpn_handle* h) {
     // causal conv table: dW[c][q][tap] = sum_t dX0[t][c] * onehot(x[t-1+tap])[q] is one more time contraction (k_wgrad3 mode 4)
     // when its tiles fit (C = 64, Q a multiple of 128); otherwise the LDS-histogram kernel owns it (gs stays -1)
     bw.g_cw = bw.g_cb = -1;
-    if (C == 64 && Q % 128 == 0) {
+    if (C == 64 && Q % 128 == 0 && !t->use_gemm) {
         bw.g_cw = gtake(2 * C * Q); bw.g_cb = gtake(C);
         for (int c = 0; c < C; ++c) {
             for (int q = 0; q < Q; ++q) for (int tp = 0; tp < 2; ++tp) gs[g.causal_w + ((int64_t)c * Q + q) * 2 + tp] = bw.g_cw + tp * C * Q + c * Q + q;
             gs[g.causal_b + c] = bw.g_cb + c;
         }
     }
-    bw.gstage = go; bw.nch = 64; bw.n_params = g.n_params;
+    bw.gstage = go; bw.nch = t->use_gemm ? 4 : 64; bw.n_params = g.n_params;
     if (const char* e = getenv("QPN_WGRAD_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 512) bw.nch = v; }   // tuning knob: time chunks (= partial slabs)
     // the upsampling kernel's gradient is written by a dedicated kernel (gs stays -1)
 
-    const size_t nmap = map.size();
+    const size_t nmap = t->use_gemm ? 4 : map.size();      // (the GEMM path keeps its own K-major blocks)
     QPN_HIP(hipMalloc(&t->d_wmap, nmap * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_wp, nmap * sizeof(float)));
     QPN_HIP(hipMalloc(&t->d_bstart, t->h_bstart.size() * sizeof(int)));
@@ -203,11 +253,18 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
     QPN_HIP(hipMalloc(&t->d_loss, 64));
-    QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
+    if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc2, gs2.data(), gs2.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (t->use_gemm) {
+        QPN_HIP(hipMalloc(&t->d_gmap, t->h_gmap.size() * sizeof(int)));
+        QPN_HIP(hipMalloc(&t->d_gwp, t->h_gmap.size() * sizeof(float)));
+        QPN_HIP(hipMemcpy(t->d_gmap, t->h_gmap.data(), t->h_gmap.size() * sizeof(int), hipMemcpyHostToDevice));
+        t->gm.wp = t->d_gwp;
+        std::vector<int>().swap(t->h_wmap);                 // the fragment-ordered blocks of the tile kernels are not used on this path
+    }
     QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
@@ -217,7 +274,7 @@ static int train_init(qpn_handle* h) {
 
 void qpn_train_destroy(TrainState* t) {
     if (!t) return;
-    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss};
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
@@ -262,7 +319,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     TrainBwd& bw = t->bw;
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
     const size_t nXC = (size_t)B * (N1 + 1);
-    size_t need = nX + 2 * nG + nH + 2 * nS + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + 4096;
+    size_t need = nX + 2 * nG + nH + 2 * nS + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -283,17 +340,23 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     bw.DXA[0] = carve((size_t)(L + 1) * nDX); bw.DXB[0] = carve((size_t)(L + 1) * nDX); bw.DXA[1] = bw.DXB[1] = nullptr;   // DXB directly follows DXA (one memset)
     bw.DZ = carve((size_t)L * nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
     p.XC = (int*)carve(nXC);
+    if (t->use_gemm) t->gm.G = carve(nG);
     p.TAP = t->d_tap; p.status = t->d_status;
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
-    const size_t nmap = t->h_wmap.size();
-    hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
+    if (t->use_gemm) {
+        const size_t ng = t->h_gmap.size();
+        hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_gmap, t->d_gwp, (int64_t)ng);
+    } else {
+        const size_t nmap = t->h_wmap.size();
+        hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
+    }
     hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
     QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
     qpn_prof_mark(PG_PREP, stream);
     t->fwd_valid = false;
     ++t->generation;
-    rc = qpn_launch_fwd(p, stream); if (rc) return rc;
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, stream); if (rc) return rc;
     t->fwd_valid = true;
     return QPN_OK;
 }
@@ -338,7 +401,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join;
-    return qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
+    return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,

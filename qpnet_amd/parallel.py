@@ -8,6 +8,8 @@ this size.  The reference's loss is a mean over one batch 
 (qpnet.py:253); across ranks batch_length may differ (it depends on max d in each rank's buffer,
 qpnet_train.py:268-284), so gradients are weighted by each rank's row count to reproduce the GLOBAL mean.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -24,8 +26,8 @@ def exchange(buf, group=None):
     """THE gradient exchange of a step: one all-reduce(SUM) of the flat buffer [n_r * g_r | n_r, 0, 0, 0] (RCCL over xGMI on
     MI355X; 2.0 MB for the paper-size model, so one unbucketed call).  In the fused step the HIP kernels produce the weighted
     buffer (qpn_train_backward_ex) and consume the sum (qpn_adam_step_ex divides by the summed row count on the device)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("QPN_EXCHANGE_ALWAYS")):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)      # QPN_EXCHANGE_ALWAYS: one-rank rehearsal of the RCCL call
     return buf
 
 

@@ -27,7 +27,8 @@ import qpnet as ref  # noqa: E402  (the reference module)
 from qpnet_amd import synth  # noqa: E402
 from qpnet_amd.config import TINY, PAPER, QPNetConfig  # noqa: E402
 sys.path.insert(0, HERE)
-from cases import DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, decode2_inputs  # noqa: E402
+from cases import (DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, FORWARD_CASES_D, TRAIN_CASES_D,  # noqa: E402
+                   decode2_inputs)
 
 torch.set_num_threads(8)
 torch.set_grad_enabled(False)
@@ -120,9 +121,9 @@ def gen_decode2():
     print("decode2.npz written")
 
 
-def gen_forward():
+def gen_forward(cases=FORWARD_CASES, fname="forward.npz"):
     out = {}
-    for name, cfg, wseed, dseed, bl, ml in FORWARD_CASES:
+    for name, cfg, wseed, dseed, bl, ml in cases:
         flat = synth.make_weights(cfg, wseed)
         m = build_ref(cfg, flat)
         x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
@@ -134,18 +135,18 @@ def gen_forward():
         out[name + "_loss"] = np.float64(loss.item())
         out[name + "_bl"] = np.int64(BL)
         print(name, "forward", logits.shape, "loss", loss.item())
-    np.savez_compressed(os.path.join(HERE, "forward.npz"), **out)
-    print("forward.npz written")
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written")
 
 
 
 
-def gen_train():
+def gen_train(cases=TRAIN_CASES, fname="train.npz", max_length=30000):
     """A few real optimisation steps: CE(mean) -> backward -> Adam(lr 1e-4)
     (reference src/bin/qpnet_train.py:426-430,517-531)."""
     torch.set_grad_enabled(True)
     out = {}
-    for name, cfg, wseed, dseed, bl, nsteps in TRAIN_CASES:
+    for name, cfg, wseed, dseed, bl, nsteps in cases:
         flat = synth.make_weights(cfg, wseed)
         m = build_ref(cfg, flat)
         m.train()
@@ -153,7 +154,7 @@ def gen_train():
         crit = torch.nn.CrossEntropyLoss()
         losses = []
         for step in range(nsteps):
-            x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+            x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, max_length)
             BL = int(b[0])
             logits = m(torch.from_numpy(x), torch.from_numpy(h), torch.from_numpy(d), torch.from_numpy(b))
             loss = crit(logits.reshape(-1, cfg.n_quantize), torch.from_numpy(t[:, -BL:]).reshape(-1))
@@ -172,15 +173,16 @@ def gen_train():
         out[name + "_losses"] = np.array(losses)
         out[name + "_wfinal_sample"] = w[::97].astype(np.float32)
         print(name, "train losses", losses)
-    np.savez_compressed(os.path.join(HERE, "train.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
     torch.set_grad_enabled(False)
-    print("train.npz written")
+    print(fname, "written")
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = [a.only] if a.only else ["kat", "decode", "decode2", "forward", "train"]
+    todo = [a.only] if a.only else ["kat", "decode", "decode2", "forward", "train", "default"]
     for t in todo:
-        {"kat": gen_kat, "decode": gen_decode, "decode2": gen_decode2, "forward": gen_forward, "train": gen_train}[t]()
+        {"kat": gen_kat, "decode": gen_decode, "decode2": gen_decode2, "forward": gen_forward, "train": gen_train,
+         "default": lambda: (gen_forward(FORWARD_CASES_D, "forward_d.npz"), gen_train(TRAIN_CASES_D, "train_d.npz", 2000))}[t]()

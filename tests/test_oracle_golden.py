@@ -179,3 +179,30 @@ def test_train_oracle_paper_loss_and_grad_sample(golden_dir):
     grad = TO.backward(cfg, flat, caches, dl)
     ref = g[name + "_grad0_sample"]
     assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_train_oracle_default_geometry(golden_dir):
+    """the repo-default geometry (C=512, 12 fixed + 4 adaptive layers): numpy oracle vs the reference's logits / loss /
+    gradient sample / two Adam steps (fixtures forward_d.npz, train_d.npz; short chunks)"""
+    from cases import FORWARD_CASES_D, TRAIN_CASES_D
+    from oracle import train_oracle as TO
+    name, cfg, wseed, dseed, bl, ml = FORWARD_CASES_D[0]
+    g = np.load(golden_dir + "/forward_d.npz")
+    flat = synth.make_weights(cfg, wseed)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
+    lg, _ = TO.forward(cfg, flat, x, h, d, b)
+    np.testing.assert_allclose(lg, g[name + "_logits"], atol=5e-5, rtol=0)
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES_D[0]
+    g = np.load(golden_dir + "/train_d.npz")
+    flat = synth.make_weights(cfg, wseed)
+    opt = TO.Adam(flat.size)
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 2000)
+        loss, grad = TO.train_step(cfg, flat, opt, x, h, t, d, b)
+        losses.append(loss)
+        if step == 0:
+            ref = g[name + "_grad0_sample"]
+            assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(flat[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)

@@ -50,7 +50,7 @@ def test_train_update_validate_decode_entry_points(cuda, tmp_path, oracle):
     os.makedirs(exp2)
     assert runners.run_train(common + geo + ["--expdir", exp2, "--config", exp2 + "/model.conf", "--iters", "6", "--checkpoint_interval", "3",
                                              "--intervals", "2", "--resume", exp + "/checkpoint-3.pkl"]) == 0
-    a = torch.load(exp + "/checkpoint-final.pkl")["model"]; b = torch.load(exp2 + "/checkpoint-final.pkl")["model"]
+    a = torch.load(exp + "/checkpoint-final.pkl", map_location="cpu")["model"]; b = torch.load(exp2 + "/checkpoint-final.pkl", map_location="cpu")["model"]
     # the resumed run restarts the shuffled stream from its beginning (as the reference does), so only shapes/finite-ness are comparable
     assert a.keys() == b.keys() and all(torch.isfinite(v).all() for v in b.values())
     # SD update from the SI model
@@ -71,7 +71,7 @@ def test_train_update_validate_decode_entry_points(cuda, tmp_path, oracle):
                                exp + "/checkpoint-final.pkl", "--outdir", out + "/feat_id.wav", "--batch_size", "2", "--mode", "argmax",
                                "--intervals", "2000", "--verbose", "0"]) == 0
     from scipy.io import wavfile
-    sd = torch.load(exp + "/checkpoint-final.pkl")["model"]
+    sd = torch.load(exp + "/checkpoint-final.pkl", map_location="cpu")["model"]
     flat = np.concatenate([v.numpy().ravel() for v in sd.values()]).astype(np.float32)
     sc = loaders.read_scaler_stats(root + "/stats.npz")
     for i in range(3):

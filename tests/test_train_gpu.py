@@ -340,3 +340,97 @@ def test_trainer_checkpoint_resumes_like_torch_adam(cuda, tmp_path):
         loss = crit(m3(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
         opt.zero_grad(); loss.backward(); opt.step()
     np.testing.assert_allclose(m3.flat_parameters().cpu().numpy(), w_ref.cpu().numpy(), atol=5e-6, rtol=0)
+
+
+# ---------------------------------------------------------------- the LDS-tiled GEMM path (train_gemm.hip)
+@pytest.mark.parametrize("case", TRAIN_CASES, ids=[c[0] for c in TRAIN_CASES])
+def test_gemm_path_on_the_small_geometries(case, cuda, golden_dir, monkeypatch):
+    """QPN_TRAIN_GEMM=1 runs the wide-stack kernels on the tiny / paper-size geometries: same reference fixtures
+    (loss per step within 1e-4, final weights), same oracle gradients per tensor."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.train import FusedTrainer
+    monkeypatch.setenv("QPN_TRAIN_GEMM", "1")
+    name, cfg, wseed, dseed, bl, nsteps = case
+    g = np.load(golden_dir + "/train.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda).train()
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    BL = int(b[0])
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    assert abs(loss.item() - g[name + "_losses"][0]) < 1e-4
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=3e-5, rtol=0)
+    _, dl = TO.ce_loss(lg, t[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        a, r = grad[o:o + n], og[o:o + n]
+        assert np.abs(a - r).max() <= 2e-5 * scale + 1e-4 * np.abs(r).max(), "grad mismatch in " + k
+    m2 = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m2, lr=1e-4)
+    losses = []
+    for step in range(nsteps):
+        xs = _to(cuda, *synth.train_inputs(cfg, bl, dseed + step, 30000))
+        losses.append(tr.step(*xs))
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(m2.flat_parameters().cpu().numpy()[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
+def test_default_geometry_vs_reference(cuda, golden_dir):
+    """The geometry runQP.py instantiates (n_resch 512, 12 fixed + 4 adaptive layers; src/utils/param_model.py:58-64):
+    forward logits, loss, per-tensor gradients (numpy oracle) and two fused Adam steps against the reference fixture."""
+    import torch
+    from cases import FORWARD_CASES_D, TRAIN_CASES_D
+    from oracle import train_oracle as TO
+    from qpnet_amd.train import FusedTrainer
+    name, cfg, wseed, dseed, bl, ml = FORWARD_CASES_D[0]
+    g = np.load(golden_dir + "/forward_d.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
+    with torch.no_grad():
+        lg = m(*_to(cuda, x, h, d, b)).cpu().numpy()
+    np.testing.assert_allclose(lg, g[name + "_logits"], atol=5e-5, rtol=0)
+    BL = int(b[0])
+    lse = np.log(np.exp(lg[0].astype(np.float64)).sum(1))
+    assert abs((lse - lg[0][np.arange(BL), t[0, -BL:]]).mean() - float(g[name + "_loss"])) < 1e-4
+    # gradients
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES_D[0]
+    g = np.load(golden_dir + "/train_d.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda).train()
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, 2000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    BL = int(b[0])
+    loss = torch.nn.CrossEntropyLoss()(m(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    assert abs(loss.item() - g[name + "_losses"][0]) < 1e-4
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    ref = g[name + "_grad0_sample"]
+    assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
+    lgo, caches = TO.forward(cfg, flat, x, h, d, b)
+    _, dl = TO.ce_loss(lgo, t[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        a, r = grad[o:o + n], og[o:o + n]
+        assert np.abs(a - r).max() <= 2e-5 * scale + 2e-4 * np.abs(r).max(), "grad mismatch in " + k
+    # two fused steps
+    m2 = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m2, lr=1e-4)
+    losses = [tr.step(*_to(cuda, *synth.train_inputs(cfg, bl, dseed + s, 2000))) for s in range(nsteps)]
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    # Adam moves every element by ~lr per step whatever the gradient's size: where a gradient is at fp32-noise level the
+    # two summation orders can disagree on a few percent of one step (lr = 1e-4): 5e-6 bounds that, 99.998 % are within 2e-6
+    w, wr = m2.flat_parameters().cpu().numpy()[::97], g[name + "_wfinal_sample"]
+    np.testing.assert_allclose(w, wr, atol=5e-6, rtol=0)
+    assert (np.abs(w - wr) > 2e-6).mean() < 1e-4
