@@ -22,119 +22,8 @@
 #include <string.h>
 #include <algorithm>
 
-// ================================================================== device helpers
-// File-scope LDS symbol: device functions index it directly, so the compiler keeps address space 3
-// (a generic float* would turn every LDS access into a FLAT op that also waits on the global-load queue).
-extern __shared__ float4 qpn_lds[];
-#define SM ((float*)qpn_lds)
-#define SMI ((int*)qpn_lds)
-__device__ __forceinline__ float qexp(float x) {
-    x = fminf(fmaxf(x, -87.0f), 88.0f);
-    float n = rintf(x * 0x1.715476p+0f);
-    float r = __builtin_fmaf(n, -0x1.63p-1f, x);
-    r = __builtin_fmaf(n, 0x1.bd0106p-13f, r);
-    float p = 0x1.a01a02p-13f;
-    p = __builtin_fmaf(p, r, 0x1.6c16c2p-10f);
-    p = __builtin_fmaf(p, r, 0x1.111112p-7f);
-    p = __builtin_fmaf(p, r, 0x1.555556p-5f);
-    p = __builtin_fmaf(p, r, 0x1.555556p-3f);
-    p = __builtin_fmaf(p, r, 0.5f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    p = __builtin_fmaf(p, r, 1.0f);
-    return p * __int_as_float(((int)n + 127) << 23);
-}
-__device__ __forceinline__ float qgate(float zs, float zt) {
-    float ea = qexp(-zs);
-    float eb = qexp(-2.0f * fabsf(zt));
-    float num = 1.0f - eb;
-    float den = (1.0f + ea) * (1.0f + eb);
-    return copysignf(num / den, zt);
-}
+#include "decode_dev.h"
 
-// 16-deep chunk of the spec dot product: p = w0*x0, then 15 fma in k order.
-__device__ __forceinline__ float chunk16(const float4 (&w)[4], const float4 (&x)[4]) {
-    float acc = w[0].x * x[0].x;
-    acc = __builtin_fmaf(w[0].y, x[0].y, acc);
-    acc = __builtin_fmaf(w[0].z, x[0].z, acc);
-    acc = __builtin_fmaf(w[0].w, x[0].w, acc);
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-        acc = __builtin_fmaf(w[j].x, x[j].x, acc);
-        acc = __builtin_fmaf(w[j].y, x[j].y, acc);
-        acc = __builtin_fmaf(w[j].z, x[j].z, acc);
-        acc = __builtin_fmaf(w[j].w, x[j].w, acc);
-    }
-    return acc;
-}
-// Same dot product, and each 1 KiB quarter of the tile is re-requested (from tp) as soon as its four FMAs have
-// been issued: the tile's registers free up a quarter at a time, so the next request reaches the (serial, 16
-// cycles per load) vector-memory front end ~150 cycles earlier than after the whole chain.  The scheduling
-// barriers pin the loads where they are written; hipcc otherwise sinks them below the epilogue.
-__device__ __forceinline__ float chunk16_reload(float4 (&w)[4], const float4 (&x)[4], const float4* __restrict__ tp) {
-    float acc = w[0].x * x[0].x;
-    acc = __builtin_fmaf(w[0].y, x[0].y, acc);
-    acc = __builtin_fmaf(w[0].z, x[0].z, acc);
-    acc = __builtin_fmaf(w[0].w, x[0].w, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    w[0] = tp[0];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-        acc = __builtin_fmaf(w[j].x, x[j].x, acc);
-        acc = __builtin_fmaf(w[j].y, x[j].y, acc);
-        acc = __builtin_fmaf(w[j].z, x[j].z, acc);
-        acc = __builtin_fmaf(w[j].w, x[j].w, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        w[j] = tp[j * 64];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    return acc;
-}
-// stride-halving tree over the R lanes of a row group (R = 1 << logR, lanes contiguous).
-// The spec order is "p_i += p_{i+s} for s = R/2 .. 1"; fp add is commutative, so every lane of the
-// group ends with the same bits whether the partner is reached by xor, rotation or quad permute.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float tree_reduce(float acc, int logR) {
-    if (logR == 2) {                       // K = 64: two quad permutes, no LDS crossbar
-        acc = acc + dpp_f<0x4E>(acc);      // quad_perm [2,3,0,1]  (stride 2)
-        acc = acc + dpp_f<0xB1>(acc);      // quad_perm [1,0,3,2]  (stride 1)
-        return acc;
-    }
-    if (logR == 4) {                       // K = 256: row rotations by 8 and 4, then the quad permutes
-        acc = acc + dpp_f<0x128>(acc);     // row_ror:8
-        acc = acc + dpp_f<0x124>(acc);     // row_ror:4
-        acc = acc + dpp_f<0x4E>(acc);
-        acc = acc + dpp_f<0xB1>(acc);
-        return acc;
-    }
-    if (logR == 1) return acc + dpp_f<0xB1>(acc);
-    for (int s = (1 << logR) >> 1; s >= 1; s >>= 1) acc = acc + __shfl_xor(acc, s);
-    return acc;
-}
-__device__ __forceinline__ void load_tile(float4 (&w)[4], const float4* __restrict__ wpk, int woff4, int lane) {
-    const float4* p = wpk + (size_t)woff4 + lane;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = p[j * 64];
-}
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-// Ring-buffer traffic stays inside ONE workgroup (= one CU): producer waves store, drain vmcnt and pass a workgroup
-// barrier before any wave loads the row -- the visibility HIP guarantees for global memory across __syncthreads().
-// Workgroup scope keeps the rows in the CU's L1 / the XCD's L2 (write-back).  Agent scope (sc1, write-through) was
-// measured to push every 4-byte store to the fabric: 2.0 KB written + ~1.8 KB fetched per generated sample
-// (profiles/r01_decode_traffic_pmc.txt) against 172 B of algorithmic HBM bytes.
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // ================================================================== small setup kernels
 __global__ void k_pack_gather(const float* __restrict__ flat, const int* __restrict__ map, float* __restrict__ out, int64_t n) {
@@ -215,85 +104,8 @@ __global__ void k_known(const int64_t* __restrict__ x, int n_x, int n_pad, int Q
 }
 
 
-// ---------------------------------------------------------------- sampling mode (reference qpnet.py:507-510)
-// softmax + categorical draw by inverse CDF with a counter-based generator (Philox4x32-10, counter = (step, row),
-// key = seed), in the fixed order of DESIGN.md §3 so that the CPU oracle reproduces every draw bit for bit.
-// (Parity with the reference's torch.Generator stream is statistical only.)  One wave, Q = 64 * per, per <= 4.
-__device__ __forceinline__ unsigned philox_first(unsigned c0, unsigned c1, unsigned k0, unsigned k1) {
-    unsigned c2 = 0, c3 = 0;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-__device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long seed, unsigned row, unsigned step, int lane) {
-    const float* lg = SM + o_lg;
-    const int per = Q >> 6;
-    float l[4], e[4];
-    float m = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { l[j] = j < per ? lg[lane * per + j] : -INFINITY; m = fmaxf(m, l[j]); }
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) e[j] = j < per ? qexp(l[j] - m) : 0.0f;
-    float a = e[0];
-#pragma unroll
-    for (int j = 1; j < 4; ++j) if (j < per) a = a + e[j];
-    float v = a;
-    for (int d = 1; d < 64; d <<= 1) { const float up = __shfl_up(v, d); if (lane >= d) v = v + up; }
-    const float total = __shfl(v, 63);
-    float c = __shfl_up(v, 1);
-    if (lane == 0) c = 0.0f;
-    const float u = (float)(philox_first(step, row, (unsigned)seed, (unsigned)(seed >> 32)) >> 8) * 0x1p-24f;
-    const float th = u * total;
-    int idx = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (j < per) { c = c + e[j]; if (idx == 0x7fffffff && c > th) idx = lane * per + j; }
-    for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(idx, s); idx = o < idx ? o : idx; }
-    return idx == 0x7fffffff ? Q - 1 : idx;
-}
 
 // ================================================================== the persistent decode kernel
-struct UttView {            // per-utterance pointers derived from kernel-argument bases (global address space)
-    const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
-    int n_pad, n0, n_samples, d_is_f32;
-};
-__device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDesc& d) {
-    UttView u;
-    u.pproj = p.pproj + d.pproj;
-    u.dfac = d.d_is_f32 ? (const void*)((const float*)p.dfac + d.dfac) : (const void*)((const double*)p.dfac + d.dfac);
-    u.known = p.known + d.known;
-    u.teacher = d.teacher >= 0 ? p.teacher + d.teacher : nullptr;
-    u.out = p.out + d.out;
-    u.logits = d.logits >= 0 ? p.logits + d.logits : nullptr;
-    u.ring = p.ring + d.ring;
-    u.n_pad = d.n_pad; u.n0 = d.n0; u.n_samples = d.n_samples; u.d_is_f32 = d.d_is_f32;
-    return u;
-}
-
-// pitch-dependent tap distance of ring `r` at (padded) time t  (qpnet.py:613-624)
-// `widx` != 0: warm-up step over the known prefix -- the reference takes those taps from _dilated_index (qpnet.py:416,
-// 592-611: rint(-d*dil + idx), idx = position from the end of the prefix), not from _generate_dilated_index
-__device__ __forceinline__ int tap_offset(const RingDesc& r, const UttView& u, int ut, int widx) {
-    if (!r.adaptive) return r.mult;
-    if (ut < 0) return r.mult;                       // d := 1.0 in the left padding (qpnet.py:361-364)
-    if (u.d_is_f32) {
-        float d = ((const float*)u.dfac)[ut];
-        if (widx) return widx - (int)rintf(__fadd_rn(-d * (float)r.mult, (float)widx));
-        return -(int)rintf(-d * (float)r.mult);
-    }
-    double d = ((const double*)u.dfac)[ut];
-    if (widx) return widx - (int)rint(__dadd_rn(-d * (double)r.mult, (double)widx));
-    return -(int)rint(-d * (double)r.mult);
-}
-// un-padded time whose aux features / dilated factor step t uses: the newest sample's own in the generation loop
-// (qpnet.py:450-452); one EARLIER during the warm-up over the known prefix, where the reference pairs layer output p with
-// h[p-1], d[p-1] (h_ = h[:, :, :causal_output.size(-1)], qpnet.py:366-368; visible only with seeds of >= 3 samples)
-__device__ __forceinline__ int aux_time(const UttView& u, int t) { return t - u.n_pad - (t < u.n0 - 1 ? 1 : 0); }
 
 // aux terms a[t1] of every layer -> LDS (needs only the frame-rate projections)
 __device__ __forceinline__ void stage_aux(const DecodeParams& p, const UttView& u, int64_t t1, int tid, int nthreads) {
@@ -959,6 +771,7 @@ static int build_program(qpn_handle* h) {
         };
         int off_past = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row / C, row % C, k, 1); });
         int off_cur = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row & 1, row >> 1, k, 0); });
+        h->w_past_il[l] = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row & 1, row >> 1, k, 1); });   // cooperative kernel: (sigma_c, tanh_c) rows together
         int off_res = pack_matrix(map, C, C, g.Cp, [&](int row, int k) { return y.res + (int64_t)row * C + k; });
         int off_skip = pack_matrix(map, S, C, g.Cp, [&](int row, int k) { return y.skip + (int64_t)row * C + k; });
         // Z phase: this step's pre-activations + the NEXT step's past-tap dots of the same layer (the
@@ -1019,7 +832,7 @@ static int build_program(qpn_handle* h) {
     p.n_slots = slot;
     p.o_tasks = o; o += slot * QPN_NW * 8;
     p.lds_floats = o;
-    if ((size_t)o * 4 > 160 * 1024) { qpn_set_error("decode state (%d KiB) exceeds the 160 KiB LDS of one CU", o * 4 / 1024); return QPN_EINVAL; }
+    h->single_cu_ok = (size_t)o * 4 <= 160 * 1024;        // otherwise: several workgroups per utterance (decode_coop.hip)
     return QPN_OK;
 }
 
@@ -1032,6 +845,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     h->d_map = nullptr; h->d_wpk = nullptr; h->d_tasks = nullptr; h->d_qb = nullptr; h->d_bd = nullptr; h->d_status = nullptr; h->d_bias_src = nullptr;
     h->d_flat = nullptr; h->have_weights = false;
     h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
+    h->d_xch = nullptr; h->xch_cap = 0; h->single_cu_ok = true;
     h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
     rc = build_program(h);
     h->decode_ok = rc == QPN_OK;
@@ -1049,7 +863,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
 extern "C" void qpn_destroy(qpn_handle* h) {
     if (!h) return;
     if (h->device >= 0) {
-        void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_bias_src, h->d_pproj, h->d_ring, h->d_known, h->d_utts};
+        void* bufs[] = {h->d_map, h->d_wpk, h->d_tasks, h->d_qb, h->d_bd, h->d_status, h->d_bias_src, h->d_pproj, h->d_ring, h->d_known, h->d_utts, h->d_xch};
         for (void* b : bufs) if (b) (void)hipFree(b);
         qpn_train_destroy(h->train);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1115,6 +929,9 @@ static int grow(T** p, size_t* cap, size_t need) {
     return QPN_OK;
 }
 
+int qpn_coop_group_size(const Geom& g, int limit);
+int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
+
 extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
                                   const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
                                   const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
@@ -1150,7 +967,15 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
         ring_floats += (size_t)len * g.C;
     }
     ring_floats = (ring_floats + 63) & ~(size_t)63;
-    rc = grow(&h->d_ring, &h->ring_cap, ring_floats * B); if (rc) return rc;
+    // several workgroups per utterance when one CU cannot hold the step state (or QPN_DECODE_COOP=<G> asks for it)
+    int coopG = 0;
+    if (const char* e = getenv("QPN_DECODE_COOP")) coopG = atoi(e) > 0 ? atoi(e) : 0;
+    if (!h->single_cu_ok && coopG == 0) coopG = 256;
+    if (coopG > 0) {
+        int cap = coopG; if (B < 256 && 256 / B < cap) cap = 256 / B;       // the whole batch in one launch when it fits the chip
+        coopG = qpn_coop_group_size(g, cap < 1 ? 1 : cap);
+    }
+    if (!coopG) { rc = grow(&h->d_ring, &h->ring_cap, ring_floats * B); if (rc) return rc; }
     rc = grow(&h->d_pproj, &h->pproj_cap, (size_t)B * F * g.L * 2 * g.C); if (rc) return rc;
     rc = grow(&h->d_known, &h->known_cap, (size_t)B * n0); if (rc) return rc;
     rc = grow(&h->d_utts, &h->utts_cap, (size_t)B); if (rc) return rc;
@@ -1168,7 +993,7 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     }
     QPN_HIP(hipMemcpyAsync(h->d_utts, utts.data(), B * sizeof(UttDesc), hipMemcpyHostToDevice, stream));
     QPN_HIP(hipStreamSynchronize(stream));   // utts is a host temporary
-    QPN_HIP(hipMemsetAsync(h->d_ring, 0, ring_floats * B * sizeof(float), stream));
+    if (!coopG) QPN_HIP(hipMemsetAsync(h->d_ring, 0, ring_floats * B * sizeof(float), stream));
     QPN_HIP(hipMemsetAsync(h->d_status, 0, 64, stream));
     hipLaunchKernelGGL(k_known, dim3((unsigned)((n0 + 255) / 256), B), dim3(256), 0, stream, d_x, n_x, (int)n_pad, g.Q, h->d_known);
     hipLaunchKernelGGL(k_aux_project, dim3((unsigned)F, B), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_h, F,
@@ -1178,6 +1003,12 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
+    if (coopG) {
+        rc = qpn_launch_decode_coop(h, p, B, coopG, stream); if (rc) return rc;
+        QPN_HIP(hipEventRecord(h->ev1, stream));
+        h->pending = true;
+        return QPN_OK;
+    }
     const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
     const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;
     // the specialised kernel does not use the task table: the residual-1x1 tiles of layers 0..L-2 take its place (and more) when they fit
@@ -1225,6 +1056,7 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
             fprintf(stderr, "\n");
         }
     }
+    if (status & 4) { qpn_set_error("cooperative decode: a workgroup timed out waiting for its peers (is another job holding CUs of this GPU?)"); return QPN_ENODEV; }
     if (status & 1) { qpn_set_error("pitch-dependent tap left its ring buffer (dilated factor <= 0.5 or > maxd)"); return QPN_ERANGE; }
     return QPN_OK;
 }

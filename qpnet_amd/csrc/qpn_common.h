@@ -45,7 +45,7 @@ struct Geom {
 };
 
 int qpn_build_geom(const qpn_config* cfg, Geom* g);
-static inline int qpn_pad_k(int K) { int R = 1; while (16 * R < K) R *= 2; return 16 * R; }
+__host__ __device__ static inline int qpn_pad_k(int K) { int R = 1; while (16 * R < K) R *= 2; return 16 * R; }
 
 // ---------------------------------------------------------------- decode program
 enum {
@@ -85,6 +85,20 @@ struct FastParams {
     int b_res[QPN_MAX_LAYERS], b_skip[QPN_MAX_LAYERS];                                                   // LDS float offsets
     int adaptive[QPN_MAX_LAYERS];
     int w_p1, w_p2, b_p1, b_p2;
+};
+
+// cooperative decode (decode_coop.hip): G workgroups per utterance, each owning 1/G of every layer's output rows; full
+// vectors are exchanged through 8-byte {tag, value} granules in global memory (tag = step + 1, zeroed before every launch)
+struct CoopParams {
+    unsigned long long* xch;          // exchange memory
+    long utt_stride;                  // granules per utterance
+    int o_ring[QPN_MAX_LAYERS];       // granule offsets inside an utterance block: layer-input history [len_l][C]
+    int o_g, o_y1, o_y2, o_lg;        // gate vectors [L][C], relu(skip total) [S], post-1 output [S], logits [Q]
+    int* abort;                       // set when a wait timed out: every workgroup drains instead of spinning on
+    int G, CB, SB, QB, Sp;            // workgroups per utterance; channels / skip rows / logit rows per workgroup
+    int logR, rpt, logRs, rpts;       // lanes per row (log2) and rows per 4 KiB tile for K = C and K = S
+    int w_past_il[QPN_MAX_LAYERS];    // float4 offsets of the past-tap tiles with (sigma_c, tanh_c) rows interleaved
+    int f_resb[QPN_MAX_LAYERS], f_skipb[QPN_MAX_LAYERS], f_p1b, f_p2b;   // flat offsets of the biases the epilogues add
 };
 
 struct DecodeParams {

@@ -26,6 +26,9 @@ struct qpn_handle {
     UttDesc* d_utts; size_t utts_cap;
     hipEvent_t ev0, ev1; float last_ms;
     bool pending;
+    bool single_cu_ok;               // the step state fits one CU's LDS (decode.hip kernels); otherwise decode_coop.hip only
+    int w_past_il[QPN_MAX_LAYERS];   // channel-interleaved past-tap tiles (cooperative kernel)
+    unsigned long long* d_xch; size_t xch_cap;   // exchange granules of the cooperative kernel
     bool decode_ok; std::string decode_err;   // geometries the decode kernels do not cover still train (and report why on decode calls)
     struct TrainState* train;        // lazily created by the training entry points (train_host.hip)
 };

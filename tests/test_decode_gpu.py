@@ -216,3 +216,59 @@ def test_dilated_index_exports_vs_reference_kat(tag, cuda, golden_dir):
         o = torch.empty(dl.shape, dtype=torch.int64, device=cuda)
         _lib.check(L.qpn_dilated_index_train(dl.data_ptr(), dl.shape[0], dl.shape[1], 8, o.data_ptr(), None))
         np.testing.assert_array_equal(o.cpu().numpy(), g["didx_long_train_f32_3"])
+
+
+# ---------------------------------------------------------------- several cooperating workgroups per utterance (decode_coop.hip)
+@pytest.mark.parametrize("case", DECODE_CASES, ids=[c[0] for c in DECODE_CASES])
+def test_cooperative_decode_matches_reference_streams(case, cuda, golden_dir, monkeypatch):
+    """QPN_DECODE_COOP=4 runs the multi-workgroup kernel (row-sliced matrices, tagged-granule all-gathers) on the small
+    geometries: the same reference streams, bit for bit (paper-size: 4 workgroups per utterance; tiny: 1)."""
+    import torch
+    monkeypatch.setenv("QPN_DECODE_COOP", "4")
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    d_arg = torch.from_numpy(bd).float().to(cuda) if extra else bd
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, d_arg, mode="argmax", extra_memory=extra)
+    assert nlist == list(g[name + "_nleft"])
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="cooperative HIP vs reference stream, row %d" % i)
+
+
+def test_cooperative_decode_sampling_and_logits(cuda, oracle, monkeypatch):
+    """sampling mode and teacher-forced logits through the cooperative kernel: bit-identical to the oracle"""
+    import torch
+    from qpnet_amd.config import PAPER
+    monkeypatch.setenv("QPN_DECODE_COOP", "2")
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 31)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(61, 5, 1.0), (62, 4, 0.5)])
+    m.sampling_seed = 99
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="sampling")
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd, mode="sampling", seed=99)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+    x, h, d, n = synth.decode_inputs(cfg, 4, 5, 1.0)
+    teacher = np.random.RandomState(9).randint(0, 256, size=n).astype(np.int64)
+    out, logits = m._stream_logits(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), d[None], torch.from_numpy(teacher[None]), n)
+    r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True)
+    assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
+
+
+def test_default_geometry_decode_vs_oracle(cuda, oracle):
+    """The repo-default QPNet (n_resch 512, 12 fixed + 4 adaptive layers: what runQP.py builds) decodes on the
+    cooperative kernel: greedy streams of two utterances of unequal length, bit-exact vs the CPU oracle."""
+    import torch
+    from qpnet_amd.config import DEFAULT
+    cfg = DEFAULT
+    flat = synth.make_weights(cfg, 7)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(11, 2, 1.0), (12, 3, 1.5)])
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
+    assert [len(o) for o in outs] == sorted(ns)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
