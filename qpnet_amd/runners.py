@@ -310,21 +310,21 @@ def run_decode(argv=None):
     feat_list = loaders.find_files(args.feats, "*" + ext) if os.path.isdir(args.feats) else loaders.read_txt(args.feats)
     mine = np.array_split(np.array(feat_list, dtype=object), world)[rank].tolist()      # qpnet_decode.py:258-259
     scaler = loaders.read_scaler_stats(args.stats, conf.feature_type)
-    torch.set_grad_enabled(False)
-    model = _build_model(conf, dev).eval()
-    loaders.load_checkpoint(args.checkpoint, model, None)
-    feats = [loaders.read_features(f, conf.feature_type) for f in mine]
-    ids = [os.path.basename(f).replace(ext, "") for f in mine]
-    from .qpnet import encode_mu_law
-    gen = loaders.decode_generator(feats, args.fs, ids, wav_transform=lambda x: encode_mu_law(x, conf.n_quantize),
-                                   feat_transform=scaler, dense_factor=conf.dense_factor, batch_size=args.batch_size,
-                                   upsampling_factor=conf.upsampling_factor, f0_factor=args.f0_factor,
-                                   f0_dim_index=args.f0_dim_index, extra_memory=args.extra_memory, device=dev)
-    for feat_ids, bx, bh, ns, bd in gen:
-        logging.info("decoding start!")
-        outs = model.batch_fast_generate(bx, bh, ns, bd, intervals=args.intervals, mode=args.mode, extra_memory=args.extra_memory)
-        for feat_id, samples in zip(feat_ids, outs):
-            name = args.outdir.replace("feat_id", feat_id)
-            loaders.write_wav(name, args.fs, samples, conf.n_quantize)
-            logging.info("wrote %s." % name)
+    with torch.no_grad():
+        model = _build_model(conf, dev).eval()
+        loaders.load_checkpoint(args.checkpoint, model, None)
+        feats = [loaders.read_features(f, conf.feature_type) for f in mine]
+        ids = [os.path.basename(f).replace(ext, "") for f in mine]
+        from .qpnet import encode_mu_law
+        gen = loaders.decode_generator(feats, args.fs, ids, wav_transform=lambda x: encode_mu_law(x, conf.n_quantize),
+                                       feat_transform=scaler, dense_factor=conf.dense_factor, batch_size=args.batch_size,
+                                       upsampling_factor=conf.upsampling_factor, f0_factor=args.f0_factor,
+                                       f0_dim_index=args.f0_dim_index, extra_memory=args.extra_memory, device=dev)
+        for feat_ids, bx, bh, ns, bd in gen:
+            logging.info("decoding start!")
+            outs = model.batch_fast_generate(bx, bh, ns, bd, intervals=args.intervals, mode=args.mode, extra_memory=args.extra_memory)
+            for feat_id, samples in zip(feat_ids, outs):
+                name = args.outdir.replace("feat_id", feat_id)
+                loaders.write_wav(name, args.fs, samples, conf.n_quantize)
+                logging.info("wrote %s." % name)
     return 0
