@@ -361,6 +361,76 @@ def run_train(args, rank, local, world):
     return out
 
 
+def run_default_geometry(local):
+    """SURVEY 8d "also report D": the geometry runQP.py instantiates (n_resch 512, 12 fixed + 4 adaptive layers, 24.2 M
+    parameters; src/utils/param_model.py:58-64) -- training step on the LDS-tiled GEMM path (train_gemm.hip) and decode on
+    the cooperative multi-workgroup kernel (decode_coop.hip).  A few steps / 20-frame utterances: extra keys, not `value`."""
+    import ctypes as C
+    import torch
+    from qpnet_amd import synth, _lib
+    from qpnet_amd.config import DEFAULT
+    from qpnet_amd.qpnet import QPNet
+    from qpnet_amd.train import FusedTrainer
+    dev = torch.device("cuda", local)
+    cfg = DEFAULT
+    flat = synth.make_weights(cfg, 13)
+    m = QPNet(**cfg.kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
+    m = m.to(dev).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    hb = [synth.train_inputs(cfg, 20000, 5000 + 17 * i, 30000, f0_lo=55.0, f0_hi=300.0) for i in range(2)]
+    bt = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in b] for b in hb]
+    maxds = [int(np.ceil(b[3]).max()) for b in hb]
+
+    def step(i):
+        x, h, t, d, _ = bt[i % 2]
+        return tr.step(x, h, t, d, hb[i % 2][4], want_loss=False, maxd=maxds[i % 2])
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); n = 8
+    for i in range(n):
+        step(i)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+    L_, hd = m._native(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ms = (C.c_float * len(PG_NAMES))()
+    _lib.check(L_.qpn_train_profile_begin(hd, stream))
+    for i in range(2):
+        step(i)
+    _lib.check(L_.qpn_train_profile_end(hd, ms, len(PG_NAMES), stream))
+    ms = [v / 2 for v in ms]
+    BL = int(hb[0][4][0]); maxd = maxds[0]; N1 = cfg.receptive_field(maxd) + BL - 1
+    starts, s_ = [], 0
+    for dil in cfg.dilationsF:
+        s_ += dil; starts.append(s_)
+    for dil in cfg.dilationsA:
+        s_ += dil * maxd; starts.append(s_)
+    fl = train_flops(cfg, N1, BL, starts)
+    out = {"geometry": "repo default: C=512, S=256, F=[1,2,4,8]x3, A=[1,2,4,8], 24151151 parameters",
+           "train": {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "tflop_per_step": sum(fl) / 1e12,
+                     "roofline": {"bound": "mfma", "achieved": sum(fl) / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": sum(fl) / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                  "groups_ms": dict(zip(PG_NAMES, [round(v, 3) for v in ms])),
+                                  "groups_tflops": {k: round(f / (v * 1e-3) / 1e12, 1) for k, v, f in zip(PG_NAMES, ms, fl + [0.0]) if f > 0 and v > 0}},
+                     "reference_cpu_s_per_step": 17.9}}
+    del tr, bt
+    m = m.eval()
+    dec = {}
+    for B in (1, 20):
+        bx, bh, bd, ns = synth.decode_batch(cfg, [(100 + b, 20, 1.0) for b in range(B)])
+        xb, hbt = torch.from_numpy(bx).to(dev), torch.from_numpy(bh).to(dev)
+        m.batch_fast_generate(xb, hbt, list(ns), bd, mode="argmax")
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        m.batch_fast_generate(xb, hbt, list(ns), bd, mode="argmax")
+        torch.cuda.synchronize(); dtd = time.perf_counter() - t0
+        dec["batch%d" % B] = {"samples_per_s": sum(ns) / dtd, "us_per_sample_per_utterance": m.last_decode_kernel_ms * 1e3 / max(ns),
+                              "workload": "%d x 20-frame utterances (%d samples each)" % (B, ns[0])}
+    dec["reference_cpu_samples_per_s"] = 40
+    dec["kernel"] = "k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= 256 whose row slices are whole tiles)"
+    out["decode"] = dec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -393,6 +463,11 @@ def main():
             d1 = run_decode(a3, rank, local, world)
             out["decode"]["batch1"] = {"value": d1["value"], "unit": d1["unit"], "ms_per_step": d1["ms_per_step"],
                                        "kernel_ms": d1["roofline"]["kernel_ms"]}
+            if not args.no_cpu:
+                try:
+                    out["default_geometry"] = run_default_geometry(local)
+                except Exception as e:        # an extra: never let it take the headline line down
+                    out["default_geometry"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     import torch.distributed as dist

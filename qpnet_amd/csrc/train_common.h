@@ -38,6 +38,7 @@ struct TrainParams {
     // global buffers
     const float* flat;        // parameters (state_dict order)
     const float4* wp;         // fragment-ordered weights
+    const float* ct;          // causal conv table transposed to [tap][class][C] (a row per looked-up class: coalesced)
     const float* bp;          // packed biases
     const int64_t* x; const float* h; const float* d;
     float* X;                 // [L+1][B][N1][C]

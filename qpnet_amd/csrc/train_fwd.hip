@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     if (s1 < 0) s1 += Q;
     if (lane == 0) { p.XC[(size_t)b * (p.N1 + 1) + n] = (int)s0; if (n == p.N1 - 1) p.XC[(size_t)b * (p.N1 + 1) + p.N1] = (int)s1; }
     float* X0 = p.X + ((size_t)b * p.N1 + n) * C;
+    const float* r0 = p.ct + (size_t)s0 * C;                   // tap 0 row of class s0, tap 1 row of class s1
+    const float* r1 = p.ct + ((size_t)Q + s1) * C;
     for (int c = lane; c < C; c += 64) {
-        float v = p.flat[p.causal_w + ((size_t)c * Q + s0) * 2] + p.flat[p.causal_w + ((size_t)c * Q + s1) * 2 + 1];
+        float v = r0[c] + r1[c];
         X0[c] = v + p.flat[p.causal_b + c];
     }
     // upsampled aux features, aligned at the END of h_up (negative hindex, qpnet.py:269-276)

@@ -29,6 +29,7 @@ struct TrainState {
     int* d_status; double* d_loss;
     bool fwd_valid;
     bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
+    int* d_ctmap; float* d_ct;                // causal conv table [tap][class][C] and its gather map
     std::vector<int> h_gmap; int* d_gmap; float* d_gwp;   // its K-major weight blocks
     TrainGemm gm;
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
@@ -117,7 +118,7 @@ static int train_init(qpn_handle* h) {
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = nullptr;
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
-    t->d_gmap = nullptr; t->d_gwp = nullptr; memset(&t->gm, 0, sizeof(t->gm));
+    t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
     TrainParams& p = t->tp;
     const int Ap = (A + 3) / 4 * 4;               // aux columns padded to the MFMA k-step
@@ -265,6 +266,14 @@ static int train_init(qpn_handle* h) {
         t->gm.wp = t->d_gwp;
         std::vector<int>().swap(t->h_wmap);                 // the fragment-ordered blocks of the tile kernels are not used on this path
     }
+    {
+        std::vector<int> ctm((size_t)2 * Q * C);
+        for (int tp = 0; tp < 2; ++tp) for (int q = 0; q < Q; ++q) for (int c = 0; c < C; ++c)
+            ctm[((size_t)tp * Q + q) * C + c] = (int)(g.causal_w + ((int64_t)c * Q + q) * 2 + tp);
+        QPN_HIP(hipMalloc(&t->d_ctmap, ctm.size() * sizeof(int)));
+        QPN_HIP(hipMalloc(&t->d_ct, ctm.size() * sizeof(float)));
+        QPN_HIP(hipMemcpy(t->d_ctmap, ctm.data(), ctm.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
@@ -274,7 +283,7 @@ static int train_init(qpn_handle* h) {
 
 void qpn_train_destroy(TrainState* t) {
     if (!t) return;
-    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp};
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
@@ -351,6 +360,9 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
         const size_t nmap = t->h_wmap.size();
         hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
     }
+    { const size_t nct = (size_t)2 * g.Q * g.C;
+      hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_ctmap, t->d_ct, (int64_t)nct); }
+    p.ct = t->d_ct;
     hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
     QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
     qpn_prof_mark(PG_PREP, stream);

@@ -13,7 +13,7 @@ def find(pattern):
     return f[0] if f else None
 
 
-for what in ("train", "decode"):
+for what in ("train", "decode", "default", "default_dec"):
     f = find("%s_stats/**/*kernel_stats.csv" % what)
     if f:
         rows = list(csv.reader(open(f)))
@@ -62,8 +62,9 @@ json.dump(per, open(os.path.join(dst, "%s_pmc_by_kernel.json" % tag), "w"), inde
 # the figures bench.py reports
 dec = [v for k, v in per.get("decode", {}).items() if "k_decode" in k]
 if dec:
-    n = 20 * (600 * 110 - 1)
-    traffic["decode"] = {"kernel": "k_decode_fast<64,256,256,16>", "workload": "batch 20 x 600 frames (20 x 65999 samples)",
+    frames = 2005 if tag != "r01" else 600
+    n = 20 * (frames * 110 - 1)
+    traffic["decode"] = {"kernel": "k_decode_fast<64,256,256,16>", "workload": "batch 20 x %d frames (20 x %d samples)" % (frames, frames * 110 - 1),
                          "hbm_bytes_per_sample": sum(v["hbm_bytes"] for v in dec) / n}
 wg = [(k, v) for k, v in per.get("train", {}).items() if "k_wgrad" in k]
 if wg:
