@@ -929,6 +929,8 @@ static int grow(T** p, size_t* cap, size_t need) {
     return QPN_OK;
 }
 
+bool qpn_pipe_supported(const Geom& g);
+int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream);
 int qpn_coop_group_size(const Geom& g, int limit);
 int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
 
@@ -1008,6 +1010,17 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
         QPN_HIP(hipEventRecord(h->ev1, stream));
         h->pending = true;
         return QPN_OK;
+    }
+    // paper-size geometry: four pipelined workgroups per utterance with resident weights (decode_pipe.hip) unless QPN_DECODE_PIPE=0
+    {
+        const char* e = getenv("QPN_DECODE_PIPE");
+        const bool want = e ? atoi(e) != 0 : false;
+        if (want && qpn_pipe_supported(g) && B <= 64 && !getenv("QPN_DECODE_GENERIC")) {
+            rc = qpn_launch_decode_pipe(h, p, B, stream); if (rc) return rc;
+            QPN_HIP(hipEventRecord(h->ev1, stream));
+            h->pending = true;
+            return QPN_OK;
+        }
     }
     const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
     const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;

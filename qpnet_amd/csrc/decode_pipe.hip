@@ -1,0 +1,427 @@
+// decode_pipe.hip -- layer-PIPELINED autoregressive decode for the paper-size QPNet (C=64, S=256, Q=256, 4 fixed + 4
+// pitch-adaptive layers): four workgroups (four CUs) per utterance, every weight tile that sits on the critical path RESIDENT
+// in registers / LDS.  Replaces QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), same arithmetic spec as
+// decode.hip (bit-identical streams).
+//
+// Why: one CU per utterance (decode.hip) re-streams the 1.7 MB of weight tiles from L2 for every generated sample and is
+// bounded by its 64 B/clk L1 port at 11.65 us per sample.  Four CUs hold ALL tiles (512 KB of VGPRs + 160 KB of LDS each):
+//   S0  fixed layers 0-3: current- and past-tap tiles in VGPRs (8 waves x 32 KB), residual tiles in LDS; their skip rows
+//       are streamed AFTER x_4 has been handed on (off the critical path) and travel as the fixed-stack skip sum accF
+//   S1  adaptive layers 4-7: same residency; the pitch-dependent history rings stay in a private, L2-resident global block
+//   K   skip rows of layers 4-7 (tiles of layers 4, 5 in LDS, of 6, 7 in VGPRs) + post 1x1 #1 (VGPRs)
+//   P   post 1x1 #2 (VGPRs), argmax / sampling, the two causal-conv table rows of the picked sample (tables in LDS)
+// A generated sample travels S0 -> S1 -> K -> P -> S0: four hand-offs (0.44 us each inside an XCD, 0.55 across:
+// profiles/r02_hop_microbench.txt) instead of 1.7 MB through one L1 port.  Hand-offs are data-tagged 8-byte granules
+// {tag = step + 1, value} written with agent-scope (sc1) stores and polled with agent-scope loads (CDNA4 guide, Guideline 16
+// R2): correct for any placement; blocks g, g+8, g+16, g+24 serve one utterance so that round-robin dispatch puts them on
+// one XCD (speed only).  Every wait is bounded; a timeout raises the abort flag and everyone drains.
+#include "decode_dev.h"
+#include "qpn_handle.h"
+#include <string.h>
+
+typedef unsigned long long u64;
+#define PIPE_NT 512
+#define PIPE_NW 8
+#define PIPE_SPIN (1u << 22)
+
+// exchange block of one utterance (granule offsets)
+#define PX_X4 0          // [64]   S0 -> S1   layer-4 input
+#define PX_ACK 64        // [1]    S1 -> S0   x4 of step t consumed (flow control while S0 is not throttled by P: warm-up)
+#define PX_G 72          // [4][64] S1 -> K   gate vectors of layers 4..7
+#define PX_ACCF 328      // [256]  S0 -> K    skip sum of the fixed stack
+#define PX_Y2 584        // [256]  K  -> P    post 1x1 #1 output
+#define PX_NX 840        // [1 + 64 + 64] P -> S0  picked sample, its tap-1 table row, its tap-0 table row
+#define PX_STRIDE 976
+
+struct PipeParams {
+    u64* xch; int* abort;
+    int w_past_il[8];            // float4 offsets: past-tap tiles with (sigma_c, tanh_c) rows interleaved
+    int f_resb[8], f_skipb[8], f_p1b, f_p2b;
+    int nutt;
+};
+
+__device__ __forceinline__ void pst(u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 pld(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// wait for ONE granule of step `tag`; returns its value (on timeout / abort: raises the flag and returns what is there)
+__device__ __forceinline__ float pwait(const u64* g, unsigned tag, int* abort, int* status) {
+    u64 v = pld(g);
+    unsigned spins = 0;
+    while ((unsigned)(v >> 32) != tag) {
+        if (++spins > PIPE_SPIN || ((spins & 255u) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(status, 4);
+            break;
+        }
+        v = pld(g);
+    }
+    return __uint_as_float((unsigned)v);
+}
+__device__ __forceinline__ void rd4(float4 (&x)[4], const float* v) {
+    const float4* p = (const float4*)v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = p[j];
+}
+__device__ __forceinline__ float red4(float a) {          // R = 4 lanes per row (K = 64)
+    a = a + dpp_f<0x4E>(a); a = a + dpp_f<0xB1>(a); return a;
+}
+__device__ __forceinline__ float red16(float a) {         // R = 16 lanes per row (K = 256)
+    a = a + dpp_f<0x128>(a); a = a + dpp_f<0x124>(a); a = a + dpp_f<0x4E>(a); a = a + dpp_f<0xB1>(a); return a;
+}
+
+// ------------------------------------------------------------------------------------------------ S0 / S1: a four-layer stack
+// ADAPT = false: layers 0..3 (fixed taps, history in LDS); true: layers 4..7 (pitch-dependent taps, history in the global ring block)
+template <bool ADAPT>
+__device__ __forceinline__ void stack_role(const DecodeParams& p, const FastParams& f, const PipeParams& pp, const UttView& u, u64* X, const int urow) {
+    constexpr int C = 64, S = 256, L0 = ADAPT ? 4 : 0;
+    float* sm = SM; int* smi = SMI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 3, grp = lane >> 2;
+    const int Q = p.Q;
+    // LDS (floats): xbuf[5][64] | g[4][64] | xp[4][64] | hist[4][16][64] (fixed stack) | t0row[64] | misc[8] | wres[4 layers][4 tiles][1024]
+    constexpr int o_x = 0, o_g = 320, o_xp = 576, o_hist = 832, o_t0 = o_hist + 4 * 16 * 64, o_misc = o_t0 + 64, o_wres = (o_misc + 8 + 3) & ~3;
+    for (int i = tid; i < o_wres; i += PIPE_NT) sm[i] = 0.0f;
+    {   // residual 1x1 tiles of my layers -> LDS (layer 7's residual output is never used)
+        float4* dst = (float4*)(sm + o_wres);
+        for (int i = tid; i < 4 * 4 * 256; i += PIPE_NT) { const int l = i >> 10; dst[i] = p.wpk[f.w_res[L0 + l] + (i & 1023)]; }
+    }
+    // resident tiles: wave w owns tile w of the interleaved current / past matrices of each of its four layers
+    float4 wc[4][4], wq[4][4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        load_tile(wc[l], p.wpk, f.w_cur[L0 + l] + wave * 256, lane);
+        load_tile(wq[l], p.wpk, pp.w_past_il[L0 + l] + wave * 256, lane);
+    }
+    const int zrow = wave * 16 + grp, zch = zrow >> 1, zhalf = zrow & 1, znat = zhalf * C + zch;      // my row of every Z tile
+    float br[4];                                                 // residual biases of my rows (waves 0..3)
+    const int rrow = (wave & 3) * 16 + grp;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) br[l] = p.flat[pp.f_resb[L0 + l] + rrow];
+    float bsk[4][2];                                             // skip biases of my two skip tiles (fixed stack only)
+    if (!ADAPT) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bsk[l][j] = p.flat[pp.f_skipb[l] + (wave + 8 * j) * 16 + grp];
+    }
+    const float cbias = (!ADAPT && tid < C) ? p.flat[p.causal_b + tid] : 0.0f;
+    const int Ttot = u.n0 + u.n_samples;
+    __syncthreads();
+    if (Ttot < 3) return;
+    float pdv[4], auxv[4];                                       // past-tap dots / aux terms of the coming step, per layer, for my row
+    auto prepare = [&](int t) {                                  // everything step t needs that does not depend on step t's own input
+        const int ut = aux_time(u, t);
+        int fr, j;
+        if (ut < 0) { fr = 0; j = 0; }
+        else if (p.U > 0) { fr = (int)((unsigned)ut / (unsigned)p.U); j = ut - fr * p.U; }
+        else { fr = ut; j = 0; }
+        const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f;
+        const float* pf = u.pproj + (size_t)fr * p.L * 2 * C;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) auxv[l] = __builtin_fmaf(wj, pf[(L0 + l) * 2 * C + znat], p.qb[(L0 + l) * 2 * C + znat]);
+        // past rows x_l[t - off] -> LDS xp
+        if (ADAPT) {
+            const int widx = t < u.n0 - 1 ? t - (u.n0 - 1) : 0;
+            if (tid < 4 * C) {
+                const int l = tid >> 6, c = tid & 63;
+                const RingDesc r = p.rings[L0 + l];
+                int off = tap_offset(r, u, ut, widx);
+                if (off < 1 || off >= r.len) { if (c == 0) atomicOr(p.status, 1); off = off < 1 ? 1 : r.len - 1; }
+                const int tp = t - off;
+                const int slot = tp >= 0 ? (int)((unsigned)tp % (unsigned)r.len) : tp + r.len;      // < 0: a never-written (zero) slot
+                sm[o_xp + l * C + c] = ld_agent(u.ring + r.base + (size_t)slot * C + c);
+            }
+        } else {
+            if (tid < 4 * C) {
+                const int l = tid >> 6, c = tid & 63;
+                const int tp = t - (1 << l);
+                sm[o_xp + l * C + c] = tp >= 1 ? sm[o_hist + (l * 16 + (tp & 15)) * C + c] : 0.0f;     // time 0 and before: zeros
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            float4 x[4]; rd4(x, sm + o_xp + l * C + 16 * q);
+            pdv[l] = red4(chunk16(wq[l], x));
+        }
+    };
+    prepare(1);
+    if (!ADAPT && tid == 0) { smi[o_misc] = u.known[0]; }        // s[t-1] of step 1
+    __syncthreads();
+    for (int t = 1; t + 1 < Ttot; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        const bool gen = t >= u.n0 - 1;                           // this step's output is a generated sample
+        // ---------------- A. this step's input
+        if (!ADAPT) {
+            if (wave == 0) {
+                float v;
+                if (t <= u.n0 - 1) {                              // known sample: two rows of the causal table from memory (qpnet.py:110-132)
+                    const int sp = smi[o_misc], sc = u.known[t];
+                    v = p.flat[p.causal_w + ((size_t)lane * Q + sp) * 2] + p.flat[p.causal_w + ((size_t)lane * Q + sc) * 2 + 1];
+                    if (lane == 0) smi[o_misc] = sc;
+                    if (t == u.n0 - 1) sm[o_t0 + lane] = p.flat[p.causal_w + ((size_t)lane * Q + sc) * 2];     // tap-0 row of the last known sample
+                } else {                                          // picked by P at step t-1: id + its tap-1 row + its tap-0 row (for the next step)
+                    const u64* nx = X + PX_NX;
+                    const float t1 = pwait(nx + 1 + lane, (unsigned)t, pp.abort, p.status);
+                    const float t0n = pwait(nx + 65 + lane, (unsigned)t, pp.abort, p.status);
+                    v = sm[o_t0 + lane] + t1;
+                    sm[o_t0 + lane] = t0n;
+                }
+                v = v + cbias;
+                sm[o_x + lane] = v;
+                sm[o_hist + (0 * 16 + (t & 15)) * C + lane] = v;
+            }
+            if (wave == 1 && lane == 0 && t > 1) pwait(X + PX_ACK, (unsigned)t, pp.abort, p.status);     // S1 took x4 of step t-1: the slot is free
+        } else {
+            if (wave == 0) {
+                const float v = pwait(X + PX_X4 + lane, tag, pp.abort, p.status);
+                sm[o_x + lane] = v;
+                const RingDesc r = p.rings[L0];
+                st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + lane, v);
+                if (lane == 0) pst(X + PX_ACK, tag, 0.0f);
+            }
+        }
+        __syncthreads();
+        // ---------------- B. four gated residual blocks, tiles resident
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            {
+                float4 x[4]; rd4(x, sm + o_x + l * C + 16 * q);
+                const float acc = red4(chunk16(wc[l], x));
+                const float z = (acc + pdv[l]) + auxv[l];
+                const float zo = dpp_f<0x104>(z);                 // row_shl:4 -> the tanh row of the same channel
+                if (q == 0 && !zhalf) {
+                    const float g = qgate(z, zo);
+                    sm[o_g + l * C + zch] = g;
+                    if (ADAPT && gen) pst(X + PX_G + l * C + zch, tag, g);
+                }
+            }
+            __syncthreads();
+            if (!(ADAPT && l == 3) && wave < 4) {                 // residual 1x1 (+ residual add): next layer's input
+                float4 w[4], x[4];
+                const float4* tp = (const float4*)(sm + o_wres) + (l * 4 + wave) * 256 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = tp[j * 64];
+                rd4(x, sm + o_g + l * C + 16 * q);
+                const float acc = red4(chunk16(w, x));
+                if (q == 0) {
+                    const float v = (acc + br[l]) + sm[o_x + l * C + rrow];
+                    if (!ADAPT && l == 3) pst(X + PX_X4 + rrow, tag, v);            // hand x_4 to the adaptive stack
+                    else {
+                        sm[o_x + (l + 1) * C + rrow] = v;
+                        if (ADAPT) { const RingDesc r = p.rings[L0 + l + 1]; st_agent(u.ring + r.base + (size_t)((unsigned)t % (unsigned)r.len) * C + rrow, v); }
+                        else sm[o_hist + ((l + 1) * 16 + (t & 15)) * C + rrow] = v;
+                    }
+                }
+            }
+            if (l < 3) __syncthreads();
+        }
+        // ---------------- C. off the critical path: skip rows of the fixed stack (streamed), then the coming step's past dots / aux terms
+        if (!ADAPT && gen) {
+            float acc2[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float4 w[4];
+                    load_tile(w, p.wpk, f.w_skip[l] + (wave + 8 * j) * 256, lane);
+                    acc2[j] = acc2[j] + (red4(chunk16(w, x)) + bsk[l][j]);
+                }
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pst(X + PX_ACCF + (wave + 8 * j) * 16 + grp, tag, acc2[j]);
+            }
+        }
+        if (ADAPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring rows have left the wave (workgroup-scope visibility across the barrier)
+        __syncthreads();
+        if (t + 2 < Ttot) prepare(t + 1);
+        if (tid == 0) smi[o_misc + 1] = __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (smi[o_misc + 1]) break;
+    }
+    (void)S; (void)urow;
+}
+
+// ------------------------------------------------------------------------------------------------ K: adaptive skip rows + post 1x1 #1
+__device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const FastParams& f, const PipeParams& pp, const UttView& u, u64* X) {
+    constexpr int C = 64, S = 256;
+    float* sm = SM; int* smi = SMI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 3, grp = lane >> 2, qs = lane & 15, grps = lane >> 4;
+    constexpr int o_g = 0, o_y1 = 256, o_misc = 512, o_sk = 520;          // o_sk: skip tiles of layers 4, 5 resident in LDS (128 KB)
+    for (int i = tid; i < 520; i += PIPE_NT) sm[i] = 0.0f;
+    {
+        float4* dst = (float4*)(sm + o_sk);
+        for (int i = tid; i < 2 * 16 * 256; i += PIPE_NT) { const int l = i >> 12; dst[i] = p.wpk[f.w_skip[4 + l] + (i & 4095)]; }
+    }
+    float4 w6[2][4], w7[2][4], wp1[8][4];                                 // layers 6, 7 and post 1x1 #1 resident in registers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { load_tile(w6[j], p.wpk, f.w_skip[6] + (wave + 8 * j) * 256, lane); load_tile(w7[j], p.wpk, f.w_skip[7] + (wave + 8 * j) * 256, lane); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) load_tile(wp1[j], p.wpk, f.w_p1 + (wave * 8 + j) * 256, lane);
+    float bsk[4][2], b1[8];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bsk[l][j] = p.flat[pp.f_skipb[4 + l] + (wave + 8 * j) * 16 + grp];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b1[j] = p.flat[pp.f_p1b + (wave * 8 + j) * 4 + grps];
+    const int Ttot = u.n0 + u.n_samples;
+    __syncthreads();
+    if (Ttot < 3) return;
+    for (int t = u.n0 - 1 > 1 ? u.n0 - 1 : 1; t + 1 < Ttot; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        float acc2[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (tid < C) sm[o_g + l * C + tid] = pwait(X + PX_G + l * C + tid, tag, pp.abort, p.status);
+            __syncthreads();
+            float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float d;
+                if (l < 2) {
+                    float4 w[4];
+                    const float4* tp = (const float4*)(sm + o_sk) + (l * 16 + wave + 8 * j) * 256 + lane;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) w[jj] = tp[jj * 64];
+                    d = red4(chunk16(w, x));
+                } else if (l == 2) d = red4(chunk16(w6[j], x));
+                else d = red4(chunk16(w7[j], x));
+                acc2[j] = acc2[j] + (d + bsk[l][j]);
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = (wave + 8 * j) * 16 + grp;
+                const float tot = pwait(X + PX_ACCF + row, tag, pp.abort, p.status) + acc2[j];     // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
+                sm[o_y1 + row] = tot > 0.0f ? tot : 0.0f;
+            }
+        }
+        __syncthreads();
+        {
+            float4 x[4]; rd4(x, sm + o_y1 + 16 * qs);
+            float pa[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = red16(chunk16(wp1[j], x));
+            if (qs == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float v = pa[j] + b1[j]; pst(X + PX_Y2 + (wave * 8 + j) * 4 + grps, tag, v > 0.0f ? v : 0.0f); }
+            }
+        }
+        if (tid == 0) smi[o_misc] = __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (smi[o_misc]) break;
+    }
+    (void)S;
+}
+
+// ------------------------------------------------------------------------------------------------ P: post 1x1 #2, pick, causal rows
+__device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const FastParams& f, const PipeParams& pp, const UttView& u, u64* X, const int urow) {
+    constexpr int C = 64;
+    float* sm = SM; int* smi = SMI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = lane & 15, grps = lane >> 4;
+    const int Q = p.Q;
+    constexpr int o_y2 = 0, o_lg = 256, o_misc = 512, o_tab = 520;       // tab: [2][Q][64]: tap-0 rows, then tap-1 rows, one row per class
+    for (int i = tid; i < 520; i += PIPE_NT) sm[i] = 0.0f;
+    for (int i = tid; i < 2 * Q * C; i += PIPE_NT) {
+        const int tp = i / (Q * C), r = i - tp * Q * C, s = r / C, c = r - s * C;
+        sm[o_tab + i] = p.flat[p.causal_w + ((size_t)c * Q + s) * 2 + tp];
+    }
+    float4 wp2[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) load_tile(wp2[j], p.wpk, f.w_p2 + (wave * 8 + j) * 256, lane);
+    float b2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b2[j] = p.flat[pp.f_p2b + (wave * 8 + j) * 4 + grps];
+    const int Ttot = u.n0 + u.n_samples;
+    __syncthreads();
+    if (Ttot < 3) return;
+    for (int t = u.n0 - 1 > 1 ? u.n0 - 1 : 1; t + 1 < Ttot; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        if (tid < 256) sm[o_y2 + tid] = pwait(X + PX_Y2 + tid, tag, pp.abort, p.status);
+        __syncthreads();
+        {
+            float4 x[4]; rd4(x, sm + o_y2 + 16 * qs);
+            float pa[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = red16(chunk16(wp2[j], x));
+            if (qs == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sm[o_lg + (wave * 8 + j) * 4 + grps] = pa[j] + b2[j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + i]; if (v > bv) { bv = v; bi = i; } }
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            const int i = t - (u.n0 - 1);
+            if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg, Q, p.seed, (unsigned)urow, (unsigned)i, lane);
+            int next = bi;
+            if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
+            // the next step's layer-0 input needs the tap-1 row of `next`; the step after that its tap-0 row
+            u64* nx = X + PX_NX;
+            pst(nx + 1 + lane, tag, sm[o_tab + (Q + next) * C + lane]);
+            pst(nx + 65 + lane, tag, sm[o_tab + next * C + lane]);
+            if (lane == 0) { pst(nx, tag, __int_as_float(next)); u.out[i] = bi; }
+            if (u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[o_lg + k];
+        }
+        if (tid == 64) smi[o_misc] = __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (smi[o_misc]) break;
+    }
+}
+
+__global__ __launch_bounds__(PIPE_NT) void k_decode_pipe(DecodeParams p, FastParams f, PipeParams pp) {
+    // 32 consecutive blocks serve 8 utterances; the four roles of an utterance are 8 blocks apart
+    const int chunk = blockIdx.x >> 5, within = blockIdx.x & 31, role = within >> 3, b = chunk * 8 + (within & 7);
+    if (b >= pp.nutt) return;
+    const UttView u = make_view(p, p.utts[b]);
+    u64* X = pp.xch + (size_t)b * PX_STRIDE;
+    if (role == 0) stack_role<false>(p, f, pp, u, X, b);
+    else if (role == 1) stack_role<true>(p, f, pp, u, X, b);
+    else if (role == 2) skip_post1_role(p, f, pp, u, X);
+    else post2_pick_role(p, f, pp, u, X, b);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool qpn_pipe_supported(const Geom& g) {
+    if (g.C != 64 || g.S != 256 || g.Q != 256 || g.LF != 4 || g.LA != 4 || g.L != 8) return false;
+    for (int l = 0; l < 8; ++l) if (g.layers[l].dilation != (1 << (l & 3)) || g.layers[l].adaptive != (l >= 4)) return false;
+    return true;
+}
+
+int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream) {
+    const Geom& g = h->g;
+    PipeParams pp; memset(&pp, 0, sizeof(pp));
+    for (int l = 0; l < 8; ++l) { pp.w_past_il[l] = h->w_past_il[l]; pp.f_resb[l] = (int)g.layers[l].resb; pp.f_skipb[l] = (int)g.layers[l].skipb; }
+    pp.f_p1b = (int)g.post1_b; pp.f_p2b = (int)g.post2_b; pp.nutt = B;
+    const size_t xwords = (size_t)PX_STRIDE * B + 16;
+    if (xwords > h->xch_cap) {
+        if (h->d_xch) (void)hipFree(h->d_xch);
+        h->d_xch = nullptr; h->xch_cap = 0;
+        if (hipMalloc(&h->d_xch, xwords * sizeof(unsigned long long)) != hipSuccess) { qpn_set_error("hipMalloc for the decode exchange buffers failed"); return QPN_ENOMEM; }
+        h->xch_cap = xwords;
+    }
+    pp.xch = h->d_xch + 16; pp.abort = (int*)h->d_xch;
+    QPN_HIP(hipMemsetAsync(h->d_xch, 0, xwords * sizeof(unsigned long long), stream));
+    const size_t lds = ((size_t)520 + 2 * 256 * 64) * sizeof(float);                 // role P (the causal tables) is the largest
+    static bool attr = false;
+    if (!attr) { QPN_HIP(hipFuncSetAttribute((const void*)k_decode_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    const int nchunks = (B + 7) / 8;
+    hipLaunchKernelGGL(k_decode_pipe, dim3(32 * nchunks), dim3(PIPE_NT), lds, stream, p, h->fp, pp);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}

@@ -272,3 +272,55 @@ def test_default_geometry_decode_vs_oracle(cuda, oracle):
     assert [len(o) for o in outs] == sorted(ns)
     for a, b in zip(outs, o_outs):
         np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------- four pipelined workgroups per utterance, resident weights (decode_pipe.hip)
+_PAPER_CASES = [c for c in DECODE_CASES if c[0].startswith("paper")]
+
+
+@pytest.mark.parametrize("case", _PAPER_CASES, ids=[c[0] for c in _PAPER_CASES])
+def test_pipelined_decode_matches_reference_streams(case, cuda, golden_dir, monkeypatch):
+    """QPN_DECODE_PIPE=1: stack / stack / skip+post1 / post2+pick on four CUs, hand-offs by tagged granules: the same
+    reference streams, bit for bit (B = 1 and B = 2 with unequal lengths, f0 x 0.5 / 1.5)."""
+    import torch
+    monkeypatch.setenv("QPN_DECODE_PIPE", "1")
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    d_arg = torch.from_numpy(bd).float().to(cuda) if extra else bd
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, d_arg, mode="argmax", extra_memory=extra)
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="pipelined HIP vs reference stream, row %d" % i)
+
+
+def test_pipelined_decode_worst_pitch_seeds_sampling_logits(cuda, golden_dir, oracle, monkeypatch):
+    import torch
+    from qpnet_amd.config import PAPER
+    monkeypatch.setenv("QPN_DECODE_PIPE", "1")
+    g = np.load(golden_dir + "/decode2.npz")
+    for case in DECODE_CASES2:
+        if case["cfg"] is not PAPER:
+            continue
+        cfg, name, extra = case["cfg"], case["name"], case["extra"]
+        m = util.build_model(cfg, synth.make_weights(cfg, case["wseed"]), cuda)
+        bx, bh, bd, ns = decode2_inputs(case)
+        d_arg = torch.from_numpy(bd).float().to(cuda) if extra else bd
+        outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), d_arg, mode="argmax", extra_memory=extra)
+        for i, s in enumerate(outs):
+            np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64), err_msg=name)
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 31)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(61 + b, 4 + (b % 3), 1.0) for b in range(11)])        # more than one 8-utterance chunk
+    m.sampling_seed = 4242
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="sampling")
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd, mode="sampling", seed=4242)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+    x, h, d, n = synth.decode_inputs(cfg, 4, 5, 1.0)
+    teacher = np.random.RandomState(9).randint(0, 256, size=n).astype(np.int64)
+    out, logits = m._stream_logits(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), d[None], torch.from_numpy(teacher[None]), n)
+    r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True)
+    assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))

@@ -25,3 +25,11 @@ else:
         run(PAPER, 1, 100, "paper coop G=" + G)
     os.environ.pop("QPN_DECODE_COOP")
     run(PAPER, 1, 100, "paper single-CU kernel")
+if which == "pipe":
+    os.environ["QPN_DECODE_PIPE"] = "1"
+    run(PAPER, 1, 300, "paper pipelined (4 CUs/utterance)")
+    run(PAPER, 20, 300, "paper pipelined (4 CUs/utterance)")
+    run(PAPER, 64, 300, "paper pipelined (4 CUs/utterance)")
+    os.environ["QPN_DECODE_PIPE"] = "0"
+    run(PAPER, 1, 300, "paper single-CU kernel")
+    run(PAPER, 20, 300, "paper single-CU kernel")
