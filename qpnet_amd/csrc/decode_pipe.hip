@@ -1,16 +1,16 @@
 // decode_pipe.hip -- layer-PIPELINED autoregressive decode for the paper-size QPNet (C=64, S=256, Q=256, 4 fixed + 4
-// pitch-adaptive layers): four workgroups (four CUs) per utterance, every weight tile that sits on the critical path RESIDENT
+// pitch-adaptive layers): five workgroups (five CUs) per utterance, every weight tile that sits on the critical path RESIDENT
 // in registers / LDS.  Replaces QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), same arithmetic spec as
 // decode.hip (bit-identical streams).
 //
 // Why: one CU per utterance (decode.hip) re-streams the 1.7 MB of weight tiles from L2 for every generated sample and is
 // bounded by its 64 B/clk L1 port at 11.65 us per sample.  Four CUs hold ALL tiles (512 KB of VGPRs + 160 KB of LDS each):
-//   S0  fixed layers 0-3: current- and past-tap tiles in VGPRs (8 waves x 32 KB), residual tiles in LDS; their skip rows
-//       are streamed AFTER x_4 has been handed on (off the critical path) and travel as the fixed-stack skip sum accF
+//   S0  fixed layers 0-3: current-tap tiles in VGPRs, residual tiles in LDS, past-tap tiles streamed while it waits for its input
+//   K0  skip rows of layers 0-3 (all tiles in VGPRs), fed with S0's gate vectors: the fixed-stack skip sum accF, off the critical path
 //   S1  adaptive layers 4-7: same residency; the pitch-dependent history rings stay in a private, L2-resident global block
 //   K   skip rows of layers 4-7 (tiles of layers 4, 5 in LDS, of 6, 7 in VGPRs) + post 1x1 #1 (VGPRs)
 //   P   post 1x1 #2 (VGPRs), argmax / sampling, the two causal-conv table rows of the picked sample (tables in LDS)
-// A generated sample travels S0 -> S1 -> K -> P -> S0: four hand-offs (0.44 us each inside an XCD, 0.55 across:
+// A generated sample travels S0 -> S1 -> K -> P -> S0 (S0 -> K0 -> K beside it): four hand-offs on the critical path (0.44 us each inside an XCD, 0.55 across:
 // profiles/r02_hop_microbench.txt) instead of 1.7 MB through one L1 port.  Hand-offs are data-tagged 8-byte granules
 // {tag = step + 1, value} written with agent-scope (sc1) stores and polled with agent-scope loads (CDNA4 guide, Guideline 16
 // R2): correct for any placement; blocks g, g+8, g+16, g+24 serve one utterance so that round-robin dispatch puts them on
@@ -28,10 +28,11 @@ typedef unsigned long long u64;
 #define PX_X4 0          // [64]   S0 -> S1   layer-4 input
 #define PX_ACK 64        // [1]    S1 -> S0   x4 of step t consumed (flow control while S0 is not throttled by P: warm-up)
 #define PX_G 72          // [4][64] S1 -> K   gate vectors of layers 4..7
-#define PX_ACCF 328      // [256]  S0 -> K    skip sum of the fixed stack
+#define PX_ACCF 328      // [256]  K0 -> K    skip sum of the fixed stack
 #define PX_Y2 584        // [256]  K  -> P    post 1x1 #1 output
 #define PX_NX 840        // [1 + 64 + 64] P -> S0  picked sample, its tap-1 table row, its tap-0 table row
-#define PX_STRIDE 976
+#define PX_G0 976        // [4][64] S0 -> K0  gate vectors of layers 0..3
+#define PX_STRIDE 1232
 
 struct PipeParams {
     u64* xch; int* abort;
@@ -88,24 +89,14 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         for (int i = tid; i < 4 * 4 * 256; i += PIPE_NT) { const int l = i >> 10; dst[i] = p.wpk[f.w_res[L0 + l] + (i & 1023)]; }
     }
     // resident tiles: wave w owns tile w of the interleaved current / past matrices of each of its four layers
-    float4 wc[4][4], wq[4][4];
+    float4 wc[4][4];          // (the past-tap tiles are needed only by prepare(), which runs while the workgroup waits: they stream from L2)
 #pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        load_tile(wc[l], p.wpk, f.w_cur[L0 + l] + wave * 256, lane);
-        load_tile(wq[l], p.wpk, pp.w_past_il[L0 + l] + wave * 256, lane);
-    }
+    for (int l = 0; l < 4; ++l) load_tile(wc[l], p.wpk, f.w_cur[L0 + l] + wave * 256, lane);
     const int zrow = wave * 16 + grp, zch = zrow >> 1, zhalf = zrow & 1, znat = zhalf * C + zch;      // my row of every Z tile
     float br[4];                                                 // residual biases of my rows (waves 0..3)
     const int rrow = (wave & 3) * 16 + grp;
 #pragma unroll
     for (int l = 0; l < 4; ++l) br[l] = p.flat[pp.f_resb[L0 + l] + rrow];
-    float bsk[4][2];                                             // skip biases of my two skip tiles (fixed stack only)
-    if (!ADAPT) {
-#pragma unroll
-        for (int l = 0; l < 4; ++l)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bsk[l][j] = p.flat[pp.f_skipb[l] + (wave + 8 * j) * 16 + grp];
-    }
     const float cbias = (!ADAPT && tid < C) ? p.flat[p.causal_b + tid] : 0.0f;
     const int Ttot = u.n0 + u.n_samples;
     __syncthreads();
@@ -143,8 +134,10 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         __syncthreads();
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            float4 x[4]; rd4(x, sm + o_xp + l * C + 16 * q);
-            pdv[l] = red4(chunk16(wq[l], x));
+            float4 x[4], wq[4];
+            load_tile(wq, p.wpk, pp.w_past_il[L0 + l] + wave * 256, lane);
+            rd4(x, sm + o_xp + l * C + 16 * q);
+            pdv[l] = red4(chunk16(wq, x));
         }
     };
     prepare(1);
@@ -165,9 +158,8 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
                 } else {                                          // picked by P at step t-1: id + its tap-1 row + its tap-0 row (for the next step)
                     const u64* nx = X + PX_NX;
                     const float t1 = pwait(nx + 1 + lane, (unsigned)t, pp.abort, p.status);
-                    const float t0n = pwait(nx + 65 + lane, (unsigned)t, pp.abort, p.status);
                     v = sm[o_t0 + lane] + t1;
-                    sm[o_t0 + lane] = t0n;
+                    sm[o_t0 + lane] = pwait(nx + 65 + lane, (unsigned)t, pp.abort, p.status);      // (stored before the tap-1 row: normally no spin)
                 }
                 v = v + cbias;
                 sm[o_x + lane] = v;
@@ -183,7 +175,7 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
                 if (lane == 0) pst(X + PX_ACK, tag, 0.0f);
             }
         }
-        __syncthreads();
+        wg_barrier();
         // ---------------- B. four gated residual blocks, tiles resident
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
@@ -195,19 +187,25 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
                 if (q == 0 && !zhalf) {
                     const float g = qgate(z, zo);
                     sm[o_g + l * C + zch] = g;
-                    if (ADAPT && gen) pst(X + PX_G + l * C + zch, tag, g);
+                    if (gen) pst(X + (ADAPT ? PX_G : PX_G0) + l * C + zch, tag, g);
                 }
             }
-            __syncthreads();
-            if (!(ADAPT && l == 3) && wave < 4) {                 // residual 1x1 (+ residual add): next layer's input
-                float4 w[4], x[4];
+            // operands of the residual phase that do not depend on the gate: requested before the barrier
+            float4 wr4[4]; float xres = 0.0f;
+            const bool do_res = !(ADAPT && l == 3) && wave < 4;
+            if (do_res) {
                 const float4* tp = (const float4*)(sm + o_wres) + (l * 4 + wave) * 256 + lane;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = tp[j * 64];
+                for (int j = 0; j < 4; ++j) wr4[j] = tp[j * 64];
+                xres = sm[o_x + l * C + rrow];
+            }
+            wg_barrier();                                         // LDS only: the hand-off stores stay in flight
+            if (do_res) {                                         // residual 1x1 (+ residual add): next layer's input
+                float4 x[4];
                 rd4(x, sm + o_g + l * C + 16 * q);
-                const float acc = red4(chunk16(w, x));
+                const float acc = red4(chunk16(wr4, x));
                 if (q == 0) {
-                    const float v = (acc + br[l]) + sm[o_x + l * C + rrow];
+                    const float v = (acc + br[l]) + xres;
                     if (!ADAPT && l == 3) pst(X + PX_X4 + rrow, tag, v);            // hand x_4 to the adaptive stack
                     else {
                         sm[o_x + (l + 1) * C + rrow] = v;
@@ -216,26 +214,9 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
                     }
                 }
             }
-            if (l < 3) __syncthreads();
+            if (l < 3) wg_barrier();
         }
-        // ---------------- C. off the critical path: skip rows of the fixed stack (streamed), then the coming step's past dots / aux terms
-        if (!ADAPT && gen) {
-            float acc2[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (int l = 0; l < 4; ++l) {
-                float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float4 w[4];
-                    load_tile(w, p.wpk, f.w_skip[l] + (wave + 8 * j) * 256, lane);
-                    acc2[j] = acc2[j] + (red4(chunk16(w, x)) + bsk[l][j]);
-                }
-            }
-            if (q == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pst(X + PX_ACCF + (wave + 8 * j) * 16 + grp, tag, acc2[j]);
-            }
-        }
+        // ---------------- C. off the critical path: the coming step's past-tap dots / aux terms
         if (ADAPT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring rows have left the wave (workgroup-scope visibility across the barrier)
         __syncthreads();
         if (t + 2 < Ttot) prepare(t + 1);
@@ -322,6 +303,50 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
     (void)S;
 }
 
+// ------------------------------------------------------------------------------------------------ K0: skip rows of the fixed stack
+// (a CU of its own: the fixed stack's skip sum is needed only when the adaptive stack has finished, but computing it inside S0
+// either delays x_4 or arrives late at K -- measured 0.9 us of stall per sample)
+__device__ __forceinline__ void skip_fixed_role(const DecodeParams& p, const FastParams& f, const PipeParams& pp, const UttView& u, u64* X) {
+    constexpr int C = 64;
+    float* sm = SM; int* smi = SMI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 3, grp = lane >> 2;
+    constexpr int o_g = 0, o_misc = 256;
+    for (int i = tid; i < 264; i += PIPE_NT) sm[i] = 0.0f;
+    float4 wsk[4][2][4];                                          // two skip tiles per wave per layer, resident (128 VGPRs)
+    float bsk[4][2];
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            load_tile(wsk[l][j], p.wpk, f.w_skip[l] + (wave + 8 * j) * 256, lane);
+            bsk[l][j] = p.flat[pp.f_skipb[l] + (wave + 8 * j) * 16 + grp];
+        }
+    const int Ttot = u.n0 + u.n_samples;
+    __syncthreads();
+    if (Ttot < 3) return;
+    for (int t = u.n0 - 1 > 1 ? u.n0 - 1 : 1; t + 1 < Ttot; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        float acc2[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (tid < C) sm[o_g + l * C + tid] = pwait(X + PX_G0 + l * C + tid, tag, pp.abort, p.status);
+            wg_barrier();
+            float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc2[j] = acc2[j] + (red4(chunk16(wsk[l][j], x)) + bsk[l][j]);
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pst(X + PX_ACCF + (wave + 8 * j) * 16 + grp, tag, acc2[j]);
+        }
+        if (tid == 0) smi[o_misc] = __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (smi[o_misc]) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ P: post 1x1 #2, pick, causal rows
 __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const FastParams& f, const PipeParams& pp, const UttView& u, u64* X, const int urow) {
     constexpr int C = 64;
@@ -361,9 +386,19 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
         }
         __syncthreads();
         if (wave == 0) {
-            float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + i]; if (v > bv) { bv = v; bi = i; } }
-            for (int sft = 32; sft >= 1; sft >>= 1) {
+            float bv; int bi;
+            {   // lane owns four consecutive classes (one ds_read_b128); lowest index among maxima
+                const float4 v4 = *(const float4*)(sm + o_lg + 4 * lane);
+                bv = v4.x; bi = 4 * lane;
+                if (v4.y > bv) { bv = v4.y; bi = 4 * lane + 1; }
+                if (v4.z > bv) { bv = v4.z; bi = 4 * lane + 2; }
+                if (v4.w > bv) { bv = v4.w; bi = 4 * lane + 3; }
+            }
+#define PIPE_AMAX(CTRL) { const float ov = dpp_f<CTRL>(bv); const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true); \
+                          if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
+            PIPE_AMAX(0xB1) PIPE_AMAX(0x4E) PIPE_AMAX(0x124) PIPE_AMAX(0x128)       // within rows of 16 lanes: quad perms, row rotations
+#undef PIPE_AMAX
+            for (int sft = 16; sft <= 32; sft <<= 1) {                               // across the four rows
                 const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
@@ -373,8 +408,8 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
             if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
             // the next step's layer-0 input needs the tap-1 row of `next`; the step after that its tap-0 row
             u64* nx = X + PX_NX;
-            pst(nx + 1 + lane, tag, sm[o_tab + (Q + next) * C + lane]);
             pst(nx + 65 + lane, tag, sm[o_tab + next * C + lane]);
+            pst(nx + 1 + lane, tag, sm[o_tab + (Q + next) * C + lane]);
             if (lane == 0) { pst(nx, tag, __int_as_float(next)); u.out[i] = bi; }
             if (u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[o_lg + k];
         }
@@ -385,15 +420,16 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
 }
 
 __global__ __launch_bounds__(PIPE_NT) void k_decode_pipe(DecodeParams p, FastParams f, PipeParams pp) {
-    // 32 consecutive blocks serve 8 utterances; the four roles of an utterance are 8 blocks apart
-    const int chunk = blockIdx.x >> 5, within = blockIdx.x & 31, role = within >> 3, b = chunk * 8 + (within & 7);
+    // 40 consecutive blocks serve 8 utterances; the five roles of an utterance are 8 blocks apart (one XCD under round-robin dispatch)
+    const int chunk = blockIdx.x / 40, within = blockIdx.x - chunk * 40, role = within >> 3, b = chunk * 8 + (within & 7);
     if (b >= pp.nutt) return;
     const UttView u = make_view(p, p.utts[b]);
     u64* X = pp.xch + (size_t)b * PX_STRIDE;
     if (role == 0) stack_role<false>(p, f, pp, u, X, b);
     else if (role == 1) stack_role<true>(p, f, pp, u, X, b);
     else if (role == 2) skip_post1_role(p, f, pp, u, X);
-    else post2_pick_role(p, f, pp, u, X, b);
+    else if (role == 3) post2_pick_role(p, f, pp, u, X, b);
+    else skip_fixed_role(p, f, pp, u, X);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -421,7 +457,7 @@ int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t st
     static bool attr = false;
     if (!attr) { QPN_HIP(hipFuncSetAttribute((const void*)k_decode_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     const int nchunks = (B + 7) / 8;
-    hipLaunchKernelGGL(k_decode_pipe, dim3(32 * nchunks), dim3(PIPE_NT), lds, stream, p, h->fp, pp);
+    hipLaunchKernelGGL(k_decode_pipe, dim3(40 * nchunks), dim3(PIPE_NT), lds, stream, p, h->fp, pp);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }

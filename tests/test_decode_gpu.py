@@ -11,8 +11,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", DECODE_CASES, ids=[c[0] for c in DECODE_CASES])
-def test_decode_matches_reference_streams(case, cuda, golden_dir, oracle):
+def test_decode_matches_reference_streams(case, cuda, golden_dir, oracle, monkeypatch):
+    """one workgroup (one CU) per utterance: k_decode_fast / k_decode (the pipelined default of the paper-size geometry has
+    its own tests below)"""
     import torch
+    monkeypatch.setenv("QPN_DECODE_PIPE", "0")
     name, cfg, wseed, utts, extra = case
     g = np.load(golden_dir + "/decode.npz")
     flat = synth.make_weights(cfg, wseed)
