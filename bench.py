@@ -171,7 +171,21 @@ def run_decode(args, rank, local, world):
     tr = (measured_traffic() or {})
     hbm_meas = tr.get("decode", {}).get("hbm_bytes_per_sample")
     us = k_ms * 1e3 / max(ns)                      # device time per generated sample of one utterance (rows run concurrently)
-    floor = 11.65                                  # profiles/r01_l2_stream_floor.txt: one CU re-streaming the 1.7 MB of tiles from L2
+    pipelined = B <= 48 and os.environ.get("QPN_DECODE_PIPE", "1") != "0"
+    if pipelined:
+        # five CUs per utterance, weights resident: per sample 4 hand-offs (0.44 us each inside an XCD) + 22 dependent stages
+        # (LDS write -> barrier -> LDS read -> 16-FMA chain, 0.205 us each): profiles/r02_hop_microbench.txt
+        floor, kernel, cus = 4 * 0.44 + 22 * 0.205, "k_decode_pipe", 5 * B
+        bound = "latency (4 cross-CU hand-offs + 22 dependent matvec stages per sample)"
+        note = ("five persistent workgroups (five CUs) per utterance -- fixed stack, adaptive stack, fixed-stack skip, skip + post-1, post-2 + pick -- "
+                "every critical-path weight tile resident in VGPRs / LDS, hand-offs by 8-byte {tag, value} granules; floor = the "
+                "microbenchmarked cost of the hand-offs and dependent stages of one sample (profiles/r02_hop_microbench.txt); "
+                "HBM sees only the per-sample inputs/outputs (172 B algorithmic)")
+    else:
+        floor, kernel, cus = 11.65, "k_decode_fast" if cfg.n_resch <= 64 else "k_decode", B       # profiles/r01_l2_stream_floor.txt
+        bound = "latency(L2 port)"
+        note = ("one persistent workgroup (one CU) per utterance; weights (1.7 MB of tiles per sample) are re-streamed from L2 every "
+                "sample (floor: one CU's 64 B/clk port), HBM sees only the per-sample inputs/outputs (172 B algorithmic)")
     out = {
         "metric": "AR decode samples/sec/GPU @22.05kHz (greedy)" if world == 1 else "AR decode samples/sec @22.05kHz (greedy), all GPUs",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -180,18 +194,16 @@ def run_decode(args, rank, local, world):
         "config": {"workload": "config[3]: batch_fast_generate(argmax) of %d x %.1f s utterances per GPU, paper-size QPNet "
                                "(C=64,S=256,4F+4A), F=%d frames -> %d samples each" % (B, ns[0] / 22050.0, F, ns[0]),
                    "batch_per_gpu": B, "parallelism": "replicas x%d (no collective)" % world, "backend": BACKEND, "world_size": world},
-        # the decode loop is a serial chain of L+2 dependent matvec stages per sample: its bound is latency, not HBM
-        # (SURVEY 8d).  achieved / floor are microseconds per sample per utterance; frac = floor / achieved.
-        "roofline": {"bound": "latency(L2 port)", "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance",
+        # the decode loop is a serial chain of dependent matvec stages per sample: its bound is latency, not HBM.
+        # achieved / floor are microseconds per sample per utterance; frac = floor / achieved.
+        "roofline": {"bound": bound, "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance",
                      "frac": floor / us if us > 0 else 0.0,
                      "hbm_algorithmic": 172, "hbm_bytes_per_sample": hbm_meas,
                      "hbm_achieved_GBps": 172.0 * sum(ns) / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                      "traffic": hbm_meas * sum(ns) if hbm_meas else None,
                      "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per sample x samples of this launch)" % tr.get("_file"),
-                     "cus_busy": min(B, 256) / 256.0,
-                     "kernel": "k_decode_fast" if cfg.n_resch <= 64 else "k_decode", "kernel_ms": k_ms,
-                     "note": "one persistent workgroup (one CU) per utterance; weights (1.7 MB of tiles per sample) are re-streamed from "
-                             "L2 every sample, HBM sees only the per-sample inputs/outputs (172 B algorithmic)"},
+                     "cus_busy": min(cus, 256) / 256.0,
+                     "kernel": kernel, "kernel_ms": k_ms, "note": note},
     }
     if world == 1 and not args.no_cpu:
         # the reference decode script's default mode (softmax + draw, qpnet_decode.py:312-314): one untimed-in-`value` launch
@@ -462,7 +474,15 @@ def main():
             a3 = copy.copy(a2); a3.batch, a3.no_cpu = 1, True
             d1 = run_decode(a3, rank, local, world)
             out["decode"]["batch1"] = {"value": d1["value"], "unit": d1["unit"], "ms_per_step": d1["ms_per_step"],
-                                       "kernel_ms": d1["roofline"]["kernel_ms"]}
+                                       "kernel_ms": d1["roofline"]["kernel_ms"], "kernel": d1["roofline"]["kernel"]}
+            os.environ["QPN_DECODE_PIPE"] = "0"          # the one-CU-per-utterance kernel on the same workload, for comparison
+            try:
+                a4 = copy.copy(a2); a4.no_cpu = True; a4.steps, a4.warmup = 1, 0
+                d20 = run_decode(a4, rank, local, world)
+                out["decode"]["one_cu_per_utterance"] = {"value": d20["value"], "unit": d20["unit"], "us_per_sample_per_utterance": d20["roofline"]["achieved"],
+                                                         "kernel": d20["roofline"]["kernel"], "frac_of_l2_stream_floor": d20["roofline"]["frac"]}
+            finally:
+                os.environ.pop("QPN_DECODE_PIPE", None)
             if not args.no_cpu:
                 try:
                     out["default_geometry"] = run_default_geometry(local)

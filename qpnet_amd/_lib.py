@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqpnet_hip.so")
+LIB_PATH = os.environ.get("QPN_LIB") or os.path.join(_HERE, "libqpnet_hip.so")     # QPN_LIB: dev aid (build variants)
 _lib = None
 
 

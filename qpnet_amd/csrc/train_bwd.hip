@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
+            wave_gemm2<MT, QPN_PD2P>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<MT, 2>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
+            wave_gemm2<MT, QPN_PD2P>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
+            wave_gemm2<MT, QPN_PD2P>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;

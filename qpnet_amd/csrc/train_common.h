@@ -191,3 +191,18 @@ __device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float
     wave_b_preload<NJ, PD>(bq, Bp, NT, nts, K, lane);
     wave_gemm_run<MT, NJ, PD>(acc, A_lds, lda, bq, Bp, NT, nts, K, lane);
 }
+
+// The two-n-tile GEMMs (gate pre-activations, post-net): weight-fragment prefetch depth as a build-time knob (1 = one step of
+// lookahead, wave_gemm; > 1 = a ring of QPN_PD2 register sets, wave_gemm_deep).  QPN_PD2L for the layer kernels, QPN_PD2P for the post-net.
+#ifndef QPN_PD2L
+#define QPN_PD2L 1
+#endif
+#ifndef QPN_PD2P
+#define QPN_PD2P 1
+#endif
+template <int MT, int PD>
+__device__ __forceinline__ void wave_gemm2(f32x4 (&acc)[MT][2], const float* __restrict__ A_lds, int lda,
+                                           const float4* __restrict__ Bp, int NT, const int (&nts)[2], int K, int lane) {
+    if constexpr (PD <= 1) wave_gemm<MT, 2>(acc, A_lds, lda, Bp, NT, nts, K, lane);
+    else wave_gemm_deep<MT, 2, PD>(acc, A_lds, lda, Bp, NT, nts, K, lane);
+}

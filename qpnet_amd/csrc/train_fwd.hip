@@ -132,7 +132,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
         const int nts[2] = {cg, NCG + cg};
-        wave_gemm<MT, 2>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
+        wave_gemm2<MT, QPN_PD2L>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
         const int c = 16 * cg + (lane & 15);
         const float bs = bias1[c], bt = bias1[C + c];
 #pragma unroll
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         f32x4 acc[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
-        if (active) { const int nts[2] = {nt0, nt1}; wave_gemm<MT, 2>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
+        if (active) { const int nts[2] = {nt0, nt1}; wave_gemm2<MT, QPN_PD2P>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
         __syncthreads();                                         // every wave is done reading Gall before St overwrites it
         if (active) {
 #pragma unroll
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
             if (fits && l + 1 < L) gfetch(l + 1);
             if (active) {
                 const int nts[2] = {nt0, nt1};
-                wave_gemm<MT, 2>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
+                wave_gemm2<MT, QPN_PD2P>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
             }
         }
         if (active) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<MT, 2>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
+            wave_gemm2<MT, QPN_PD2P>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm<MT, 2>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
+            wave_gemm2<MT, QPN_PD2P>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
