@@ -32,22 +32,31 @@ __device__ __forceinline__ u64 gr_load(const u64* g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// every thread fetches its share of n granules of step `tag` into LDS
+// The first ceil(n / 256) waves fetch n granules of step `tag` into LDS: four granules per lane per sweep, re-read until every tag
+// matches (a few polling waves instead of one polling lane per granule: pollers next to a weight stream cost bandwidth)
 __device__ __forceinline__ void gather_vec(const u64* src, int n, unsigned tag, float* dst, int tid, int* abort, int* status) {
-    for (int i = tid; i < n; i += COOP_NT) {
-        u64 v = gr_load(src + i);
-        unsigned spins = 0;
-        while ((unsigned)(v >> 32) != tag) {
-            if (++spins > COOP_SPIN_LIMIT || ((spins & 255u) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                atomicOr(status, 4);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-            v = gr_load(src + i);
+    const int base = (tid >> 6) * 256 + (tid & 63);
+    if ((tid >> 6) * 256 >= n) return;
+    u64 v[4];
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + 64 * k;
+            v[k] = i < n ? gr_load(src + i) : ((u64)tag << 32);
+            ok &= (unsigned)(v[k] >> 32) == tag;
         }
-        dst[i] = __uint_as_float((unsigned)v);
+        if (__all(ok)) break;
+        if (++spins > COOP_SPIN_LIMIT || ((spins & 255u) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(status, 4);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = base + 64 * k; if (i < n) dst[i] = __uint_as_float((unsigned)v[k]); }
 }
 
 __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastParams f, CoopParams c, int b0) {
@@ -119,54 +128,54 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
         }
         __syncthreads();
         int xin = o_xa, xnext = o_xb;
+        const int npair = (2 * CB) / rpt, zt0 = (2 * c0) / rpt;
+        // the tiles of a phase's FIRST pass are requested before the wait that precedes the phase (they do not depend on it)
+        float4 wcN[4], wqN[4], wrN[4];
+        if (wave < npair) { load_tile(wcN, p.wpk, f.w_cur[0] + (zt0 + wave) * 256, lane); load_tile(wqN, p.wpk, c.w_past_il[0] + (zt0 + wave) * 256, lane); }
         for (int l = 0; l < L; ++l) {
             // ---------------- Z: pre-activations of my channels (current + past tap + aux), gate
-            {
-                const int npair = (2 * CB) / rpt, t0 = (2 * c0) / rpt;
-                for (int i = wave; i < npair; i += COOP_NW) {
-                    const int ti = t0 + i;
-                    float4 wc[4], wq[4], x[4], xp[4];
-                    load_tile(wc, p.wpk, f.w_cur[l] + ti * 256, lane);
-                    load_tile(wq, p.wpk, c.w_past_il[l] + ti * 256, lane);
-                    const float4* xv = (const float4*)(sm + xin + 16 * q);
-                    const float4* pv = (const float4*)(sm + o_xp + l * Cp + 16 * q);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { x[k] = xv[k]; xp[k] = pv[k]; }
-                    const float ac = tree_reduce(chunk16(wc, x), logR);
-                    const float ap = tree_reduce(chunk16(wq, xp), logR);
-                    const int row = ti * rpt + grp, ch = row >> 1, half = row & 1;
-                    const float z = (ac + ap) + sm[o_aux + l * 2 * CB + half * CB + (ch - c0)];
-                    const float zo = __shfl_down(z, R);           // the tanh row of the same channel
-                    if (q == 0 && !half) gr_store(X + c.o_g + (size_t)l * C + ch, tag, qgate(z, zo));
+            for (int i = wave; i < npair; i += COOP_NW) {
+                const int ti = zt0 + i;
+                float4 x[4], xp[4];
+                if (i != wave) {                              // (the first pass's tiles were requested before the wait)
+                    load_tile(wcN, p.wpk, f.w_cur[l] + ti * 256, lane);
+                    load_tile(wqN, p.wpk, c.w_past_il[l] + ti * 256, lane);
                 }
+                const float4* xv = (const float4*)(sm + xin + 16 * q);
+                const float4* pv = (const float4*)(sm + o_xp + l * Cp + 16 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { x[k] = xv[k]; xp[k] = pv[k]; }
+                const float ac = tree_reduce(chunk16(wcN, x), logR);
+                const float ap = tree_reduce(chunk16(wqN, xp), logR);
+                const int row = ti * rpt + grp, ch = row >> 1, half = row & 1;
+                const float z = (ac + ap) + sm[o_aux + l * 2 * CB + half * CB + (ch - c0)];
+                const float zo = __shfl_down(z, R);           // the tanh row of the same channel
+                if (q == 0 && !half) gr_store(X + c.o_g + (size_t)l * C + ch, tag, qgate(z, zo));
             }
+            const bool has_res = l + 1 < L;               // the last block's residual output is unused (qpnet.py:505)
+            const int nres = has_res ? CB / rpt : 0, nsk = SB / rpt;
+            if (wave < nres + nsk)
+                load_tile(wrN, p.wpk, wave < nres ? f.w_res[l] + (c0 / rpt + wave) * 256 : f.w_skip[l] + (s0 / rpt + (wave - nres)) * 256, lane);
             gather_vec(X + c.o_g + (size_t)l * C, C, tag, sm + o_g, tid, c.abort, p.status);
             __syncthreads();
             // ---------------- R: residual 1x1 rows of my channels (-> next layer's input), skip 1x1 rows of my slice
             {
-                const bool has_res = l + 1 < L;           // the last block's residual output is unused (qpnet.py:505)
-                const int nres = has_res ? CB / rpt : 0, nsk = SB / rpt;
                 float4 xg[4];
                 const float4* gv = (const float4*)(sm + o_g + 16 * q);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) xg[k] = gv[k];
                 for (int i = wave; i < nres + nsk; i += COOP_NW) {
-                    float4 w[4];
+                    if (i != wave) load_tile(wrN, p.wpk, i < nres ? f.w_res[l] + (c0 / rpt + i) * 256 : f.w_skip[l] + (s0 / rpt + (i - nres)) * 256, lane);
+                    const float acc = tree_reduce(chunk16(wrN, xg), logR);
                     if (i < nres) {
-                        const int ti = c0 / rpt + i;
-                        load_tile(w, p.wpk, f.w_res[l] + ti * 256, lane);
-                        const float acc = tree_reduce(chunk16(w, xg), logR);
-                        const int row = ti * rpt + grp;
+                        const int row = (c0 / rpt + i) * rpt + grp;
                         if (q == 0) {
                             const float v = (acc + p.flat[c.f_resb[l] + row]) + sm[xin + row];
                             const RingDesc rn = p.rings[l + 1];
                             gr_store(X + c.o_ring[l + 1] + (size_t)((unsigned)t % (unsigned)rn.len) * C + row, tag, v);
                         }
                     } else {
-                        const int ti = s0 / rpt + (i - nres);
-                        load_tile(w, p.wpk, f.w_skip[l] + ti * 256, lane);
-                        const float acc = tree_reduce(chunk16(w, xg), logR);
-                        const int row = ti * rpt + grp;
+                        const int row = (s0 / rpt + (i - nres)) * rpt + grp;
                         if (q == 0) {
                             const int a = o_acc + (f.adaptive[l] ? SB : 0) + (row - s0);
                             sm[a] = sm[a] + (acc + p.flat[c.f_skipb[l] + row]);
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                     }
                 }
                 if (has_res) {
+                    if (wave < npair) { load_tile(wcN, p.wpk, f.w_cur[l + 1] + (zt0 + wave) * 256, lane); load_tile(wqN, p.wpk, c.w_past_il[l + 1] + (zt0 + wave) * 256, lane); }
                     const RingDesc rn = p.rings[l + 1];
                     gather_vec(X + c.o_ring[l + 1] + (size_t)((unsigned)t % (unsigned)rn.len) * C, C, tag, sm + xnext, tid, c.abort, p.status);
                 }
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             const float tot = sm[o_acc + r] + sm[o_acc + SB + r];     // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
             gr_store(X + c.o_y1 + s0 + r, tag, tot > 0.0f ? tot : 0.0f);
         }
+        if (wave < SB / rpts) load_tile(wrN, p.wpk, f.w_p1 + (s0 / rpts + wave) * 256, lane);
         gather_vec(X + c.o_y1, S, tag, sm + o_y1, tid, c.abort, p.status);
         __syncthreads();
         {
@@ -195,13 +206,13 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             for (int k = 0; k < 4; ++k) xq[k] = yv[k];
             for (int i = wave; i < SB / rpts; i += COOP_NW) {
                 const int ti = s0 / rpts + i;
-                float4 w[4];
-                load_tile(w, p.wpk, f.w_p1 + ti * 256, lane);
-                const float acc = tree_reduce(chunk16(w, xq), logRs);
+                if (i != wave) load_tile(wrN, p.wpk, f.w_p1 + ti * 256, lane);
+                const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
                 if (qs == 0) { const float v = acc + p.flat[c.f_p1b + row]; gr_store(X + c.o_y2 + row, tag, v > 0.0f ? v : 0.0f); }
             }
         }
+        if (wave < QB / rpts) load_tile(wrN, p.wpk, f.w_p2 + (q0 / rpts + wave) * 256, lane);
         gather_vec(X + c.o_y2, S, tag, sm + o_y2, tid, c.abort, p.status);
         __syncthreads();
         {
@@ -211,9 +222,8 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             for (int k = 0; k < 4; ++k) xq[k] = yv[k];
             for (int i = wave; i < QB / rpts; i += COOP_NW) {
                 const int ti = q0 / rpts + i;
-                float4 w[4];
-                load_tile(w, p.wpk, f.w_p2 + ti * 256, lane);
-                const float acc = tree_reduce(chunk16(w, xq), logRs);
+                if (i != wave) load_tile(wrN, p.wpk, f.w_p2 + ti * 256, lane);
+                const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
                 if (qs == 0) gr_store(X + c.o_lg + row, tag, acc + p.flat[c.f_p2b + row]);
             }

@@ -763,6 +763,8 @@ __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
     }
 }
 
+void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
+
 // ------------------------------------------------------------------------------------------ launchers
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     hipLaunchKernelGGL(k_zero_dx, dim3(64, p.L, p.B), dim3(256), 0, stream, p, bw);
@@ -830,19 +832,66 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
             w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
             w.row0A[0] = w.row0B[0] = 0; w.R[0] = BL; w.tap_off[0] = -1;
             w.ncol_groups = S % 64 == 0 ? S / 64 : 1;
+            if (getenv("QPN_POST_WGRAD_GEMM") && Q % 32 == 0 && S % 32 == 0) {
+                // the 128 x 128 x 32 LDS-tiled time contraction of train_gemm.hip on the two 256-row outputs: measured 34 us SLOWER per
+                // step than the tile kernel at paper size (64 partial slabs leave each workgroup 10 K-chunks); kept as a knob
+                qpn_launch_post_wgrad_gemm(p, bw, st);
+            } else {
             w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
             ok = ok && wgrad2_any(w, nch, st);
             w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
             ok = ok && wgrad2_any(w, nch, st);
+            }
+        }
+    };
+    // layers [lo, hi) of a per-layer weight-gradient launch (blockIdx.y counts from lo)
+    auto subset = [&](Wg2 w, int lo, int hi) {
+        w.A += (size_t)lo * w.A_lstride; if (w.A2) w.A2 += (size_t)lo * w.A_lstride;
+        w.B1 += (size_t)lo * w.B_lstride; if (w.B2) w.B2 += (size_t)lo * w.B_lstride;
+        for (int i = 0; i + lo < hi; ++i) {
+            w.row0A[i] = w.row0A[lo + i]; w.row0B[i] = w.row0B[lo + i]; w.R[i] = w.R[lo + i]; w.goff[i] = w.goff[lo + i];
+            w.gbias[i] = w.gbias[lo + i]; w.tap_off[i] = w.tap_off[lo + i]; w.dil[i] = w.dil[lo + i];
+        }
+        w.nlayers = hi - lo;
+        return w;
+    };
+    // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
+    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st) {
+        if (lo >= hi) return;
+        Wg2 w = wbase;
+        {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
+            w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
+            w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
+            w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
+            for (int l = 0; l < L; ++l) {
+                const TrLayer& ly = p.layers[l];
+                w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
+                w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
+            }
+            ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
+        }
+        {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
+            w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
+            w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+            w.ncol_groups = wgrad_col_groups(w.M, w.N);
+            for (int l = 0; l < L; ++l) {
+                w.row0A[l] = w.row0B[l] = p.layers[l].s_out;
+                w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1; w.dil[l] = 0;
+            }
+            ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
         }
     };
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
     const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
+    // the side stream carries, under the layer backward: the skip / post-net weight gradients (ready after k_post_bwd) and, once the
+    // upper half of the stack has been differentiated, that half's dW1 / dWr (QPN_WGRAD_SPLIT = first layer of that half; L = none)
+    int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
+    if (const char* e = getenv("QPN_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= L) mid = v; }
+    if (!overlap) mid = L;
     if (overlap) {
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
-        QPN_HIP(hipEventRecord(ev_join, side));
     }
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
@@ -853,30 +902,16 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
             hipLaunchKernelGGL((k_layer_bwd<1>), dim3((rows + 15) / 16, B), dim3(256), lds1, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
         } else
         hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
+        if (overlap && l == mid && mid < L) {
+            QPN_HIP(hipEventRecord(bw.ev_mid, stream));
+            QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
+            launch_w1_wr(mid, L, side);
+        }
     }
+    if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
-    // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
+    launch_w1_wr(0, mid, stream);
     Wg2 w = wbase;
-    {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
-        w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
-        w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
-        w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
-        for (int l = 0; l < L; ++l) {
-            const TrLayer& ly = p.layers[l];
-            w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
-            w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
-        }
-        ok = ok && wgrad2_any(w, nch, stream);
-    }
-    {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
-        w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
-        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
-        w.ncol_groups = wgrad_col_groups(w.M, w.N);
-        for (int l = 0; l < L; ++l) {
-            w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1;
-        }
-        ok = ok && wgrad2_any(w, nch, stream);
-    }
     if (!overlap) launch_skip_post(stream);
     if (bw.g_cw >= 0) {   // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
         w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;

@@ -75,7 +75,7 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
     float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
     int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
-    hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream of the skip / post-net weight gradients (owned by TrainState)
+    hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
 };
 
 // K-major, zero-padded weight blocks of the GEMM path (train_gemm.hip; n_resch > 128): float offsets into `wp`

@@ -411,6 +411,18 @@ int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t st
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
 int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
 
+// post-net weight gradients dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0) (+ bias column sums) into the `nch` partial slabs;
+// also used by the tile path of the narrow geometries (train_bwd.hip), where these two are the only 256-row outputs
+void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+    TArgs a; memset(&a, 0, sizeof(a));
+    a.nb = p.B; a.nsplit = bw.nch; a.slab = bw.slab; a.gstage = bw.gstage; a.C = p.C; a.Ap = p.Ap;
+    a.M = p.Q; a.N = p.S; a.a = bw.dlogits; a.lda = p.Q; a.rowsA = p.BL; a.b1 = p.Y0; a.ldb = p.S; a.rowsB = p.BL; a.ldc = p.S;
+    a.R[0] = p.BL; a.goff[0] = bw.g_p2; a.gbias[0] = bw.g_bp2; a.tap_off[0] = -1;
+    launch_tn<BM_RELU>(a, 1, stream);
+    a.M = p.S; a.a = bw.DY0; a.lda = p.S; a.b1 = p.S0; a.goff[0] = bw.g_p1; a.gbias[0] = bw.g_bp1;
+    launch_tn<BM_RELU>(a, 1, stream);
+}
+
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
@@ -493,14 +505,7 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
         for (int l = 0; l < L; ++l) { a.row0A[l] = 0; a.row0B[l] = N1 - BL; a.R[l] = BL; a.goff[l] = bw.g_ws[l]; a.gbias[l] = l == 0 ? bw.g_bs : -1; a.tap_off[l] = -1; }
         launch_tn<BM_PLAIN>(a, L, stream);
     }
-    {   // post-net: dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0)
-        TArgs a = t;
-        a.M = Q; a.N = S; a.a = bw.dlogits; a.lda = Q; a.rowsA = BL; a.b1 = p.Y0; a.ldb = S; a.rowsB = BL; a.ldc = S;
-        a.R[0] = BL; a.goff[0] = bw.g_p2; a.gbias[0] = bw.g_bp2; a.tap_off[0] = -1;
-        launch_tn<BM_RELU>(a, 1, stream);
-        a.M = S; a.a = bw.DY0; a.lda = S; a.b1 = p.S0; a.goff[0] = bw.g_p1; a.gbias[0] = bw.g_bp1;
-        launch_tn<BM_RELU>(a, 1, stream);
-    }
+    qpn_launch_post_wgrad_gemm(p, bw, stream);
     qpn_prof_mark(PG_WGRAD, stream);
     return qpn_launch_grad_tail(p, bw, stream);
 }

@@ -33,7 +33,7 @@ struct TrainState {
     std::vector<int> h_gmap; int* d_gmap; float* d_gwp;   // its K-major weight blocks
     TrainGemm gm;
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
-    hipStream_t side; hipEvent_t ev_fork, ev_join;   // side stream for the weight gradients that overlap the layer backward
+    hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
 };
 
 // ---- per-group timing
@@ -116,7 +116,7 @@ static int train_init(qpn_handle* h) {
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
-    t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = nullptr;
+    t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -277,6 +277,7 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
     h->train = t;
     return QPN_OK;
 }
@@ -288,6 +289,7 @@ void qpn_train_destroy(TrainState* t) {
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->ev_mid) (void)hipEventDestroy(t->ev_mid);
     delete t;
 }
 
@@ -412,7 +414,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     TrainBwd& bw = t->bw;
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
-    bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join;
+    bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
 }
 

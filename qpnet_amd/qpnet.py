@@ -83,6 +83,10 @@ class QPNet(nn.Module):
         super().__init__()
         cfg = QPNetConfig(n_quantize, n_aux, n_resch, n_skipch, dilationF_depth, dilationF_repeat,
                           dilationA_depth, dilationA_repeat, kernel_size, upsampling_factor)
+        # unsupported geometries fail HERE, not at the first forward / decode (the library validates without a GPU)
+        import ctypes as _C
+        if _lib.lib().qpn_param_count(_C.byref(_lib.make_config(cfg))) < 0:
+            raise ValueError("qpnet_amd.QPNet: " + _lib.lib().qpn_last_error().decode("utf-8", "replace"))
         self.cfg = cfg
         self.n_quantize, self.n_aux, self.n_resch, self.n_skipch = n_quantize, n_aux, n_resch, n_skipch
         self.kernel_size, self.upsampling_factor = kernel_size, upsampling_factor
