@@ -19,51 +19,61 @@
 __device__ __forceinline__ float sigmoidf_(float z) { return __frcp_rn(1.0f + __expf(-z)); }
 __device__ __forceinline__ float tanhf_(float z) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * z)) - 1.0f; }
 
+// Elementwise over (row, 4 channels): every access is a coalesced 16-byte load / store, no per-row serialisation.
+//   items [0, N1*C/4)                : X0[n][c..c+3] = tap-0 row of class x[n] + tap-1 row of class x[n+1] + bias  (transposed table p.ct)
+//   items [.., + N1*Ap/4)            : upsampled aux features HUP[n][a..a+3]
+//   items [.., + N1*LA)              : pitch-dependent tap of adaptive layer i at row n (+ the class ids XC for the table gradient)
 __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     const int b = blockIdx.y;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per time row
-    const int lane = threadIdx.x & 63;
-    if (n >= p.N1) return;
-    const int C = p.C, Q = p.Q;
-    // causal conv on one-hot input == two table rows (tap 0 = older sample)
-    const int64_t xo = (int64_t)p.T - p.N0 + n;
-    int64_t s0 = p.x[(size_t)b * p.T + xo] % Q, s1 = p.x[(size_t)b * p.T + xo + 1] % Q;
-    if (s0 < 0) s0 += Q;
-    if (s1 < 0) s1 += Q;
-    if (lane == 0) { p.XC[(size_t)b * (p.N1 + 1) + n] = (int)s0; if (n == p.N1 - 1) p.XC[(size_t)b * (p.N1 + 1) + p.N1] = (int)s1; }
-    float* X0 = p.X + ((size_t)b * p.N1 + n) * C;
-    const float* r0 = p.ct + (size_t)s0 * C;                   // tap 0 row of class s0, tap 1 row of class s1
-    const float* r1 = p.ct + ((size_t)Q + s1) * C;
-    for (int c = lane; c < C; c += 64) {
-        float v = r0[c] + r1[c];
-        X0[c] = v + p.flat[p.causal_b + c];
-    }
-    // upsampled aux features, aligned at the END of h_up (negative hindex, qpnet.py:269-276)
-    float* hu = p.HUP + ((size_t)b * p.N1 + n) * p.Ap;
-    for (int a = lane; a < p.Ap; a += 64) {                  // any n_aux (one pass for the usual 39)
-        float v = 0.0f;
-        if (a < p.A) {
-            if (p.U > 0) {
-                const int64_t q = (int64_t)p.F * p.U - p.N1 + n;
-                const int64_t f = q / p.U; const int j = (int)(q - f * p.U);
-                v = p.h[((size_t)b * p.A + a) * p.F + f] * p.flat[p.up_w + j] + p.flat[p.up_b];
-            } else {
-                v = p.h[((size_t)b * p.A + a) * p.F + (p.F - p.N1 + n)];
+    const int C = p.C, Q = p.Q, N1 = p.N1, Ap = p.Ap;
+    const int C4 = C / 4, A4 = Ap / 4;
+    const int nX = N1 * C4, nH = N1 * A4;
+    int nA = 0;
+    for (int l = 0; l < p.L; ++l) nA += p.layers[l].adaptive;
+    const int total = nX + nH + N1 * (nA > 0 ? nA : 1);
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += gridDim.x * 256) {
+        if (it < nX) {
+            const int n = it / C4, c = (it - n * C4) * 4;
+            const int64_t xo = (int64_t)p.T - p.N0 + n;
+            int64_t s0 = p.x[(size_t)b * p.T + xo] % Q, s1 = p.x[(size_t)b * p.T + xo + 1] % Q;
+            if (s0 < 0) s0 += Q;
+            if (s1 < 0) s1 += Q;
+            const float4 r0 = *(const float4*)(p.ct + (size_t)s0 * C + c);               // tap 0 = older sample (qpnet.py:110-132)
+            const float4 r1 = *(const float4*)(p.ct + ((size_t)Q + s1) * C + c);
+            const float4 bb = *(const float4*)(p.flat + p.causal_b + c);
+            float4 v;
+            v.x = (r0.x + r1.x) + bb.x; v.y = (r0.y + r1.y) + bb.y; v.z = (r0.z + r1.z) + bb.z; v.w = (r0.w + r1.w) + bb.w;
+            *(float4*)(p.X + ((size_t)b * N1 + n) * C + c) = v;
+            if (c == 0) { p.XC[(size_t)b * (N1 + 1) + n] = (int)s0; if (n == N1 - 1) p.XC[(size_t)b * (N1 + 1) + N1] = (int)s1; }
+        } else if (it < nX + nH) {
+            // upsampled aux features, aligned at the END of h_up (negative hindex, qpnet.py:269-276)
+            const int i2 = it - nX, n = i2 / A4, a0 = (i2 - n * A4) * 4;
+            float v[4];
+            int64_t f = 0; int j = 0;
+            if (p.U > 0) { const int64_t q = (int64_t)p.F * p.U - N1 + n; f = q / p.U; j = (int)(q - f * p.U); }
+            else f = (int64_t)p.F - N1 + n;
+            const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f, ub = p.U > 0 ? p.flat[p.up_b] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = a0 + e;
+                float t = 0.0f;
+                if (a < p.A) { t = p.h[((size_t)b * p.A + a) * p.F + f]; if (p.U > 0) t = t * wj + ub; }
+                v[e] = t;
             }
-        }
-        hu[a] = v;
-    }
-    // pitch-dependent taps: N1 + rint(float32(-d*dil) + float32(idx)), idx = n - N1 (qpnet.py:595-600)
-    if (lane < p.L) {
-        const TrLayer ly = p.layers[lane];
-        if (ly.adaptive) {
-            const float dv = p.d[(size_t)b * p.Td + (p.Td - p.N1 + n)];
+            *(float4*)(p.HUP + ((size_t)b * N1 + n) * Ap + a0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (nA > 0) {
+            // pitch-dependent taps: N1 + rint(float32(-d*dil) + float32(idx)), idx = n - N1 (qpnet.py:595-600)
+            const int i3 = it - nX - nH, ia = i3 / N1, n = i3 - ia * N1;
+            int l = 0;
+            for (int k = 0, seen = 0; k < p.L; ++k) if (p.layers[k].adaptive) { if (seen == ia) { l = k; break; } ++seen; }
+            const TrLayer ly = p.layers[l];
+            const float dv = p.d[(size_t)b * p.Td + (p.Td - N1 + n)];
             const float dil = -dv * (float)ly.dilation;
-            const float s = __fadd_rn(dil, (float)(n - p.N1));
-            int tap = p.N1 + (int)rintf(s);
+            const float s = __fadd_rn(dil, (float)(n - N1));
+            int tap = N1 + (int)rintf(s);
             if (n >= ly.s_out && (tap < ly.s_in || tap > n)) { atomicOr(p.status, 1); }   // reference assert (qpnet.py:294)
-            tap = tap < 0 ? 0 : (tap >= p.N1 ? p.N1 - 1 : tap);
-            p.TAP[ly.tap_off + (size_t)b * p.N1 + n] = tap;
+            tap = tap < 0 ? 0 : (tap >= N1 ? N1 - 1 : tap);
+            p.TAP[ly.tap_off + (size_t)b * N1 + n] = tap;
         }
     }
 }
@@ -418,7 +428,9 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
 void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(k_train_prep, dim3((p.N1 + 3) / 4, p.B), dim3(256), 0, stream, p);
+    const long items = (long)p.N1 * (p.C / 4 + p.Ap / 4 + 8);
+    const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_train_prep, dim3(blocks, p.B), dim3(256), 0, stream, p);
 }
 
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
