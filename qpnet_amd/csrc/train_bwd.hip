@@ -765,9 +765,12 @@ __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
     const int b0 = ly.adaptive ? 0 : p.N1 - ly.dilation, b1 = p.N1;
     const size_t na = (size_t)(a1 - a0) * C / 4, nb = (size_t)(b1 > b0 ? b1 - b0 : 0) * C / 4;      // C % 16 == 0
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (size_t)gridDim.x * blockDim.x) {
+    // layer 0's blocks also clear the aux-feature gradient [N1][Ap] of this batch item (every layer adds to it)
+    const size_t nh = j == 0 ? (size_t)p.N1 * p.Ap / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nh; i += (size_t)gridDim.x * blockDim.x) {
         if (i < na) ((float4*)(A + (size_t)a0 * C))[i] = z;
-        else ((float4*)(Bq + (size_t)(b0 > 0 ? b0 : 0) * C))[i - na] = z;
+        else if (i < na + nb) ((float4*)(Bq + (size_t)(b0 > 0 ? b0 : 0) * C))[i - na] = z;
+        else ((float4*)(bw.DHUP + (size_t)b * p.N1 * p.Ap))[i - na - nb] = z;
     }
 }
 
@@ -810,7 +813,6 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
     if (lds_post > 160 * 1024 || lds_layer > 160 * 1024) { qpn_set_error("backward tiles do not fit LDS"); return QPN_EINVAL; }
     if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
-    QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
     qpn_launch_zero_dx(p, bw, stream);

@@ -476,9 +476,10 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
     return QPN_OK;
 }
 
-int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, hipStream_t stream) {
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream) {
     const int64_t rows = (int64_t)B * BL;
-    QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
+    // (the loss accumulator was cleared by this step's k_refresh; a CE call without a forward in front clears it itself)
+    if (!loss_cleared) QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
     const int rpw = 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
     hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw, status);
     qpn_prof_mark(PG_CE, stream);

@@ -426,7 +426,6 @@ void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStr
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
-    QPN_HIP(hipMemsetAsync(bw.DHUP, 0, (size_t)B * N1 * p.Ap * sizeof(float), stream));
     qpn_launch_zero_dx(p, bw, stream);
     {   // post-net backward: dY0 = (dlogits . W2) * (Y0 > 0); dS0 = (dY0 . W1) * (S0 > 0); DGS = dS0 . Ws
         GArgs g = gbase(p);

@@ -8,7 +8,7 @@
 #include <string.h>
 
 int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
-int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, hipStream_t stream);
+int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
@@ -28,6 +28,7 @@ struct TrainState {
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
     bool fwd_valid;
+    bool loss_clear;                          // the loss accumulator is zero (cleared by the forward's refresh kernel, consumed by one CE call)
     bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
     int* d_ctmap; float* d_ct;                // causal conv table [tap][class][C] and its gather map
     std::vector<int> h_gmap; int* d_gmap; float* d_gwp;   // its K-major weight blocks
@@ -73,6 +74,22 @@ __global__ void k_gather_f(const float* __restrict__ flat, const int* __restrict
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
 }
+// the per-step refresh of everything derived from the parameters, in ONE launch: weight blocks (fragment order or K-major), the
+// transposed causal table, the packed bias sums; also clears the status word and the loss accumulator of the coming step
+__global__ void k_refresh(const float* __restrict__ flat, const int* __restrict__ wmap, float* __restrict__ wout, int64_t nw,
+                          const int* __restrict__ ctmap, float* __restrict__ ct, int64_t nct,
+                          const int* __restrict__ bstart, const int* __restrict__ blist, float* __restrict__ bp, int nb,
+                          int* __restrict__ status, double* __restrict__ loss) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nw) { const int m = wmap[i]; wout[i] = m >= 0 ? flat[m] : 0.0f; return; }
+    i -= nw;
+    if (i < nct) { ct[i] = flat[ctmap[i]]; return; }
+    i -= nct;
+    if (i < nb) { float a = 0.f; for (int j = bstart[i]; j < bstart[i + 1]; ++j) a += flat[blist[j]]; bp[i] = a; return; }
+    i -= nb;
+    if (i < 16) status[i] = 0;
+    else if (i == 16) *loss = 0.0;
+}
 __global__ void k_bias_pack(const float* __restrict__ flat, const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { float a = 0.f; for (int j = start[i]; j < start[i + 1]; ++j) a += flat[list[j]]; out[i] = a; }
@@ -115,7 +132,7 @@ static int train_init(qpn_handle* h) {
     TrainState* t = new TrainState();
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
-    t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false;
+    t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
@@ -355,20 +372,17 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     p.TAP = t->d_tap; p.status = t->d_status;
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
-    if (t->use_gemm) {
-        const size_t ng = t->h_gmap.size();
-        hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_gmap, t->d_gwp, (int64_t)ng);
-    } else {
-        const size_t nmap = t->h_wmap.size();
-        hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_wmap, t->d_wp, (int64_t)nmap);
+    {
+        const int* wmap = t->use_gemm ? t->d_gmap : t->d_wmap;
+        float* wout = t->use_gemm ? t->d_gwp : t->d_wp;
+        const int64_t nw = (int64_t)(t->use_gemm ? t->h_gmap.size() : t->h_wmap.size()), nct = (int64_t)2 * g.Q * g.C;
+        const int64_t tot = nw + nct + t->n_bias + 17;
+        hipLaunchKernelGGL(k_refresh, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d_flat, wmap, wout, nw, t->d_ctmap, t->d_ct, nct,
+                           t->d_bstart, t->d_blist, t->d_bp, t->n_bias, t->d_status, t->d_loss);
+        p.ct = t->d_ct;
     }
-    { const size_t nct = (size_t)2 * g.Q * g.C;
-      hipLaunchKernelGGL(k_gather_f, dim3((unsigned)((nct + 255) / 256)), dim3(256), 0, stream, d_flat, t->d_ctmap, t->d_ct, (int64_t)nct); }
-    p.ct = t->d_ct;
-    hipLaunchKernelGGL(k_bias_pack, dim3((t->n_bias + 255) / 256), dim3(256), 0, stream, d_flat, t->d_bstart, t->d_blist, t->d_bp, t->n_bias);
-    QPN_HIP(hipMemsetAsync(t->d_status, 0, 64, stream));
     qpn_prof_mark(PG_PREP, stream);
-    t->fwd_valid = false;
+    t->fwd_valid = false; t->loss_clear = true;
     ++t->generation;
     rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, stream); if (rc) return rc;
     t->fwd_valid = true;
@@ -392,7 +406,8 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
     rc = train_init(h); if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_logits || !d_targets || B < 1 || BL < 1 || tgt_stride < BL) { qpn_set_error("bad ce_loss arguments"); return QPN_EINVAL; }
-    rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, h->train->d_status, stream); if (rc) return rc;
+    rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, h->train->d_status, h->train->loss_clear, stream); if (rc) return rc;
+    h->train->loss_clear = false;
     if (h_loss) {
         QPN_HIP(hipMemcpyAsync(h_loss, h->train->d_loss, sizeof(double), hipMemcpyDeviceToHost, stream));
         QPN_HIP(hipStreamSynchronize(stream));
