@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
     }
     if (lane == 0) part[wave] = lsum;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (double)rows);
+    // 64 accumulator slots (summed by the reader): one double atomic per workgroup on ONE address serialises at the memory side
+    if (threadIdx.x == 0) atomicAdd(loss + (blockIdx.x & 63), (part[0] + part[1] + part[2] + part[3]) / (double)rows);
 }
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
@@ -479,8 +480,8 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream) {
     const int64_t rows = (int64_t)B * BL;
     // (the loss accumulator was cleared by this step's k_refresh; a CE call without a forward in front clears it itself)
-    if (!loss_cleared) QPN_HIP(hipMemsetAsync(loss, 0, sizeof(double), stream));
-    const int rpw = 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
+    if (!loss_cleared) QPN_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(double), stream));
+    const int rpw = getenv("QPN_CE_RPW") ? atoi(getenv("QPN_CE_RPW")) : 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
     hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw, status);
     qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());

@@ -88,7 +88,7 @@ __global__ void k_refresh(const float* __restrict__ flat, const int* __restrict_
     if (i < nb) { float a = 0.f; for (int j = bstart[i]; j < bstart[i + 1]; ++j) a += flat[blist[j]]; bp[i] = a; return; }
     i -= nb;
     if (i < 16) status[i] = 0;
-    else if (i == 16) *loss = 0.0;
+    else if (i < 16 + 64) loss[i - 16] = 0.0;
 }
 __global__ void k_bias_pack(const float* __restrict__ flat, const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,7 +270,7 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_gsrc, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
-    QPN_HIP(hipMalloc(&t->d_loss, 64));
+    QPN_HIP(hipMalloc(&t->d_loss, 64 * sizeof(double)));
     if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -376,7 +376,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
         const int* wmap = t->use_gemm ? t->d_gmap : t->d_wmap;
         float* wout = t->use_gemm ? t->d_gwp : t->d_wp;
         const int64_t nw = (int64_t)(t->use_gemm ? t->h_gmap.size() : t->h_wmap.size()), nct = (int64_t)2 * g.Q * g.C;
-        const int64_t tot = nw + nct + t->n_bias + 17;
+        const int64_t tot = nw + nct + t->n_bias + 16 + 64;
         hipLaunchKernelGGL(k_refresh, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, d_flat, wmap, wout, nw, t->d_ctmap, t->d_ct, nct,
                            t->d_bstart, t->d_blist, t->d_bp, t->n_bias, t->d_status, t->d_loss);
         p.ct = t->d_ct;
@@ -409,8 +409,12 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
     rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, h->g.Q, d_dlogits, h->train->d_loss, h->train->d_status, h->train->loss_clear, stream); if (rc) return rc;
     h->train->loss_clear = false;
     if (h_loss) {
-        QPN_HIP(hipMemcpyAsync(h_loss, h->train->d_loss, sizeof(double), hipMemcpyDeviceToHost, stream));
+        double parts[64];
+        QPN_HIP(hipMemcpyAsync(parts, h->train->d_loss, sizeof(parts), hipMemcpyDeviceToHost, stream));
         QPN_HIP(hipStreamSynchronize(stream));
+        double sum = 0.0;
+        for (int i = 0; i < 64; ++i) sum += parts[i];
+        *h_loss = sum;
     }
     return QPN_OK;
 }
