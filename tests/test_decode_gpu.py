@@ -93,11 +93,12 @@ def test_sampling_mode_bitwise_vs_oracle(cfgname, cuda, oracle):
 
 def test_full_size_decode_properties(cuda, oracle):
     """BASELINE config[3]/[4] size (10 s @22.05 kHz = 2005 frames -> 220 549 samples, F0 x1.0 / x0.5 / x1.5 in one batch):
-    too long for the oracle end to end, so it is pinned by size-independent properties --
+    compared with the oracle over the full length (3 x 220 549 samples, bit-exact) and through size-independent properties --
       prefix:   an autoregressive stream does not depend on how long the utterance goes on, so the first samples of the 10 s
                 streams equal a 40-frame decode of the same features, which IS compared with the oracle bit by bit;
       batch:    a row's stream does not depend on its batch mates (alone == in the batch of three);
-      repeat:   two launches give identical streams; ordering = ascending length, ties in input order."""
+      repeat:   two launches give identical streams; ordering = ascending length, ties in input order;
+      kernels:  three independently written kernels (pipelined five-CU, one-CU, cooperative row-sliced) agree on every sample."""
     import torch
     from qpnet_amd.config import PAPER
     cfg = PAPER
@@ -126,6 +127,31 @@ def test_full_size_decode_properties(cuda, oracle):
     assert int(np.ceil(d[1]).max()) == maxd                 # the halved-F0 row sets the batch's maxd, so alone == in the batch
     alone = m.batch_fast_generate(xt[1:2], ht[1:2], [ns[1]], d[1:2], mode="argmax")[0]
     np.testing.assert_array_equal(alone, ys[1])
+    # independent implementations: the streams above come from the pipelined five-CU kernel (decode_pipe.hip); the one-CU
+    # kernel (decode.hip: different tiling, synchronisation and data flow, same arithmetic spec) must give the same 3 x 220 549
+    # samples, and so must the cooperative row-sliced kernel (decode_coop.hip) on the worst-pitch row
+    import os
+    try:
+        os.environ["QPN_DECODE_PIPE"] = "0"
+        ys3 = m.batch_fast_generate(xt, ht, list(ns), d, mode="argmax")
+        os.environ["QPN_DECODE_COOP"] = "4"
+        coop = m.batch_fast_generate(xt[1:2], ht[1:2], [ns[1]], d[1:2], mode="argmax")[0]
+    finally:
+        os.environ.pop("QPN_DECODE_PIPE", None); os.environ.pop("QPN_DECODE_COOP", None)
+    for a, b in zip(ys, ys3):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(coop, ys[1])
+    # and the oracle itself over the FULL 10 s of all three rows (the C port does ~40 k samples/s per core: one thread per row)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def full(i):
+        seed, _, fac = utts[i]
+        xs, hs, ds, n = synth.decode_inputs(cfg, F, seed, fac)
+        return oracle.decode(cfg, flat, hs, ds, xs, n, maxd=maxd)["samples"]
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        refs = list(ex.map(full, range(3)))
+    for i in range(3):
+        np.testing.assert_array_equal(ys[i], refs[i], err_msg="full 10 s stream of row %d vs the oracle" % i)
 
 
 @pytest.mark.parametrize("geo", [(128, 128, 2, 1, 2, 1), (96, 256, 2, 1, 1, 1), (64, 128, 3, 2, 2, 1)], ids=["C128", "C96", "F3x2"])
