@@ -148,7 +148,7 @@ def run_decode(args, rank, local, world):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
     m = m.to(dev).eval()
     B, F = args.batch, args.frames
-    utts = [(1000 * rank + 100 + b, F, 1.0) for b in range(B)]
+    utts = [(1000 * rank + 100 + b, F, getattr(args, "f0_factor", 1.0)) for b in range(B)]
     bx, bh, bd, ns = synth.decode_batch(cfg, utts)
     xb, hb = torch.from_numpy(bx).to(dev), torch.from_numpy(bh).to(dev)
 
@@ -452,6 +452,7 @@ def main():
                     help="all (default) = train step as the headline value (BASELINE config[1]) + a 'decode' object (config[3]) at N=1")
     ap.add_argument("--batch", type=int, default=20, help="utterances per GPU (reference decode_batch_size = 20, runQP.py:66)")
     ap.add_argument("--frames", type=int, default=2005, help="frames per utterance (2005 -> 10 s @22.05 kHz)")
+    ap.add_argument("--f0-factor", dest="f0_factor", type=float, default=1.0, help="F0 scaling of the decode workload (BASELINE config[4]: 0.5 / 1.5)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
@@ -475,6 +476,14 @@ def main():
             d1 = run_decode(a3, rank, local, world)
             out["decode"]["batch1"] = {"value": d1["value"], "unit": d1["unit"], "ms_per_step": d1["ms_per_step"],
                                        "kernel_ms": d1["roofline"]["kernel_ms"], "kernel": d1["roofline"]["kernel"]}
+            # BASELINE config[4]: F0-scaled decode (0.5x / 1.5x pitch: the per-sample dynamic dilation gather at its deepest / shallowest),
+            # one utterance per GPU
+            out["decode"]["f0_scaled"] = {}
+            for fac in (0.5, 1.5):
+                a5 = copy.copy(a3); a5.f0_factor = fac; a5.steps, a5.warmup = 1, 0
+                d5 = run_decode(a5, rank, local, world)
+                out["decode"]["f0_scaled"]["x%.1f" % fac] = {"value": d5["value"], "unit": d5["unit"], "us_per_sample_per_utterance": d5["roofline"]["achieved"],
+                                                              "kernel": d5["roofline"]["kernel"]}
             os.environ["QPN_DECODE_PIPE"] = "0"          # the one-CU-per-utterance kernel on the same workload, for comparison
             try:
                 a4 = copy.copy(a2); a4.no_cpu = True; a4.steps, a4.warmup = 1, 0

@@ -64,7 +64,8 @@ dec = [v for k, v in per.get("decode", {}).items() if "k_decode" in k]
 if dec:
     frames = 2005 if tag != "r01" else 600
     n = 20 * (frames * 110 - 1)
-    traffic["decode"] = {"kernel": "k_decode_fast<64,256,256,16>", "workload": "batch 20 x %d frames (20 x %d samples)" % (frames, frames * 110 - 1),
+    names = [k for k in per.get("decode", {}) if "k_decode" in k]
+    traffic["decode"] = {"kernel": ", ".join(names), "workload": "batch 20 x %d frames (20 x %d samples)" % (frames, frames * 110 - 1),
                          "hbm_bytes_per_sample": sum(v["hbm_bytes"] for v in dec) / n}
 wg = [(k, v) for k, v in per.get("train", {}).items() if "k_wgrad" in k]
 if wg:
