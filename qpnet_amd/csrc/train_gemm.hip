@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
         const int n = g.row_base + m;
         rtap[p] = any_tap ? (g.tap ? g.tap[(size_t)b * g.tap_bs + n] : n - g.dil) : 0;
     }
-    float4 ra[4], rb[4];
+    float4 ra[4];
     auto loadA = [&](int kc) {
         const int k0 = kc * GK;
         const int s = k0 < g.a_kend[0] ? 0 : k0 < g.a_kend[1] ? 1 : 2;
@@ -99,11 +99,13 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
             ra[p] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto loadB = [&](int kc) {
-        const float* bp = g.b + (size_t)(kc * GK + bk) * g.ldb + n0 + bn4;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) rb[p] = *(const float4*)(bp + (size_t)(8 * p) * g.ldb);
-    };
+    // (plain scalars instead of an array for the B staging registers: hipcc kept a captured float4[4] in scratch memory,
+    //  80 bytes per lane stored and re-loaded every chunk with an s_waitcnt right behind the loads)
+    const float* bsrc = g.b + (size_t)bk * g.ldb + n0 + bn4;
+    const size_t bstep8 = (size_t)8 * g.ldb, bchunk = (size_t)GK * g.ldb;
+    float4 rb0, rb1, rb2, rb3;
+#define G_LOADB(kc) { const float* bp_ = bsrc + (size_t)(kc) * bchunk; rb0 = *(const float4*)bp_; rb1 = *(const float4*)(bp_ + bstep8); \
+                      rb2 = *(const float4*)(bp_ + 2 * bstep8); rb3 = *(const float4*)(bp_ + 3 * bstep8); }
     auto put = [&](int buf) {
         float* ad = As + buf * (GM * G_LDA) + ar * G_LDA + ak4;
         float* bd = Bs + buf * (GK * G_LDB) + bk * G_LDB + bn4;
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
         for (int p = 0; p < 4; ++p) {
             float* d = ad + 32 * p * G_LDA;
             d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
-            *(float4*)(bd + 8 * p * G_LDB) = rb[p];
         }
+        *(float4*)(bd) = rb0; *(float4*)(bd + 8 * G_LDB) = rb1; *(float4*)(bd + 16 * G_LDB) = rb2; *(float4*)(bd + 24 * G_LDB) = rb3;
     };
     f32x16 acc[4];
 #pragma unroll
@@ -120,21 +122,29 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int nk = g.K / GK;
-    if (nk > 0) { loadA(0); loadB(0); put(0); }
+    rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nk > 0) { loadA(0); G_LOADB(0); put(0); }
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const bool more = kc + 1 < nk;
-        if (more) { loadA(kc + 1); loadB(kc + 1); }           // in flight under this chunk's MFMAs
+        if (more) { loadA(kc + 1); G_LOADB(kc + 1); }         // in flight under this chunk's MFMAs
         const float* A = As + (kc & 1) * (GM * G_LDA) + (32 * wave + (lane & 31)) * G_LDA + (lane >> 5);
         const float* Bq = Bs + (kc & 1) * (GK * G_LDB) + (lane >> 5) * G_LDB + (lane & 31);
+        // fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks issue (one step of lookahead in registers)
+        float an = A[0], bn0 = Bq[0], bn1 = Bq[32], bn2 = Bq[64], bn3 = Bq[96];
 #pragma unroll
         for (int ks = 0; ks < GK / 2; ++ks) {
-            const float a = A[2 * ks];
-            const float b0 = Bq[2 * ks * G_LDB], b1 = Bq[2 * ks * G_LDB + 32], b2 = Bq[2 * ks * G_LDB + 64], b3 = Bq[2 * ks * G_LDB + 96];
+            const float a = an, b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
+            if (ks + 1 < GK / 2) {
+                an = A[2 * (ks + 1)];
+                bn0 = Bq[2 * (ks + 1) * G_LDB]; bn1 = Bq[2 * (ks + 1) * G_LDB + 32]; bn2 = Bq[2 * (ks + 1) * G_LDB + 64]; bn3 = Bq[2 * (ks + 1) * G_LDB + 96];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) put((kc + 1) & 1);
         __syncthreads();
@@ -160,6 +170,39 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
         }
         return;
     }
+    if (EPI == EP_DZ) {
+        // dg = dXout.Wr^T + skip-path part (rows of the last batch_length only); dz = dg * gate'.  Branch-free, the 3 x 16 operand
+        // loads of a column batch in flight together (a per-element branch around the skip-path load serialised them: 34 TFLOP/s)
+        const float* sgp = g.e[0] + (size_t)b * g.e_bs; const float* thp = g.e[1] + (size_t)b * g.e_bs;
+        const float* dgp = g.e3 + (size_t)b * g.e3_bs + g.e3_col0;
+        float* op = g.o[0] + (size_t)b * g.o_bs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 32 * j + cl;
+            if (n >= g.N) continue;
+            float sg[16], th[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq; m = m < g.M ? m : g.M - 1;
+                const int row = g.e_row0 + m;
+                const size_t eo = (size_t)row * g.e_ld + n;
+                sg[r] = sgp[eo]; th[r] = thp[eo];
+                const int wr = row - g.e3_rowmin;
+                const float t = dgp[(size_t)(wr > 0 ? wr : 0) * g.e3_ld + n];
+                ds[r] = wr >= 0 ? t : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq;
+                if (m >= g.M) continue;
+                const float dg = acc[j][r] + ds[r];
+                const size_t oo = (size_t)(g.o_row0 + m) * g.o_ld + n;
+                op[oo] = dg * th[r] * sg[r] * (1.0f - sg[r]);
+                op[oo + g.C] = dg * sg[r] * (1.0f - th[r] * th[r]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + 32 * j + cl;
@@ -178,15 +221,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
             } else if (EPI == EP_MASK) {           // backward of a ReLU: pass where the saved pre-activation was positive
                 const float pre = g.e[0][(size_t)b * g.e_bs + (size_t)(g.e_row0 + m) * g.e_ld + n];
                 g.o[0][(size_t)b * g.o_bs + (size_t)(g.o_row0 + m) * g.o_ld + n] = pre > 0.f ? v : 0.f;
-            } else if (EPI == EP_DZ) {             // dg = dXout.Wr^T + skip-path part; dz = dg * gate'
-                const int row = g.e_row0 + m;      // time row
-                float dg = v;
-                if (row >= g.e3_rowmin) dg += g.e3[(size_t)b * g.e3_bs + (size_t)(row - g.e3_rowmin) * g.e3_ld + g.e3_col0 + n];
-                const size_t eo = (size_t)b * g.e_bs + (size_t)row * g.e_ld + n;
-                const float sg = g.e[0][eo], th = g.e[1][eo];
-                const size_t oo = (size_t)b * g.o_bs + (size_t)(g.o_row0 + m) * g.o_ld + n;
-                g.o[0][oo] = dg * th * sg * (1.0f - sg);
-                g.o[0][oo + g.C] = dg * sg * (1.0f - th * th);
+            } else if (EPI == EP_DZ) {             // handled below (all loads of a column batch issued together)
             } else if (EPI == EP_DA) {             // d[x_cur | x_past | aux] = dZ . W1^T
                 const int row = g.e_row0 + m;
                 if (n < g.C) {                     // own row, plus the residual path's gradient
@@ -290,14 +325,20 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
         if (more) load(k0 + GK);
         const float* Aq = As + buf * (GK * GM) + (lane >> 5) * GM + 32 * wave + (lane & 31);
         const float* Bq = Bs + buf * (GK * GN) + (lane >> 5) * GN + (lane & 31);
+        float an = Aq[0], bn0 = Bq[0], bn1 = Bq[32], bn2 = Bq[64], bn3 = Bq[96];       // one k-step of lookahead in registers
 #pragma unroll
         for (int ks = 0; ks < GK / 2; ++ks) {
-            const float a = Aq[2 * ks * GM];
-            const float b0 = Bq[2 * ks * GN], b1 = Bq[2 * ks * GN + 32], b2 = Bq[2 * ks * GN + 64], b3 = Bq[2 * ks * GN + 96];
+            const float a = an, b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
+            if (ks + 1 < GK / 2) {
+                an = Aq[2 * (ks + 1) * GM];
+                bn0 = Bq[2 * (ks + 1) * GN]; bn1 = Bq[2 * (ks + 1) * GN + 32]; bn2 = Bq[2 * (ks + 1) * GN + 64]; bn3 = Bq[2 * (ks + 1) * GN + 96];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
             acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
             acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (gbias >= 0 && tid < GM) {              // bias gradient = column sums of A (n-tile 0 only)
             const float* Ac = As + buf * (GK * GM) + tid;
