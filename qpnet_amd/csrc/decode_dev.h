@@ -133,14 +133,21 @@ __device__ __forceinline__ unsigned philox_first(unsigned c0, unsigned c1, unsig
     }
     return c0;
 }
-__device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long seed, unsigned row, unsigned step, int lane) {
+__device__ __forceinline__ float sample_uniform(unsigned long long seed, unsigned row, unsigned step) {
+    return (float)(philox_first(step, row, (unsigned)seed, (unsigned)(seed >> 32)) >> 8) * 0x1p-24f;
+}
+
+// inverse-CDF draw over the Q logits at SM[o_lg..]; `u` is the step's uniform (sample_uniform), which does not depend on the
+// logits and can be computed while the producer is still working
+__device__ __forceinline__ int sample_wave_u(int o_lg, int Q, float u, int lane) {
     const float* lg = SM + o_lg;
     const int per = Q >> 6;
     float l[4], e[4];
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { l[j] = j < per ? lg[lane * per + j] : -INFINITY; m = fmaxf(m, l[j]); }
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    m = fmaxf(m, dpp_f<0xB1>(m)); m = fmaxf(m, dpp_f<0x4E>(m)); m = fmaxf(m, dpp_f<0x124>(m)); m = fmaxf(m, dpp_f<0x128>(m));
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
 #pragma unroll
     for (int j = 0; j < 4; ++j) e[j] = j < per ? qexp(l[j] - m) : 0.0f;
     float a = e[0];
@@ -151,13 +158,16 @@ __device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long s
     const float total = __shfl(v, 63);
     float c = __shfl_up(v, 1);
     if (lane == 0) c = 0.0f;
-    const float u = (float)(philox_first(step, row, (unsigned)seed, (unsigned)(seed >> 32)) >> 8) * 0x1p-24f;
     const float th = u * total;
     int idx = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (j < per) { c = c + e[j]; if (idx == 0x7fffffff && c > th) idx = lane * per + j; }
     for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(idx, s); idx = o < idx ? o : idx; }
     return idx == 0x7fffffff ? Q - 1 : idx;
+}
+
+__device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long seed, unsigned row, unsigned step, int lane) {
+    return sample_wave_u(o_lg, Q, sample_uniform(seed, row, step), lane);
 }
 
 struct UttView {            // per-utterance pointers derived from kernel-argument bases (global address space)

@@ -368,10 +368,14 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
 #pragma unroll
     for (int j = 0; j < 8; ++j) b2[j] = p.flat[pp.f_p2b + (wave * 8 + j) * 4 + grps];
     const int Ttot = u.n0 + u.n_samples;
+    const bool sampling = p.mode == QPN_MODE_SAMPLING;
     __syncthreads();
     if (Ttot < 3) return;
     for (int t = u.n0 - 1 > 1 ? u.n0 - 1 : 1; t + 1 < Ttot; ++t) {
         const unsigned tag = (unsigned)t + 1u;
+        const int i = t - (u.n0 - 1);
+        float uni = 0.0f;
+        if (sampling && wave == 0) uni = sample_uniform(p.seed, (unsigned)urow, (unsigned)i);   // ahead of the wait: independent of the logits
         if (tid < 256) sm[o_y2 + tid] = pwait(X + PX_Y2 + tid, tag, pp.abort, p.status);
         __syncthreads();
         {
@@ -386,24 +390,26 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
         }
         __syncthreads();
         if (wave == 0) {
-            float bv; int bi;
-            {   // lane owns four consecutive classes (one ds_read_b128); lowest index among maxima
-                const float4 v4 = *(const float4*)(sm + o_lg + 4 * lane);
-                bv = v4.x; bi = 4 * lane;
-                if (v4.y > bv) { bv = v4.y; bi = 4 * lane + 1; }
-                if (v4.z > bv) { bv = v4.z; bi = 4 * lane + 2; }
-                if (v4.w > bv) { bv = v4.w; bi = 4 * lane + 3; }
-            }
+            int bi;
+            if (sampling) bi = sample_wave_u(o_lg, Q, uni, lane);
+            else {
+                float bv;
+                {   // lane owns four consecutive classes (one ds_read_b128); lowest index among maxima
+                    const float4 v4 = *(const float4*)(sm + o_lg + 4 * lane);
+                    bv = v4.x; bi = 4 * lane;
+                    if (v4.y > bv) { bv = v4.y; bi = 4 * lane + 1; }
+                    if (v4.z > bv) { bv = v4.z; bi = 4 * lane + 2; }
+                    if (v4.w > bv) { bv = v4.w; bi = 4 * lane + 3; }
+                }
 #define PIPE_AMAX(CTRL) { const float ov = dpp_f<CTRL>(bv); const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true); \
                           if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
-            PIPE_AMAX(0xB1) PIPE_AMAX(0x4E) PIPE_AMAX(0x124) PIPE_AMAX(0x128)       // within rows of 16 lanes: quad perms, row rotations
+                PIPE_AMAX(0xB1) PIPE_AMAX(0x4E) PIPE_AMAX(0x124) PIPE_AMAX(0x128)   // within rows of 16 lanes: quad perms, row rotations
 #undef PIPE_AMAX
-            for (int sft = 16; sft <= 32; sft <<= 1) {                               // across the four rows
-                const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                for (int sft = 16; sft <= 32; sft <<= 1) {                           // across the four rows
+                    const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
             }
-            const int i = t - (u.n0 - 1);
-            if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg, Q, p.seed, (unsigned)urow, (unsigned)i, lane);
             int next = bi;
             if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
             // the next step's layer-0 input needs the tap-1 row of `next`; the step after that its tap-0 row
