@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int ldx = tr_lda(C), ldz = tr_lda(2 * C);
     float* Dx = sm; float* Dz = sm + TM * ldx;
-    const int b = blockIdx.y, n0 = ly.s_out + tr_xcd_tile(blockIdx.x, gridDim.x, pp) * TM;
+    const int b = blockIdx.y, n0 = ly.s_out + ((pp >> 4) + tr_xcd_tile(blockIdx.x, gridDim.x, pp & 1)) * TM;      // pp: bit 0 XCD swizzle, bits 4.. first tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)b * p.N1;
     const size_t nDX = (size_t)p.B * p.N1 * C;     // grads wrt X[j] live at DXA/DXB[0] + j*nDX
@@ -804,7 +804,7 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
     return QPN_OK;
 }
 
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
     constexpr int MT = TR_MT, TM = 16 * MT;
@@ -907,21 +907,38 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream)
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
     }
+    // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
+    // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
+    // layer l+1 (whose pitch-tap scatter reaches back across the cut) is done
+    const bool lbmt1 = !getenv("QPN_LAYER_BWD_MT") || atoi(getenv("QPN_LAYER_BWD_MT")) == 1;
+    const bool split = sp && lbmt1 && L >= 2 && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL") &&
+                       (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) && N1 - p.layers[L - 1].s_out >= 4096;
+    const int cut_row = split ? tr_split_cut(p) : 0;
+    const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
+    if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
-        if (!getenv("QPN_LAYER_BWD_MT") || atoi(getenv("QPN_LAYER_BWD_MT")) == 1) {      // 16-row tiles measured 11 % faster than 32
+        if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
             const size_t lds1 = lds_layer / MT;
             if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            hipLaunchKernelGGL((k_layer_bwd<1>), dim3((rows + 15) / 16, B), dim3(256), lds1, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
+            const int tiles = (rows + 15) / 16, lastf = l == L - 1 ? 1 : 0;
+            const int t0 = split ? tr_split_tiles(p, l, cut_row, tiles) : 0;
+            hipLaunchKernelGGL((k_layer_bwd<1>), dim3(tiles - t0, B), dim3(256), lds1, stream, p, bw, l, lastf, swz | (t0 << 4));
+            if (split) {
+                QPN_HIP(hipEventRecord(sp->ev[l], stream));
+                if (l < L - 1) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l + 1], 0));
+                hipLaunchKernelGGL((k_layer_bwd<1>), dim3(t0, B), dim3(256), lds1, sp->side, p, bw, l, lastf, swz);
+            }
         } else
-        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1);
+        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, swz);
         if (overlap && l == mid && mid < L) {
             QPN_HIP(hipEventRecord(bw.ev_mid, stream));
             QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
             launch_w1_wr(mid, L, side);
         }
     }
+    if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
     launch_w1_wr(0, mid, stream);

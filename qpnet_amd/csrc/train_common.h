@@ -78,6 +78,20 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
 };
 
+// Host-side only: the second stream and events of the two-part time split of the layer kernels (owned by TrainState).
+// The stack is causal, so the EARLIER part of layer l needs nothing from the later part; launching the two parts of every
+// layer on two streams lets one part's load / store phases and launch gaps hide under the other part's matrix work.
+struct TrainSplit { hipStream_t side; hipEvent_t ev[TR_MAXL]; hipEvent_t fork, join; };
+// row where the later part of layer 0 starts, and the number of 16-row tiles of layer l below its cut: the cut moves 16 rows
+// earlier per layer, so cut(l) <= cut(l-1) whatever the layers' first valid rows are
+static inline int tr_split_cut(const TrainParams& p) { return p.layers[0].s_out + (p.N1 - p.layers[0].s_out) / 2; }
+static inline int tr_split_tiles(const TrainParams& p, int l, int cut_row, int tiles) {
+    int t0 = (cut_row - 16 * l - p.layers[l].s_out) / 16;
+    if (t0 < 1) t0 = 1;
+    if (t0 > tiles - 1) t0 = tiles - 1;
+    return t0;
+}
+
 // K-major, zero-padded weight blocks of the GEMM path (train_gemm.hip; n_resch > 128): float offsets into `wp`
 struct TrainGemm {
     const float* wp;                  // packed weights (refreshed from the flat parameters every step)

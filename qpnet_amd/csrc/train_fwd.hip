@@ -182,9 +182,9 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 // one layer per launch.  [A persistent all-layers kernel with per-tile completion flags was tried: on this multi-XCD part
 // an agent-scope release is a whole-L2 write-back (buffer_wbl2 sc1) per tile, 4x slower than the eight launches.]
 template <int MT>
-__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {
+__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {      // last: bit 0 last layer, bit 1 XCD swizzle, bits 4.. first tile
     extern __shared__ float sm[];
-    layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2) * 16 * MT, sm);
+    layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + ((last >> 4) + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2)) * 16 * MT, sm);
 }
 
 // dynamic LDS: St[TM][lda(S)] | Yt[TM][max(lda(S), 2 lda(C))]  (the two G_l staging buffers alias Yt)
@@ -434,7 +434,7 @@ void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(k_train_prep, dim3(blocks, p.B), dim3(256), 0, stream, p);
 }
 
-int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
+int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t stream) {
     const int C = p.C, S = p.S;
     qpn_launch_prep(p, stream);
     qpn_prof_mark(PG_PREP, stream);
@@ -452,18 +452,37 @@ int qpn_launch_fwd(const TrainParams& p, hipStream_t stream) {
         // 16-row tiles (twice the workgroups, all co-resident) measured 8 % faster than 32-row tiles for the layer forward;
         // QPN_LAYER_MT / QPN_LAYER_LDS (occupancy cap) are tuning knobs (tools/sweep_layer.sh)
         const int lmt = e1 ? atoi(e1) : 1; const size_t pad = e2 ? (size_t)atoi(e2) : 0;
+        // two-part time split (TrainSplit): part 0 = tiles below the cut, part 1 = the rest, on a second stream.  The cut moves 16 rows
+        // earlier per layer so that part 0 of layer l only reads rows part 0 of layer l-1 wrote; part 1 of layer l waits for
+        // part 0 of layer l-1 (its pitch taps reach back across the cut).  Opt-in (QPN_TRAIN_SPLIT=1): measured 981 vs 1014 steps/s at paper size -- the
+        // layer kernels are not limited by launch gaps or phase separation, and the 34 extra event calls cost more than the overlap gives.
+        const int split_min_rows = 4096;
+        const bool split = sp && lmt == 1 && p.L >= 2 && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL") &&
+                           (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) &&
+                           p.N1 - p.layers[p.L - 1].s_out >= split_min_rows;
+        const int flags0 = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2;
+        const int cut_row = split ? tr_split_cut(p) : 0;
+        if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
         for (int l = 0; l < p.L; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
             if (lmt == 1) {
                 size_t lds1 = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float); if (pad > lds1) lds1 = pad;
                 if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                hipLaunchKernelGGL((k_layer_fwd<1>), dim3((rows + 15) / 16, p.B), dim3(256), lds1, stream, p, l, (l == p.L - 1 ? 1 : 0) | (getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2));
+                const int tiles = (rows + 15) / 16, fl = (l == p.L - 1 ? 1 : 0) | flags0;
+                const int t0 = split ? tr_split_tiles(p, l, cut_row, tiles) : tiles;
+                hipLaunchKernelGGL((k_layer_fwd<1>), dim3(t0, p.B), dim3(256), lds1, stream, p, l, fl);
+                if (split) {
+                    QPN_HIP(hipEventRecord(sp->ev[l], stream));
+                    if (l > 0) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l - 1], 0));
+                    hipLaunchKernelGGL((k_layer_fwd<1>), dim3(tiles - t0, p.B), dim3(256), lds1, sp->side, p, l, fl | (t0 << 4));
+                }
             } else {
                 size_t lds2 = lds_layer; if (pad > lds2) lds2 = pad;
                 if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, (l == p.L - 1 ? 1 : 0) | (getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2));
+                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, (l == p.L - 1 ? 1 : 0) | flags0);
             }
         }
+        if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     }
     qpn_prof_mark(PG_LAYER_FWD, stream);
     if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)

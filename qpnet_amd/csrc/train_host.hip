@@ -7,9 +7,9 @@
 #include <algorithm>
 #include <string.h>
 
-int qpn_launch_fwd(const TrainParams& p, hipStream_t stream);
+int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t stream);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
@@ -35,6 +35,7 @@ struct TrainState {
     TrainGemm gm;
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
+    TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
 };
 
 // ---- per-group timing
@@ -134,6 +135,7 @@ static int train_init(qpn_handle* h) {
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
+    memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -295,6 +297,11 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
+    QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
+    for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->split.fork, hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->split.join, hipEventDisableTiming));
+    t->have_split = true;
     h->train = t;
     return QPN_OK;
 }
@@ -307,6 +314,10 @@ void qpn_train_destroy(TrainState* t) {
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->ev_mid) (void)hipEventDestroy(t->ev_mid);
+    if (t->split.side) (void)hipStreamDestroy(t->split.side);
+    for (int l = 0; l < TR_MAXL; ++l) if (t->split.ev[l]) (void)hipEventDestroy(t->split.ev[l]);
+    if (t->split.fork) (void)hipEventDestroy(t->split.fork);
+    if (t->split.join) (void)hipEventDestroy(t->split.join);
     delete t;
 }
 
@@ -384,7 +395,7 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     qpn_prof_mark(PG_PREP, stream);
     t->fwd_valid = false; t->loss_clear = true;
     ++t->generation;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, stream); if (rc) return rc;
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, stream); if (rc) return rc;
     t->fwd_valid = true;
     return QPN_OK;
 }
@@ -434,7 +445,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
-    return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, (hipStream_t)stream_);
+    return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
