@@ -5,7 +5,7 @@
 //
 // At C = 64 a layer's weights are 0.2 MB and the per-tile kernels of train_fwd/bwd.hip stream them from L2 for every
 // 16-row tile.  At C = 512 they are 5.2 MB per layer (more than one XCD's L2) and a step is 2.9 TFLOP: the path is
-// compute-bound (~470 FLOP/B), so both operands go through LDS in 128 x 128 x 32 tiles and every weight
+// compute-bound (~470 FLOP/B), so both operands go through LDS in 128 x 128 x GK tiles (GK = 16) and every weight
 // element is reused by 128 time rows.
 //
 //   k_gemm_nn  C[M,N] = A[M,K] . B[K,N]     A = activations, time-major rows (optionally a row GATHER: the pitch-
@@ -18,9 +18,9 @@
 //
 // Tile: 256 threads = 4 waves, wave w owns rows 32w..32w+31 x all 128 columns = four 32x32 accumulators
 // (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD = the fp32 peak, one A and one B float per lane per instruction, so a
-// 32-deep chunk costs 16 x (1 + 4) ds_read_b32 against 64 MFMAs = 4096 matrix-core cycles).  Operands are staged
+// 16-deep chunk costs 8 x (1 + 4) ds_read_b32 against 32 MFMAs = 2048 matrix-core cycles).  Operands are staged
 // global -> registers -> LDS with the NEXT chunk's loads in flight under the MFMAs (two LDS buffers, one barrier per
-// chunk); A tile [128][33] (odd stride: conflict-free column reads), B tile [32][128].
+// chunk); A tile [128][GK + 1] (odd stride: conflict-free column reads), B tile [GK][128].
 #include "train_common.h"
 #include "qpn_handle.h"
 #include <string.h>
@@ -29,8 +29,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define GM 128
 #define GN 128
-#define GK 32
-#define G_LDA 33
+#ifndef GK
+#define GK 16                // K depth of a k_gemm_nn chunk (16 or 32): 16 -> 33 KB of LDS per workgroup, 3 co-resident per CU (registers)
+#endif                       //   instead of 2; measured 25.0 -> 28.3 steps/s on the C=512 geometry (with GKT); 4 per CU (forced 128 registers): no further gain
+#ifndef GKT
+#define GKT 16               // ... of a k_gemm_tn chunk (16 or 32)
+#endif
+#define G_LDA (GK + 1)
+#ifndef GEMM_WAVES
+#define GEMM_WAVES
+#endif
 #define G_LDB 128
 
 enum { AL_PLAIN = 0, AL_SUM2 = 1, AL_RELU = 2 };
@@ -60,24 +68,25 @@ __device__ __forceinline__ float sigmoid_g(float z) { return __frcp_rn(1.0f + __
 __device__ __forceinline__ float tanh_g(float z) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * z)) - 1.0f; }
 
 template <int AL, int EPI>
-__global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
+__global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
     extern __shared__ float sm[];
     float* As = sm;                              // [2][GM * G_LDA]
     float* Bs = sm + 2 * GM * G_LDA;             // [2][GK * G_LDB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * GN, m0 = blockIdx.y * GM, b = blockIdx.z;
-    const int ar = tid >> 3, ak4 = (tid & 7) * 4;            // A staging: rows ar + 32p, four k
+    constexpr int TA = GK / 4, RA = 256 / TA, PA = GM / RA, PB = GK / 8;
+    const int ar = tid / TA, ak4 = (tid % TA) * 4;            // A staging: rows ar + RA*p, four k
     const int bk = tid >> 5, bn4 = (tid & 31) * 4;           // B staging: k rows bk + 8p, four columns
-    int rid[4], rtap[4];
+    int rid[PA], rtap[PA];
     const bool any_tap = g.a_tap[0] | g.a_tap[1] | g.a_tap[2];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int m = m0 + ar + 32 * p; m = m < g.M ? m : g.M - 1;             // rows past the end repeat the last one (never stored)
+    for (int p = 0; p < PA; ++p) {
+        int m = m0 + ar + RA * p; m = m < g.M ? m : g.M - 1;             // rows past the end repeat the last one (never stored)
         rid[p] = m;
         const int n = g.row_base + m;
         rtap[p] = any_tap ? (g.tap ? g.tap[(size_t)b * g.tap_bs + n] : n - g.dil) : 0;
     }
-    float4 ra[4];
+    float4 ra[PA];
     auto loadA = [&](int kc) {
         const int k0 = kc * GK;
         const int s = k0 < g.a_kend[0] ? 0 : k0 < g.a_kend[1] ? 1 : 2;
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
         const bool tp = g.a_tap[s];
         const int r0 = g.a_row0[s];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PA; ++p) {
             const size_t row = tp ? (size_t)rtap[p] : (size_t)(r0 + rid[p]);
             const size_t o = row * ld + (valid ? kk : 0);
             float4 v = *(const float4*)(base + o);
@@ -105,16 +114,17 @@ __global__ __launch_bounds__(256) void k_gemm_nn(GArgs g) {
     const size_t bstep8 = (size_t)8 * g.ldb, bchunk = (size_t)GK * g.ldb;
     float4 rb0, rb1, rb2, rb3;
 #define G_LOADB(kc) { const float* bp_ = bsrc + (size_t)(kc) * bchunk; rb0 = *(const float4*)bp_; rb1 = *(const float4*)(bp_ + bstep8); \
-                      rb2 = *(const float4*)(bp_ + 2 * bstep8); rb3 = *(const float4*)(bp_ + 3 * bstep8); }
+                      if (PB > 2) { rb2 = *(const float4*)(bp_ + 2 * bstep8); rb3 = *(const float4*)(bp_ + 3 * bstep8); } }
     auto put = [&](int buf) {
         float* ad = As + buf * (GM * G_LDA) + ar * G_LDA + ak4;
         float* bd = Bs + buf * (GK * G_LDB) + bk * G_LDB + bn4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float* d = ad + 32 * p * G_LDA;
+        for (int p = 0; p < PA; ++p) {
+            float* d = ad + RA * p * G_LDA;
             d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
         }
-        *(float4*)(bd) = rb0; *(float4*)(bd + 8 * G_LDB) = rb1; *(float4*)(bd + 16 * G_LDB) = rb2; *(float4*)(bd + 24 * G_LDB) = rb3;
+        *(float4*)(bd) = rb0; *(float4*)(bd + 8 * G_LDB) = rb1;
+        if (PB > 2) { *(float4*)(bd + 16 * G_LDB) = rb2; *(float4*)(bd + 24 * G_LDB) = rb3; }
     };
     f32x16 acc[4];
 #pragma unroll
@@ -253,16 +263,16 @@ struct TArgs {
 };
 
 template <int BMODE>
-__global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
+__global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_tn(TArgs g) {
     extern __shared__ float sm[];
-    float* As = sm;                              // [2][GK * 128]
-    float* Bs = sm + 2 * GK * GM;                // [2][GK * 128]
+    float* As = sm;                              // [2][GKT * 128]
+    float* Bs = sm + 2 * GKT * GM;                // [2][GKT * 128]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * GN, m0 = blockIdx.y * GM;
     const int y = blockIdx.z / g.nsplit, sp = blockIdx.z - y * g.nsplit;
     const int Rl = g.R[y];
     const long total = (long)Rl * g.nb;
-    const long per = ((total + g.nsplit - 1) / g.nsplit + GK - 1) / GK * GK;
+    const long per = ((total + g.nsplit - 1) / g.nsplit + GKT - 1) / GKT * GKT;
     const long kbeg = per * sp, kend = kbeg + per < total ? kbeg + per : total;
     const int sk = tid >> 5, c4 = (tid & 31) * 4;            // staging: k rows sk + 8p, four columns
     const int am = m0 + c4, bn = n0 + c4;
@@ -279,10 +289,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
         else { bkind = 2; bbase = g.hup + (bn < 2 * g.C + g.Ap ? bn - 2 * g.C : 0); bstride = g.Ap; b_ok = bn < 2 * g.C + g.Ap; }
     }
     const int row0A = g.row0A[y], row0B = g.row0B[y], dil = g.dil[y];
-    float4 ra[4], rb[4];
+    constexpr int PT = GKT / 8;
+    float4 ra[PT], rb[PT];
     auto load = [&](long k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PT; ++p) {
             long kk = k0 + sk + 8 * p;
             const bool ok = kk < kend;
             kk = ok ? kk : kend - 1;
@@ -305,9 +316,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
     };
     auto put = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *(float4*)(As + buf * (GK * GM) + (sk + 8 * p) * GM + c4) = ra[p];
-            *(float4*)(Bs + buf * (GK * GN) + (sk + 8 * p) * GN + c4) = rb[p];
+        for (int p = 0; p < PT; ++p) {
+            *(float4*)(As + buf * (GKT * GM) + (sk + 8 * p) * GM + c4) = ra[p];
+            *(float4*)(Bs + buf * (GKT * GN) + (sk + 8 * p) * GN + c4) = rb[p];
         }
     };
     f32x16 acc[4];
@@ -320,16 +331,16 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
     if (kbeg < kend) { load(kbeg); put(0); }
     __syncthreads();
     int buf = 0;
-    for (long k0 = kbeg; k0 < kend; k0 += GK, buf ^= 1) {
-        const bool more = k0 + GK < kend;
-        if (more) load(k0 + GK);
-        const float* Aq = As + buf * (GK * GM) + (lane >> 5) * GM + 32 * wave + (lane & 31);
-        const float* Bq = Bs + buf * (GK * GN) + (lane >> 5) * GN + (lane & 31);
+    for (long k0 = kbeg; k0 < kend; k0 += GKT, buf ^= 1) {
+        const bool more = k0 + GKT < kend;
+        if (more) load(k0 + GKT);
+        const float* Aq = As + buf * (GKT * GM) + (lane >> 5) * GM + 32 * wave + (lane & 31);
+        const float* Bq = Bs + buf * (GKT * GN) + (lane >> 5) * GN + (lane & 31);
         float an = Aq[0], bn0 = Bq[0], bn1 = Bq[32], bn2 = Bq[64], bn3 = Bq[96];       // one k-step of lookahead in registers
 #pragma unroll
-        for (int ks = 0; ks < GK / 2; ++ks) {
+        for (int ks = 0; ks < GKT / 2; ++ks) {
             const float a = an, b0 = bn0, b1 = bn1, b2 = bn2, b3 = bn3;
-            if (ks + 1 < GK / 2) {
+            if (ks + 1 < GKT / 2) {
                 an = Aq[2 * (ks + 1) * GM];
                 bn0 = Bq[2 * (ks + 1) * GN]; bn1 = Bq[2 * (ks + 1) * GN + 32]; bn2 = Bq[2 * (ks + 1) * GN + 64]; bn3 = Bq[2 * (ks + 1) * GN + 96];
             }
@@ -341,10 +352,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
             __builtin_amdgcn_sched_barrier(0);
         }
         if (gbias >= 0 && tid < GM) {              // bias gradient = column sums of A (n-tile 0 only)
-            const float* Ac = As + buf * (GK * GM) + tid;
+            const float* Ac = As + buf * (GKT * GM) + tid;
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < GK; ++k) s += Ac[k * GM];
+            for (int k = 0; k < GKT; ++k) s += Ac[k * GM];
             csum += s;
         }
         if (more) put(buf ^ 1);
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(TArgs g) {
 
 // ------------------------------------------------------------------------------------------ host side
 static const size_t LDS_NN = (size_t)(2 * GM * G_LDA + 2 * GK * G_LDB) * sizeof(float);
-static const size_t LDS_TN = (size_t)(2 * GK * GM + 2 * GK * GN) * sizeof(float);
+static const size_t LDS_TN = (size_t)(2 * GKT * GM + 2 * GKT * GN) * sizeof(float);
 
 template <int AL, int EPI>
 static void launch_nn(const GArgs& g, int ntiles_n, hipStream_t stream) {
