@@ -139,6 +139,17 @@ int qpn_train_status(qpn_handle* h, void* stream);
 int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,
                 float* d_dlogits, double* h_loss, void* stream);
 
+/* Forward + loss in one call: qpn_train_forward followed by qpn_ce_loss (reference src/bin/qpnet_train.py:520-528:
+ * `batch_output = model(...)`, `criterion(batch_output[i], batch_t[i])`), with the cross entropy and its gradient computed
+ * inside the post-net kernel while a tile's logits are still in LDS (paper-size stacks; wider ones run the separate kernel
+ * behind the forward -- same results either way).  d_targets / tgt_stride / d_dlogits as in qpn_ce_loss.  d_logits must be a
+ * (B x BL x n_quantize) buffer; with want_logits == 0 the implementation may leave it unwritten.  The loss stays on the
+ * device until qpn_train_loss (synchronises) is called. */
+int qpn_train_forward_loss(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                           const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
+                           float* d_logits, int want_logits, float* d_dlogits, void* stream);
+int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream);
+
 /* torch.optim.Adam step (reference src/bin/qpnet_train.py:426-429,531), fp32, in place:
  * d_flat, d_m, d_v (n floats each) updated from d_grad; `step` is the 1-based step count. */
 int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,

@@ -47,7 +47,9 @@ struct TrainParams {
     int* TAP;                 // [LA][B][N1]
     int* XC;                  // [B][N1+1] sample classes of the rows (x % Q), for the causal conv's weight gradient
     float* S0; float* Y0;     // [B][BL][S] pre-relu skip sum / post1
-    float* logits;            // [B][BL][Q]
+    float* logits;            // [B][BL][Q] (nullptr: not stored -- only with the fused cross entropy below)
+    // fused cross entropy in the post-net kernel (qpn_train_forward_loss): targets = last BL columns of ce_tgt rows; nullptr = off
+    const int64_t* ce_tgt; int64_t ce_stride; float* ce_dlogits; double* ce_loss;
     int* status;
     // post-net packed blocks
     int ws_f4, p1_f4, p2_f4;          // fwd: [LC x S], [S x S], [S x Q]

@@ -376,9 +376,50 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
-                        if (t0 + r < p.BL) p.logits[((size_t)b * p.BL + t0 + r) * Q + c] = acc[mt][j][i] + bb;
+                        const float v = acc[mt][j][i] + bb;
+                        if (p.logits && t0 + r < p.BL) p.logits[((size_t)b * p.BL + t0 + r) * Q + c] = v;
+                        if (p.ce_tgt) St[(size_t)r * lds + c] = v;          // St (relu(s0)) is dead since the first 1x1; Q <= S checked by the host
                     }
             }
+        }
+    }
+    if (!p.ce_tgt) return;
+    // ---------- fused torch.nn.CrossEntropyLoss() (mean) and its gradient on the tile's rows while the logits are in LDS
+    // (same arithmetic as k_ce: one wave per row, four classes per lane; reference qpnet_train.py:430,526-528)
+    __syncthreads();
+    {
+        const int64_t rows = (int64_t)p.B * p.BL;
+        const float inv = 1.0f / (float)rows;
+        double lsum = 0.0;
+        for (int r = wave; r < TM; r += 8) {
+            if (t0 + r >= p.BL) break;
+            const float* lg = St + (size_t)r * lds;
+            const int64_t row = (int64_t)b * p.BL + t0 + r;
+            int64_t tg = p.ce_tgt[(size_t)b * p.ce_stride + (p.ce_stride - p.BL) + t0 + r];
+            if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
+            float m = -INFINITY;
+            for (int q = lane * 4; q < Q; q += 256) { const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */ m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
+            for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+            float se = 0.f;
+            for (int q = lane * 4; q < Q; q += 256) { const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */ se += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m)); }
+            for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+            const float lse = logf(se) + m;
+            if (p.ce_dlogits) for (int q = lane * 4; q < Q; q += 256) {
+                const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */
+                float4 gq = make_float4(__expf(v.x - lse), __expf(v.y - lse), __expf(v.z - lse), __expf(v.w - lse));
+                const int dq = (int)tg - q;
+                if (dq == 0) gq.x -= 1.0f; else if (dq == 1) gq.y -= 1.0f; else if (dq == 2) gq.z -= 1.0f; else if (dq == 3) gq.w -= 1.0f;
+                *(float4*)(p.ce_dlogits + (size_t)row * Q + q) = make_float4(gq.x * inv, gq.y * inv, gq.z * inv, gq.w * inv);
+            }
+            lsum += (double)(lse - lg[tg]);
+        }
+        double* part = (double*)Yt;                 // relu(y0) is dead: every wave passed the barrier above after its last read
+        if (lane == 0) part[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) {
+            double sacc = 0.0;
+            for (int w8 = 0; w8 < 8; ++w8) sacc += part[w8];
+            atomicAdd(p.ce_loss + (blockIdx.x & 63), sacc / (double)rows);
         }
     }
 }

@@ -327,14 +327,18 @@ static int need_dev(qpn_handle* h) {
     return QPN_OK;
 }
 
-extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
-                                 const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits, void* stream_) {
+// targets == nullptr: plain forward.  Otherwise the mean cross entropy (and d_dlogits) is computed too: inside the post-net kernel
+// when the tile path can hold a row of logits in LDS, by a k_ce launch behind the forward otherwise.
+static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                              const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits,
+                              const int64_t* d_targets, int64_t tgt_stride, float* d_dlogits, int want_logits, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     rc = train_init(h); if (rc) return rc;
     TrainState* t = h->train;
     hipStream_t stream = (hipStream_t)stream_;
     const Geom& g = h->g;
     if (!d_flat || !d_x || !d_h || !d_dfac || !d_logits || B < 1 || BL < 1 || maxd < 1) { qpn_set_error("bad train_forward arguments"); return QPN_EINVAL; }
+    if (d_targets && tgt_stride < BL) { qpn_set_error("bad train_forward_loss arguments: target rows shorter than batch_length"); return QPN_EINVAL; }
     const int64_t N0 = (int64_t)g.recA * maxd + g.recF + 1 + BL;           // qpnet.py:254-262
     if (N0 > T || N0 - 1 > Td || N0 - 1 > (g.U > 0 ? F * g.U : F)) {
         qpn_set_error("chunk too short: need receptive field (%lld) + batch_length (%d) = %lld samples, have x:%lld d:%lld h_up:%lld",
@@ -395,8 +399,43 @@ extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int6
     qpn_prof_mark(PG_PREP, stream);
     t->fwd_valid = false; t->loss_clear = true;
     ++t->generation;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, stream); if (rc) return rc;
+    const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !getenv("QPN_CE_SEPARATE");
+    p.ce_tgt = fuse_ce ? d_targets : nullptr; p.ce_stride = tgt_stride; p.ce_dlogits = d_dlogits; p.ce_loss = t->d_loss;
+    if (fuse_ce && !want_logits) p.logits = nullptr;
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, stream);
+    p.ce_tgt = nullptr; p.logits = d_logits;
+    if (rc) return rc;
     t->fwd_valid = true;
+    if (fuse_ce) { t->loss_clear = false; qpn_prof_mark(PG_CE, stream); }
+    else if (d_targets) {
+        rc = qpn_launch_ce(d_logits, d_targets, tgt_stride, B, BL, g.Q, d_dlogits, t->d_loss, t->d_status, t->loss_clear, stream); if (rc) return rc;
+        t->loss_clear = false;
+    }
+    return QPN_OK;
+}
+
+extern "C" int qpn_train_forward(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                                 const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits, void* stream_) {
+    return train_forward_impl(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_logits, nullptr, 0, nullptr, 1, stream_);
+}
+
+extern "C" int qpn_train_forward_loss(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                                      const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
+                                      float* d_logits, int want_logits, float* d_dlogits, void* stream_) {
+    if (!d_targets) { qpn_set_error("bad train_forward_loss arguments: no targets"); return QPN_EINVAL; }
+    return train_forward_impl(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_logits, d_targets, tgt_stride, d_dlogits, want_logits, stream_);
+}
+
+extern "C" int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train || !h_loss) { qpn_set_error("qpn_train_loss needs a preceding qpn_train_forward_loss / qpn_ce_loss"); return QPN_ESTATE; }
+    hipStream_t stream = (hipStream_t)stream_;
+    double parts[64];
+    QPN_HIP(hipMemcpyAsync(parts, h->train->d_loss, sizeof(parts), hipMemcpyDeviceToHost, stream));
+    QPN_HIP(hipStreamSynchronize(stream));
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) sum += parts[i];
+    *h_loss = sum;
     return QPN_OK;
 }
 

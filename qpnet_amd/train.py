@@ -281,10 +281,10 @@ class FusedTrainer:
         loss = C.c_double(0.0)
         multi = self.world > 1
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
-                                           x.data_ptr(), h.data_ptr(), d.data_ptr(), self._logits.data_ptr(), stream))
-            _lib.check(L.qpn_ce_loss(hd, self._logits.data_ptr(), t.data_ptr(), t.shape[1], B, BL,
-                                     self._dlogits.data_ptr(), C.byref(loss) if want_loss else None, stream))
+            # forward + CrossEntropyLoss + dL/dlogits in one call (the loss stays on the device unless asked for)
+            _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
+                                                x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
+                                                self._logits.data_ptr(), 0, self._dlogits.data_ptr(), stream))
             if multi:
                 # g <- n_r * grad_r with n_r appended; SUM over ranks; Adam divides by the summed row count on the device
                 _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 1, stream))
@@ -297,6 +297,8 @@ class FusedTrainer:
             _lib.check(L.qpn_adam_step_ex(hd, flat.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), flat.numel(),
                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                           self.g.data_ptr() + 4 * flat.numel() if multi else None, stream))
+            if want_loss:
+                _lib.check(L.qpn_train_loss(hd, C.byref(loss), stream))
             if want_loss or self.step_count % self.STATUS_EVERY == 1:
                 _lib.check(L.qpn_train_status(hd, stream))
         return loss.value if want_loss else None
@@ -317,9 +319,10 @@ class FusedTrainer:
         stream = torch.cuda.current_stream(dev).cuda_stream
         loss = C.c_double(0.0)
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
-                                           x.data_ptr(), h.data_ptr(), d.data_ptr(), logits.data_ptr(), stream))
-            _lib.check(L.qpn_ce_loss(hd, logits.data_ptr(), t.data_ptr(), t.shape[1], B, BL, None, C.byref(loss), stream))
+            _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
+                                                x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
+                                                logits.data_ptr(), 0, None, stream))
+            _lib.check(L.qpn_train_loss(hd, C.byref(loss), stream))
             _lib.check(L.qpn_train_status(hd, stream))
         return loss.value
 

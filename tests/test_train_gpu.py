@@ -444,3 +444,57 @@ def test_default_geometry_vs_reference(cuda, golden_dir):
     w, wr = m2.flat_parameters().cpu().numpy()[::97], g[name + "_wfinal_sample"]
     np.testing.assert_allclose(w, wr, atol=5e-6, rtol=0)
     assert (np.abs(w - wr) > 2e-6).mean() < 1e-4
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_fused_forward_loss_equals_forward_then_ce(cfgname, cuda, monkeypatch):
+    """qpn_train_forward_loss (cross entropy inside the post-net kernel) against qpn_train_forward + qpn_ce_loss:
+    same logits, same dL/dlogits bit for bit (same per-row arithmetic), same loss up to the order of the partial sums;
+    with want_logits = 0 the logits buffer is left alone.  (reference qpnet_train.py:520-528)"""
+    import ctypes as C
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import TINY, PAPER
+    from qpnet_amd.train import ensure_flat
+    cfg = TINY if cfgname == "tiny" else PAPER
+    m = util.build_model(cfg, synth.make_weights(cfg, 23), cuda)
+    bl = 700 if cfgname == "tiny" else 1500
+    x, h, t, d, b = synth.train_inputs(cfg, bl, 77, bl + 3000)
+    x, h, t, d = np.repeat(x, 2, 0), np.repeat(h, 2, 0), np.repeat(t, 2, 0).copy(), np.repeat(d, 2, 0)
+    t[1, -5] = (t[1, -5] + 7) % cfg.n_quantize                       # two different rows in the batch
+    xt, ht, tt, dt = _to(cuda, x, h, t, d)
+    L, hd = m._native(cuda)
+    flat = ensure_flat(m, cuda)
+    B, T = xt.shape; BL = int(b[0]); Q = cfg.n_quantize
+    maxd = int(np.ceil(d).max())
+    stream = torch.cuda.current_stream(cuda).cuda_stream
+    lg0 = torch.empty((B, BL, Q), device=cuda); dl0 = torch.empty_like(lg0)
+    lg1 = torch.full((B, BL, Q), 7.0, device=cuda); dl1 = torch.empty_like(lg0)
+    l0, l1 = C.c_double(0), C.c_double(0)
+    args = (hd, flat.data_ptr(), B, T, ht.shape[2], dt.shape[1], BL, maxd, xt.data_ptr(), ht.data_ptr(), dt.data_ptr())
+    _lib.check(L.qpn_train_forward(*args, lg0.data_ptr(), stream))
+    _lib.check(L.qpn_ce_loss(hd, lg0.data_ptr(), tt.data_ptr(), tt.shape[1], B, BL, dl0.data_ptr(), C.byref(l0), stream))
+    _lib.check(L.qpn_train_forward_loss(*args, tt.data_ptr(), tt.shape[1], lg1.data_ptr(), 1, dl1.data_ptr(), stream))
+    _lib.check(L.qpn_train_loss(hd, C.byref(l1), stream))
+    _lib.check(L.qpn_train_status(hd, stream))
+    assert torch.equal(lg0, lg1) and torch.equal(dl0, dl1)
+    assert abs(l0.value - l1.value) < 1e-12 and l0.value > 0
+    # gradient through the fused path == through the separate one
+    g0 = torch.empty(flat.numel(), device=cuda); g1 = torch.empty_like(g0)
+    _lib.check(L.qpn_train_backward(hd, dl1.data_ptr(), g1.data_ptr(), stream))
+    _lib.check(L.qpn_train_forward(*args, lg0.data_ptr(), stream))
+    _lib.check(L.qpn_train_backward(hd, dl0.data_ptr(), g0.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert float((g0 - g1).abs().max()) <= 1e-6 * max(1.0, float(g0.abs().max()))
+    # want_logits = 0: loss and gradient only
+    lg2 = torch.full((B, BL, Q), 7.0, device=cuda); dl2 = torch.empty_like(lg0)
+    _lib.check(L.qpn_train_forward_loss(*args, tt.data_ptr(), tt.shape[1], lg2.data_ptr(), 0, dl2.data_ptr(), stream))
+    _lib.check(L.qpn_train_loss(hd, C.byref(l1), stream))
+    assert torch.equal(dl2, dl0) and abs(l0.value - l1.value) < 1e-12
+    if cfgname == "paper":
+        assert float(lg2.min()) == 7.0                               # fused in the kernel: never written
+    # the separate kernel behind the forward gives the same (QPN_CE_SEPARATE: the route wide stacks take)
+    monkeypatch.setenv("QPN_CE_SEPARATE", "1")
+    _lib.check(L.qpn_train_forward_loss(*args, tt.data_ptr(), tt.shape[1], lg2.data_ptr(), 0, dl2.data_ptr(), stream))
+    _lib.check(L.qpn_train_loss(hd, C.byref(l1), stream))
+    assert torch.equal(dl2, dl0) and torch.equal(lg2, lg0) and abs(l0.value - l1.value) < 1e-12
