@@ -3,6 +3,7 @@
 // against the 100 MHz s_memrealtime.   hipcc --offload-arch=gfx950 -O3 tools/mfma_clock.hip -o /tmp/mfma_clock && /tmp/mfma_clock
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* clk, int iters) {
     f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
@@ -20,8 +21,8 @@ __global__ __launch_bounds__(256) void k_mfma(float* out, unsigned long long* cl
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
-int main() {
-    const int iters = 20000;
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 20000;
     for (int wpc = 1; wpc <= 2; ++wpc) {                 // workgroups (4 waves each) per CU
         const int nwg = 256 * wpc;
         float* out; unsigned long long* clk;
