@@ -87,27 +87,35 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
         rtap[p] = any_tap ? (g.tap ? g.tap[(size_t)b * g.tap_bs + n] : n - g.dil) : 0;
     }
     float4 ra[PA];
-    auto loadA = [&](int kc) {
-        const int k0 = kc * GK;
-        const int s = k0 < g.a_kend[0] ? 0 : k0 < g.a_kend[1] ? 1 : 2;
-        int kk = k0 - (s ? g.a_kend[s - 1] : 0) + ak4;
-        const bool valid = kk < g.a_kvalid[s];
-        const float* base = g.a[s] + (size_t)b * g.a_bs[s];
-        size_t off2 = 0;
-        if (g.a_rep_len) { const int l = kk / g.a_rep_len; kk -= l * g.a_rep_len; base += (size_t)l * g.a_rep_stride; off2 = (size_t)l * g.a_rep_stride; }
-        const int ld = g.a_ld[s];
-        const bool tp = g.a_tap[s];
-        const int r0 = g.a_row0[s];
+    // per-thread row pointers of the (up to) three side-by-side A arrays, computed once: the chunk loop only adds the chunk's
+    // column offset (the row * ld products and the tap / own-row choice used to sit in front of every chunk's loads)
+    const float* pa0[PA]; const float* pa1[PA]; const float* pa2[PA];
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const size_t row = tp ? (size_t)rtap[p] : (size_t)(r0 + rid[p]);
-            const size_t o = row * ld + (valid ? kk : 0);
-            float4 v = *(const float4*)(base + o);
-            if (AL == AL_SUM2) { const float4 w = *(const float4*)(g.a2 + (size_t)b * g.a_bs[0] + off2 + o); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
-            if (AL == AL_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            ra[p] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
+    for (int p = 0; p < PA; ++p) {
+        pa0[p] = g.a[0] + (size_t)b * g.a_bs[0] + (g.a_tap[0] ? (size_t)rtap[p] : (size_t)(g.a_row0[0] + rid[p])) * g.a_ld[0] + ak4;
+        pa1[p] = g.a[1] ? g.a[1] + (size_t)b * g.a_bs[1] + (g.a_tap[1] ? (size_t)rtap[p] : (size_t)(g.a_row0[1] + rid[p])) * g.a_ld[1] + ak4 : pa0[p];
+        pa2[p] = g.a[2] ? g.a[2] + (size_t)b * g.a_bs[2] + (g.a_tap[2] ? (size_t)rtap[p] : (size_t)(g.a_row0[2] + rid[p])) * g.a_ld[2] + ak4 : pa0[p];
+    }
+    const ptrdiff_t d2 = AL == AL_SUM2 ? g.a2 - g.a[0] : 0;
+    // (macros with literal row indices, not a lambda or a loop: hipcc keeps arrays it cannot fully scalarise in scratch memory)
+#define G_LOADA_ROW(P) { \
+            const float* ptr_ = (s_ == 0 ? pa0[P] : s_ == 1 ? pa1[P] : pa2[P]) + off_; \
+            float4 v = *(const float4*)ptr_; \
+            if (AL == AL_SUM2) { const float4 w = *(const float4*)(ptr_ + d2); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; } \
+            if (AL == AL_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
+            ra[P] = valid_ ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+#define G_LOADA(kc) { \
+        const int k0_ = (kc) * GK; \
+        const int s_ = k0_ < g.a_kend[0] ? 0 : k0_ < g.a_kend[1] ? 1 : 2; \
+        const int kl_ = k0_ - (s_ ? g.a_kend[s_ - 1] : 0); \
+        const bool valid_ = kl_ + ak4 < g.a_kvalid[s_]; \
+        ptrdiff_t off_ = valid_ ? kl_ : -ak4;              /* columns past the valid ones: a safe address (column 0), value zeroed */ \
+        if (g.a_rep_len) {                                 /* a[0] repeats every a_rep_len columns (the L gate arrays of the skip sum) */ \
+            const int kk_ = kl_ + ak4, l_ = kk_ / g.a_rep_len; \
+            off_ = (ptrdiff_t)l_ * g.a_rep_stride + (valid_ ? kk_ - l_ * g.a_rep_len - ak4 : -ak4); \
+        } \
+        G_LOADA_ROW(0) G_LOADA_ROW(1) \
+        if (PA > 2) { G_LOADA_ROW(2 % PA) G_LOADA_ROW(3 % PA) } }
     // (plain scalars instead of an array for the B staging registers: hipcc kept a captured float4[4] in scratch memory,
     //  80 bytes per lane stored and re-loaded every chunk with an s_waitcnt right behind the loads)
     const float* bsrc = g.b + (size_t)bk * g.ldb + n0 + bn4;
@@ -133,11 +141,11 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int nk = g.K / GK;
     rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nk > 0) { loadA(0); G_LOADB(0); put(0); }
+    if (nk > 0) { G_LOADA(0); G_LOADB(0); put(0); }
     __syncthreads();
     for (int kc = 0; kc < nk; ++kc) {
         const bool more = kc + 1 < nk;
-        if (more) { loadA(kc + 1); G_LOADB(kc + 1); }         // in flight under this chunk's MFMAs
+        if (more) { G_LOADA(kc + 1); G_LOADB(kc + 1); }         // in flight under this chunk's MFMAs
         const float* A = As + (kc & 1) * (GM * G_LDA) + (32 * wave + (lane & 31)) * G_LDA + (lane >> 5);
         const float* Bq = Bs + (kc & 1) * (GK * G_LDB) + (lane >> 5) * G_LDB + (lane & 31);
         // fragments of k-step ks+1 are read from LDS before the MFMAs of k-step ks issue (one step of lookahead in registers)
