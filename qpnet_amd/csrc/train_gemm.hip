@@ -198,25 +198,31 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + 32 * j + cl;
             if (n >= g.N) continue;
-            float sg[16], th[16], ds[16];
+            // four rows per batch: 12 operand registers in flight (sixteen rows cost 48 and held the kernel at two workgroups per CU)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq; m = m < g.M ? m : g.M - 1;
-                const int row = g.e_row0 + m;
-                const size_t eo = (size_t)row * g.e_ld + n;
-                sg[r] = sgp[eo]; th[r] = thp[eo];
-                const int wr = row - g.e3_rowmin;
-                const float t = dgp[(size_t)(wr > 0 ? wr : 0) * g.e3_ld + n];
-                ds[r] = wr >= 0 ? t : 0.f;
-            }
+            for (int hb = 0; hb < 4; ++hb) {
+                float sg[4], th[4], ds[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq;
-                if (m >= g.M) continue;
-                const float dg = acc[j][r] + ds[r];
-                const size_t oo = (size_t)(g.o_row0 + m) * g.o_ld + n;
-                op[oo] = dg * th[r] * sg[r] * (1.0f - sg[r]);
-                op[oo + g.C] = dg * sg[r] * (1.0f - th[r] * th[r]);
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * hb + q;
+                    int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq; m = m < g.M ? m : g.M - 1;
+                    const int row = g.e_row0 + m;
+                    const size_t eo = (size_t)row * g.e_ld + n;
+                    sg[q] = sgp[eo]; th[q] = thp[eo];
+                    const int wr = row - g.e3_rowmin;
+                    const float t = dgp[(size_t)(wr > 0 ? wr : 0) * g.e3_ld + n];
+                    ds[q] = wr >= 0 ? t : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * hb + q;
+                    const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + rq;
+                    if (m >= g.M) continue;
+                    const float dg = acc[j][r] + ds[q];
+                    const size_t oo = (size_t)(g.o_row0 + m) * g.o_ld + n;
+                    op[oo] = dg * th[q] * sg[q] * (1.0f - sg[q]);
+                    op[oo + g.C] = dg * sg[q] * (1.0f - th[q] * th[q]);
+                }
             }
         }
         return;
