@@ -297,11 +297,13 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
-    QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
-    for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
-    QPN_HIP(hipEventCreateWithFlags(&t->split.fork, hipEventDisableTiming));
-    QPN_HIP(hipEventCreateWithFlags(&t->split.join, hipEventDisableTiming));
-    t->have_split = true;
+    if (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) {     // opt-in experiment: no extra hardware queue otherwise
+        QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
+        for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
+        QPN_HIP(hipEventCreateWithFlags(&t->split.fork, hipEventDisableTiming));
+        QPN_HIP(hipEventCreateWithFlags(&t->split.join, hipEventDisableTiming));
+        t->have_split = true;
+    }
     h->train = t;
     return QPN_OK;
 }
