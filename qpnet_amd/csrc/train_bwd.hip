@@ -870,10 +870,10 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         return w;
     };
     // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
-    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st) {
+    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st, int which = 3) {      // which: bit 0 dW1, bit 1 dWr
         if (lo >= hi) return;
         Wg2 w = wbase;
-        {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
+        if (which & 1) {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
             w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
             w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
             w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
@@ -884,7 +884,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             }
             ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
         }
-        {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
+        if (which & 2) {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
             w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
             w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
             w.ncol_groups = wgrad_col_groups(w.M, w.N);
@@ -939,9 +939,17 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         }
     }
     if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
+    // the residual-1x1 weight gradient is a memory-bound 64 x 64 contraction: on the side stream next to the matrix-heavy dW1 launch
+    // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
+    const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
+    if (wr_side) {
+        QPN_HIP(hipEventRecord(bw.ev_mid, stream));
+        QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
+        launch_w1_wr(0, mid, side, 2);
+    }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
-    launch_w1_wr(0, mid, stream);
+    launch_w1_wr(0, mid, stream, wr_side ? 1 : 3);
     Wg2 w = wbase;
     if (!overlap) launch_skip_post(stream);
     if (bw.g_cw >= 0) {   // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
