@@ -353,3 +353,27 @@ def test_pipelined_decode_worst_pitch_seeds_sampling_logits(cuda, golden_dir, or
     out, logits = m._stream_logits(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), d[None], torch.from_numpy(teacher[None]), n)
     r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True)
     assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", ["pipelined", "one_cu", "cooperative"])
+def test_degenerate_lengths_on_every_kernel(kernel, cuda, oracle, monkeypatch):
+    """Utterances of 0, 1 and 2 samples next to longer ones (the persistent loops have nothing, or only the warm-up step,
+    to run for them): no hang, shortest-first retirement order, every stream equal to the oracle's
+    (reference qpnet.py:417-419, 521-559)."""
+    import torch
+    from qpnet_amd.config import PAPER
+    if kernel == "one_cu":
+        monkeypatch.setenv("QPN_DECODE_PIPE", "0")
+    elif kernel == "cooperative":
+        monkeypatch.setenv("QPN_DECODE_COOP", "4")
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    for ns in ([5, 1, 2], [1], [2], [0, 3], [330, 1]):
+        bx, bh, bd, _ = synth.decode_batch(cfg, [(100 + b, 3, 1.0) for b in range(len(ns))])
+        nlist = list(ns)
+        outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, bd, mode="argmax")
+        refs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
+        assert [len(o) for o in outs] == sorted(ns) == [len(r) for r in refs]
+        for o, r in zip(outs, refs):
+            np.testing.assert_array_equal(o, r)
