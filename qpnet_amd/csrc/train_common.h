@@ -121,35 +121,80 @@ __device__ __forceinline__ int tr_xcd_tile(int orig, int nwg, int swz) {
 // ---- one wave: acc[mt][j] += A_lds[16*mt.., :K] * Bfrag[:, nt_j]   (K multiple of 16)
 // A_lds row-major with leading dim lda (floats); Bp fragment order: [(ks4*NT + nt)*64 + lane] float4,
 // element e of the float4 = B[4*(4*ks4+e) + (lane>>4)][16*nt + (lane&15)].
+// one 16-deep step: 4 x MT x NJ MFMAs on fragments b[j] (A rows of the step read from LDS here)
+template <int MT, int NJ>
+__device__ __forceinline__ void wave_gemm_step(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda, int ks4, int arow, int ak, const float4 (&b)[NJ]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float* ap = A_lds + (size_t)(16 * mt + arow) * lda + 16 * ks4 + ak;
+        const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j].x, acc[mt][j], 0, 0, 0);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j].y, acc[mt][j], 0, 0, 0);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[j].z, acc[mt][j], 0, 0, 0);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[j].w, acc[mt][j], 0, 0, 0);
+        }
+    }
+}
+// The weight fragments of step k+1 are requested BEFORE step k's MFMAs and waited for after them.  Two register sets used
+// alternately and scheduling barriers around each group: written as "load next; copy; compute" hipcc rotated the loop so that
+// every step loaded its OWN fragments and waited for them at once (s_waitcnt right behind the global_load: the whole L2 round
+// trip exposed 11 times per K = 176 contraction -- the reason these contractions ran at 0.6 of the matrix-core rate).
 template <int MT, int NJ>
 __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
                                           const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
     const int arow = lane & 15, ak = lane >> 4;
     const int nk = K / 16;
-    float4 bn[NJ];
+    float4 b0[NJ], b1[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bn[j] = Bp[(size_t)nts[j] * 64 + lane];
-    for (int ks4 = 0; ks4 < nk; ++ks4) {
-        float4 b[NJ];
+    for (int j = 0; j < NJ; ++j) b0[j] = Bp[(size_t)nts[j] * 64 + lane];
+    int ks4 = 0;
+    for (; ks4 + 1 < nk; ks4 += 2) {          // two steps per trip, ONE basic block (a conditional second half lets LLVM sink the loads to their use)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = bn[j];
-        // the weight fragments of the next 16-deep step are requested before this step's MFMAs (L2 latency hidden)
-        const int kn = ks4 + 1 < nk ? ks4 + 1 : ks4;
+        for (int j = 0; j < NJ; ++j) b1[j] = Bp[((size_t)(ks4 + 1) * NT + nts[j]) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks4, arow, ak, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kn = ks4 + 2 < nk ? ks4 + 2 : nk - 1;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bn[j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
+        for (int j = 0; j < NJ; ++j) b0[j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks4 + 1, arow, ak, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ks4 < nk) wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks4, arow, ak, b0);      // odd step count: the last fragments are already here
+}
+
+// Ring of PD fragment sets: slot d is refilled right behind the step that consumed it with the fragments of PD steps later, so a
+// request has PD - 1 steps of MFMAs to arrive under.  Full trips are one basic block without conditionals (see wave_gemm).
+template <int MT, int NJ, int PD>
+__device__ __forceinline__ void wave_gemm_ring(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
+                                               const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
+    const int arow = lane & 15, ak = lane >> 4;
+    const int nk = K / 16;
+    float4 bq[PD][NJ];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float* ap = A_lds + (size_t)(16 * mt + arow) * lda + 16 * ks4 + ak;
-            const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+    for (int d = 0; d < PD; ++d) {
+        const int kd = d < nk ? d : nk - 1;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[j].x, acc[mt][j], 0, 0, 0);
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[j].y, acc[mt][j], 0, 0, 0);
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b[j].z, acc[mt][j], 0, 0, 0);
-                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b[j].w, acc[mt][j], 0, 0, 0);
-            }
+        for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kd * NT + nts[j]) * 64 + lane];
+    }
+    int ks0 = 0;
+    for (; ks0 + PD <= nk; ks0 += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+            wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks0 + d, arow, ak, bq[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = ks0 + d + PD < nk ? ks0 + d + PD : nk - 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
         }
     }
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (ks0 + d < nk) wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks0 + d, arow, ak, bq[d]);      // the last partial trip: fragments already requested
 }
 
 // Variant for the narrow GEMMs (one n-tile per wave): the weight fragments come from L2 (~1 k cycles away) and are requested PD
@@ -220,5 +265,5 @@ template <int MT, int PD>
 __device__ __forceinline__ void wave_gemm2(f32x4 (&acc)[MT][2], const float* __restrict__ A_lds, int lda,
                                            const float4* __restrict__ Bp, int NT, const int (&nts)[2], int K, int lane) {
     if constexpr (PD <= 1) wave_gemm<MT, 2>(acc, A_lds, lda, Bp, NT, nts, K, lane);
-    else wave_gemm_deep<MT, 2, PD>(acc, A_lds, lda, Bp, NT, nts, K, lane);
+    else wave_gemm_ring<MT, 2, PD>(acc, A_lds, lda, Bp, NT, nts, K, lane);
 }
