@@ -495,9 +495,13 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
     int tpv[NB];
+    bool a_ok[NA];
 
     // rows of a stage: r in [0,32); rows at or past rend are clamped to the last valid row and zeroed
     auto rowsplit = [&](int rr, int& b, int& i) { if (multi) { b = (int)((unsigned)rr / uR); i = rr - b * (int)uR; } else { b = 0; i = rr; } };
+    // (every thread loads its row's tap entry, needed or not: a per-thread condition around the load becomes a branch with an
+    //  s_waitcnt behind each load, which also drains the operand loads issued just before -- the next stage's prefetch no longer
+    //  ran under the MFMAs)
     auto taps = [&](int rs) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
             int rr = rs + r; rr = rr < rend ? rr : rend - 1;
             int b, i; rowsplit(rr, b, i);
             const int nloc = row0B + i;
-            tpv[k] = (use_tap && b_act) ? (tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - dil) : nloc;
+            tpv[k] = tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - dil;
         }
     };
     auto fetch = [&](int rs) {
@@ -515,9 +519,10 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
             int rr = rs + r; const bool ok = rr < rend; rr = ok ? rr : rend - 1;
             int b, i; rowsplit(rr, b, i);
             const size_t o = ((size_t)b * w.rowsA + row0A + i) * w.lda + a_col;
-            float4 v = *(const float4*)(A + o);
-            if (A2) { const float4 v2 = *(const float4*)(A2 + o); v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w; }
+            const float4 v = *(const float4*)(A + o);
+            if (A2) ra2[k] = *(const float4*)(A2 + o);          // summed when the stage goes to LDS: no wait between the passes' loads
             ra[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            a_ok[k] = ok;
         }
         if (b_act) {
 #pragma unroll
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
                 const int r = b_row0 + k * BRS;
                 int rr = rs + r; const bool ok = r < RS && rr < rend && !b_pad; rr = rr < rend ? rr : rend - 1;
                 int b, i; rowsplit(rr, b, i);
-                const size_t row = (size_t)b * w.rowsB + (BMODE == 3 ? tpv[k] : row0B + i);
+                const size_t row = (size_t)b * w.rowsB + ((BMODE == 3 && use_tap) ? tpv[k] : row0B + i);
                 float4 v;
                 if (BMODE == 4) {
                     const int dlt = w.xc[row] - n;
@@ -539,7 +544,6 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
             }
         }
     };
-    (void)ra2;
     if (rbeg < rend) {
         if (BMODE == 3) taps(rbeg);
         fetch(rbeg);
@@ -550,7 +554,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
         // registers -> LDS
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const float4 v = ra[k];
+            float4 v = ra[k];
+            if (A2 && a_ok[k]) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
             cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;
             *(float4*)(As + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
         }
