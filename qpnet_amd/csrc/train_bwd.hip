@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     // ---- d[x_cur | x_past | aux] = dZ . W1.  A wave's n-tiles run back to back; the weight fragments of the NEXT n-tile and the
     //      scatter rows are requested before the barrier / under the previous tile's epilogue (K = 2C <= 128: all 8 steps fit the ring)
     const int NTK = Ktp / 16;
-    const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
+    const int* taps = p.TAP + ly.tap_off + (size_t)b * p.N1;      // a table for every layer (k_train_prep)
     float* DH = bw.DHUP + rb * Ap;
     constexpr int PD3 = 8;
     const float4* W1t = p.wp + ly.w1t_f4;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = n0 + 16 * mt + 4 * (lane >> 4) + i;
-            tprow[mt][i] = n < p.N1 ? (taps ? taps[n] : n - ly.dilation) : 0;
+            tprow[mt][i] = taps[n < p.N1 ? n : p.N1 - 1];
         }
     if (wave < NTK) { const int nts0[1] = {wave}; wave_b_preload<1, PD3>(bq, W1t, NTK, nts0, 2 * C, lane); }
     __syncthreads();
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
                 const float v = acc[mt][0][i];
                 if (k < C) DAout[(size_t)n * C + k] = v + Dx[(size_t)r * ldx + k];              // + residual path
                 else if (k < 2 * C) {
-                    if (taps) atomicAdd(&DBout[(size_t)tprow[mt][i] * C + (k - C)], v);          // gather backward (collisions)
+                    if (ly.adaptive) atomicAdd(&DBout[(size_t)tprow[mt][i] * C + (k - C)], v);          // gather backward (collisions)
                     else DBout[(size_t)tprow[mt][i] * C + (k - C)] = v;                           // unique writer
                 } else if (k < 2 * C + Ap) atomicAdd(&DH[(size_t)n * Ap + (k - 2 * C)], v);      // unique writer per layer, layers in order: fire-and-forget add
             }
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
     const float* B1 = BMODE == 4 ? nullptr : w.B1 + (size_t)y * w.B_lstride;
     const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
-    const int* tap = (BMODE == 3 && w.tap && w.tap_off[y] >= 0) ? w.tap + w.tap_off[y] : nullptr;
-    const int row0A = w.row0A[y], row0B = w.row0B[y], dil = w.dil[y], ncol0 = zg * Np;
+    const int* tap = BMODE == 3 ? w.tap + w.tap_off[y] : nullptr;      // BMODE 3: a tap table for every layer (the launcher checks)
+    const int row0A = w.row0A[y], row0B = w.row0B[y], ncol0 = zg * Np;
     const unsigned uR = (unsigned)(Rl > 0 ? Rl : 1);
     const bool multi = w.nb > 1;
     const int gbias = zg == 0 ? w.gbias[y] : -1, goff = w.goff[y];
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
             int rr = rs + r; rr = rr < rend ? rr : rend - 1;
             int b, i; rowsplit(rr, b, i);
             const int nloc = row0B + i;
-            tpv[k] = tap ? tap[(size_t)b * w.rowsB + nloc] : nloc - dil;
+            tpv[k] = tap[(size_t)b * w.rowsB + nloc];
         }
     };
     auto fetch = [&](int rs) {
@@ -615,7 +615,8 @@ template <int BMODE, int MPW, int NT>
 static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     const int Ng = w.N / w.ncol_groups;
     if (w.M != 64 * MPW || Ng != 16 * NT || w.N % w.ncol_groups || (w.Nvalid != w.N && (w.ncol_groups != 1 || w.Nvalid % 4))) return false;
-    if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4))) return false;
+    if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4) || !w.tap)) return false;
+    if (BMODE == 3) for (int l = 0; l < w.nlayers; ++l) if (w.tap_off[l] < 0) return false;      // the kernel loads taps unconditionally
     const size_t lds = (size_t)32 * (tr_ldt(64 * MPW) + tr_ldt(16 * NT)) * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
@@ -885,7 +886,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             for (int l = 0; l < L; ++l) {
                 const TrLayer& ly = p.layers[l];
                 w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
-                w.tap_off[l] = ly.adaptive ? ly.tap_off : -1; w.dil[l] = ly.dilation;
+                w.tap_off[l] = ly.tap_off; w.dil[l] = ly.dilation;
             }
             ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
         }

@@ -22,15 +22,14 @@ __device__ __forceinline__ float tanhf_(float z) { return 2.0f * __frcp_rn(1.0f 
 // Elementwise over (row, 4 channels): every access is a coalesced 16-byte load / store, no per-row serialisation.
 //   items [0, N1*C/4)                : X0[n][c..c+3] = tap-0 row of class x[n] + tap-1 row of class x[n+1] + bias  (transposed table p.ct)
 //   items [.., + N1*Ap/4)            : upsampled aux features HUP[n][a..a+3]
-//   items [.., + N1*LA)              : pitch-dependent tap of adaptive layer i at row n (+ the class ids XC for the table gradient)
+//   items [.., + N1*L)               : tap row of layer l at row n: pitch-dependent (adaptive) or n - dilation (fixed) -- a table for
+//                                      every layer lets the consumers load taps without a branch (+ the class ids XC for the table gradient)
 __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     const int b = blockIdx.y;
     const int C = p.C, Q = p.Q, N1 = p.N1, Ap = p.Ap;
     const int C4 = C / 4, A4 = Ap / 4;
     const int nX = N1 * C4, nH = N1 * A4;
-    int nA = 0;
-    for (int l = 0; l < p.L; ++l) nA += p.layers[l].adaptive;
-    const int total = nX + nH + N1 * (nA > 0 ? nA : 1);
+    const int total = nX + nH + N1 * p.L;
     for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += gridDim.x * 256) {
         if (it < nX) {
             const int n = it / C4, c = (it - n * C4) * 4;
@@ -61,17 +60,18 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
                 v[e] = t;
             }
             *(float4*)(p.HUP + ((size_t)b * N1 + n) * Ap + a0) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (nA > 0) {
+        } else {
             // pitch-dependent taps: N1 + rint(float32(-d*dil) + float32(idx)), idx = n - N1 (qpnet.py:595-600)
-            const int i3 = it - nX - nH, ia = i3 / N1, n = i3 - ia * N1;
-            int l = 0;
-            for (int k = 0, seen = 0; k < p.L; ++k) if (p.layers[k].adaptive) { if (seen == ia) { l = k; break; } ++seen; }
+            const int i3 = it - nX - nH, l = i3 / N1, n = i3 - l * N1;
             const TrLayer ly = p.layers[l];
-            const float dv = p.d[(size_t)b * p.Td + (p.Td - N1 + n)];
-            const float dil = -dv * (float)ly.dilation;
-            const float s = __fadd_rn(dil, (float)(n - N1));
-            int tap = N1 + (int)rintf(s);
-            if (n >= ly.s_out && (tap < ly.s_in || tap > n)) { atomicOr(p.status, 1); }   // reference assert (qpnet.py:294)
+            int tap;
+            if (ly.adaptive) {
+                const float dv = p.d[(size_t)b * p.Td + (p.Td - N1 + n)];
+                const float dil = -dv * (float)ly.dilation;
+                const float s = __fadd_rn(dil, (float)(n - N1));
+                tap = N1 + (int)rintf(s);
+                if (n >= ly.s_out && (tap < ly.s_in || tap > n)) { atomicOr(p.status, 1); }   // reference assert (qpnet.py:294)
+            } else tap = n - ly.dilation;
             tap = tap < 0 ? 0 : (tap >= N1 ? N1 - 1 : tap);
             p.TAP[ly.tap_off + (size_t)b * N1 + n] = tap;
         }
@@ -90,7 +90,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
-    const int* taps = ly.adaptive ? p.TAP + ly.tap_off + (size_t)b * p.N1 : nullptr;
+    const int* taps = p.TAP + ly.tap_off + (size_t)b * p.N1;      // every layer has a table: no branch (and no s_waitcnt) around the load
     // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4).
     //      All tap rows first, then all row segments, then the LDS stores: two memory round trips per tile, not two per row.
     {
@@ -104,7 +104,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 const int n = n0 + tr + k * rpp;
-                tp[k] = (tr + k * rpp < TM && n < p.N1) ? (taps ? taps[n] : n - ly.dilation) : 0;
+                tp[k] = taps[n < p.N1 ? n : p.N1 - 1];
             }
             for (int c4 = tc; c4 < K4; c4 += tpr) {
                 const int k0 = c4 * 4;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
 void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
-    const long items = (long)p.N1 * (p.C / 4 + p.Ap / 4 + 8);
+    const long items = (long)p.N1 * (p.C / 4 + p.Ap / 4 + p.L);
     const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_train_prep, dim3(blocks, p.B), dim3(256), 0, stream, p);
 }

@@ -357,7 +357,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     for (int l = 0; l < L; ++l) {
         TrLayer& ly = p.layers[l];
         ly.s_in = s; s += ly.adaptive ? ly.dilation * maxd : ly.dilation; ly.s_out = s;
-        if (ly.adaptive) ly.tap_off = (nA++) * B * N1;
+        ly.tap_off = (nA++) * B * N1;          // every layer gets a tap table (fixed layers: n - dilation), so the kernels load taps unconditionally
     }
     // ---- carve the arena
     const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
