@@ -29,6 +29,27 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
     const int b = blockIdx.y, t0 = blockIdx.x * TM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTS = S / 16;
+    // The ReLU masks of the two epilogues (saved pre-activations Y0, S0 at this wave's output positions) are requested AHEAD of the
+    // contraction they follow -- Y0 before the staging, S0 before the first contraction -- and pinned with an empty asm in front of
+    // it: as plain epilogue loads each of the 8 sat behind its own s_waitcnt (a per-row `if` around load and store), 16 exposed L2
+    // round trips per workgroup.  Rows past the chunk end read the arena's padding rows and are masked at the store.
+    const int npairs = (NTS + 1) / 2;
+    const int np0 = wave < npairs ? wave : 0;
+    const int pnt[2] = {2 * np0, (2 * np0 + 1 < NTS) ? 2 * np0 + 1 : 2 * np0};
+    float my[2][MT][4], ms[2][MT][4];
+    auto mask_load = [&](const float* src, float (&m)[2][MT][4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = t0 + 16 * mt + 4 * (lane >> 4) + i;      // rows past the chunk end: readable padding (see the arena), masked below
+                    m[j][mt][i] = src[((size_t)b * p.BL + r) * S + 16 * pnt[j] + (lane & 15)];
+                }
+    };
+#define PIN8(m) asm volatile("" :: "v"(m[0][0][0]), "v"(m[0][0][1]), "v"(m[0][0][2]), "v"(m[0][0][3]), "v"(m[1][0][0]), "v"(m[1][0][1]), "v"(m[1][0][2]), "v"(m[1][0][3]))
+    mask_load(p.Y0, my);
     // stage dlogits rows
     for (int idx = tid; idx < TM * (Q / 2); idx += 512) {
         const int r = idx / (Q / 2), k = (idx - r * (Q / 2)) * 2;
@@ -37,8 +58,13 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
         *(float2*)(P + (size_t)r * ldp + k) = v;
     }
     __syncthreads();
+    mask_load(p.S0, ms);
+    PIN8(my);
+    if (MT > 1) {
+#pragma unroll
+        for (int mt = 1; mt < MT; ++mt) asm volatile("" :: "v"(my[0][mt][0]), "v"(my[0][mt][1]), "v"(my[0][mt][2]), "v"(my[0][mt][3]), "v"(my[1][mt][0]), "v"(my[1][mt][1]), "v"(my[1][mt][2]), "v"(my[1][mt][3]));
+    }
     // dY0 = (dlogits . W2) * (Y0 > 0)
-    const int npairs = (NTS + 1) / 2;
     for (int pb = 0; pb < npairs; pb += 8) {
         const int np = pb + wave;
         if (np < npairs) {
@@ -57,18 +83,23 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
-                        float v = 0.f;
-                        if (t0 + r < p.BL) {
-                            const size_t o = ((size_t)b * p.BL + t0 + r) * S + c;
-                            v = p.Y0[o] > 0.f ? acc[mt][j][i] : 0.f;
-                            bw.DY0[o] = v;
-                        }
+                        const bool in = t0 + r < p.BL;
+                        const size_t o = ((size_t)b * p.BL + t0 + r) * S + c;
+                        const float pre = pb == 0 ? my[j][mt][i] : (in ? p.Y0[o] : 0.f);
+                        const float v = (in && pre > 0.f) ? acc[mt][j][i] : 0.f;
+                        if (in) bw.DY0[o] = v;
                         R[(size_t)r * ldr + c] = v;
                     }
             }
         }
     }
     __syncthreads();
+    PIN8(ms);
+    if (MT > 1) {
+#pragma unroll
+        for (int mt = 1; mt < MT; ++mt) asm volatile("" :: "v"(ms[0][mt][0]), "v"(ms[0][mt][1]), "v"(ms[0][mt][2]), "v"(ms[0][mt][3]), "v"(ms[1][mt][0]), "v"(ms[1][mt][1]), "v"(ms[1][mt][2]), "v"(ms[1][mt][3]));
+    }
+#undef PIN8
     // dS0 = (dY0 . W1post) * (S0 > 0)   -> P (dlogits are dead)
     for (int pb = 0; pb < npairs; pb += 8) {
         const int np = pb + wave;
@@ -88,12 +119,11 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = 16 * mt + 4 * (lane >> 4) + i;
-                        float v = 0.f;
-                        if (t0 + r < p.BL) {
-                            const size_t o = ((size_t)b * p.BL + t0 + r) * S + c;
-                            v = p.S0[o] > 0.f ? acc[mt][j][i] : 0.f;
-                            bw.DS0[o] = v;
-                        }
+                        const bool in = t0 + r < p.BL;
+                        const size_t o = ((size_t)b * p.BL + t0 + r) * S + c;
+                        const float pre = pb == 0 ? ms[j][mt][i] : (in ? p.S0[o] : 0.f);
+                        const float v = (in && pre > 0.f) ? acc[mt][j][i] : 0.f;
+                        if (in) bw.DS0[o] = v;
                         P[(size_t)r * ldp + c] = v;
                     }
             }

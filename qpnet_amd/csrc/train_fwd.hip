@@ -91,6 +91,12 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
     const float* Xin = p.X + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* hup = p.HUP + (size_t)b * p.N1 * Ap;
     const int* taps = p.TAP + ly.tap_off + (size_t)b * p.N1;      // every layer has a table: no branch (and no s_waitcnt) around the load
+    // the biases the two epilogues add are requested here and pinned (empty asm) in front of the gate contraction: loaded where
+    // they are used, each sits behind its own s_waitcnt right after the MFMA loop -- an exposed L2 round trip per epilogue
+    const float* bias1 = p.bp + ly.bias1;
+    const float* br = p.bp + ly.biasr;
+    const int cpre = 16 * (wave < C / 16 ? wave : 0) + (lane & 15);
+    const float bs_pre = bias1[cpre], bt_pre = bias1[C + cpre], bb_pre = br[cpre];
     // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4).
     //      All tap rows first, then all row segments, then the LDS stores: two memory round trips per tile, not two per row.
     {
@@ -133,7 +139,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
     }
     __syncthreads();
     const float4* W1 = p.wp + ly.w1_f4;
-    const float* bias1 = p.bp + ly.bias1;
+    asm volatile("" :: "v"(bs_pre), "v"(bt_pre), "v"(bb_pre));
     float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
     float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
     const int NCG = C / 16;
@@ -144,7 +150,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
         const int nts[2] = {cg, NCG + cg};
         wave_gemm2<MT, QPN_PD2L>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
         const int c = 16 * cg + (lane & 15);
-        const float bs = bias1[c], bt = bias1[C + c];
+        const float bs = cg == wave ? bs_pre : bias1[c], bt = cg == wave ? bt_pre : bias1[C + c];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -159,7 +165,6 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
     if (last) return;               // the last block's residual output is never used (qpnet.py:306-309)
     __syncthreads();
     const float4* Wr = p.wp + ly.wr_f4;
-    const float* br = p.bp + ly.biasr;
     float* Xout = p.X + ((size_t)((l + 1) * p.B + b) * p.N1) * C;
     for (int nt = wave; nt < NCG; nt += 4) {
         f32x4 acc[MT][1];
@@ -168,7 +173,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
         const int nts[1] = {nt};
         wave_gemm_deep<MT, 1, 4>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
         const int c = 16 * nt + (lane & 15);
-        const float bb = br[c];
+        const float bb = nt == wave ? bb_pre : br[c];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -200,6 +205,18 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     const int nbase = p.N1 - p.BL + t0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NTS = S / 16, NTQ = Q / 16, NCG = C / 16;
+    // the biases of the three epilogues, requested before anything else and pinned (empty asm) in front of the first contraction:
+    // loaded in the epilogues they sat behind an s_waitcnt each (an exposed L2 round trip after every MFMA loop)
+    float bpre[3][2];
+    {
+        const int npq = wave < (NTS + 1) / 2 ? wave : 0, nqq = wave < (NTQ + 1) / 2 ? wave : 0;
+        const int cs0 = 16 * (2 * npq) + (lane & 15), cs1 = 16 * ((2 * npq + 1 < NTS) ? 2 * npq + 1 : 2 * npq) + (lane & 15);
+        const int cq0 = 16 * (2 * nqq) + (lane & 15), cq1 = 16 * ((2 * nqq + 1 < NTQ) ? 2 * nqq + 1 : 2 * nqq) + (lane & 15);
+        bpre[0][0] = p.bp[p.bias_s + cs0]; bpre[0][1] = p.bp[p.bias_s + cs1];
+        bpre[1][0] = p.bp[p.bias_p1 + cs0]; bpre[1][1] = p.bp[p.bias_p1 + cs1];
+        bpre[2][0] = p.bp[p.bias_p2 + cq0]; bpre[2][1] = p.bp[p.bias_p2 + cq1];
+    }
+#define POST_PIN_BIAS asm volatile("" :: "v"(bpre[0][0]), "v"(bpre[0][1]), "v"(bpre[1][0]), "v"(bpre[1][1]), "v"(bpre[2][0]), "v"(bpre[2][1]))
     // ---------- skip sum: K = L*C over the saved gates
     const int npairs = (NTS + 1) / 2;
     const int LC = L * C, ldall = tr_lda(LC);
@@ -227,6 +244,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         f32x4 acc[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+        POST_PIN_BIAS;
         if (active) { const int nts[2] = {nt0, nt1}; wave_gemm2<MT, QPN_PD2P>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
         __syncthreads();                                         // every wave is done reading Gall before St overwrites it
         if (active) {
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int nt = j ? nt1 : nt0;
                 if (j && nt1 == nt0) break;
                 const int c = 16 * nt + (lane & 15);
-                const float bs = p.bp[p.bias_s + c];
+                const float bs = wave < npairs ? bpre[0][j] : p.bp[p.bias_s + c];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -311,7 +329,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int nt = j ? nt1 : nt0;
                 if (j && nt1 == nt0) break;
                 const int c = 16 * nt + (lane & 15);
-                const float bs = p.bp[p.bias_s + c];
+                const float bs = pb == 0 ? bpre[0][j] : p.bp[p.bias_s + c];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int nt = j ? nt1 : nt0;
                 if (j && nt1 == nt0) break;
                 const int c = 16 * nt + (lane & 15);
-                const float bb = p.bp[p.bias_p1 + c];
+                const float bb = pb == 0 ? bpre[1][j] : p.bp[p.bias_p1 + c];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -370,7 +388,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int nt = j ? nt1 : nt0;
                 if (j && nt1 == nt0) break;
                 const int c = 16 * nt + (lane & 15);
-                const float bb = p.bp[p.bias_p2 + c];
+                const float bb = pb == 0 ? bpre[2][j] : p.bp[p.bias_p2 + c];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
