@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
     const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
     const int win0 = p.N1 - p.BL;
+    // the residual-1x1 fragments of this wave's first n-tile do not depend on the tile: requested before the staging loads, consumed
+    // behind the barrier (requested there, their L2 round trip was exposed in front of the first contraction)
+    float4 bqr[4][1];
+    if (!last) { const int ntr[1] = {wave < NCG ? wave : 0}; wave_b_preload<1, 4>(bqr, p.wp + ly.wrt_f4, NCG, ntr, C, lane); }
     {
         const int C4 = C / 4, tpr = C4 < 64 ? C4 : 64, rpp = 256 / tpr;
         const int tr = tid / tpr, tc = tid - tr * tpr;
@@ -212,7 +216,11 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
         f32x4 acc[MT][1];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
-        if (!last) { const int nts[1] = {nt}; wave_gemm_deep<MT, 1, 4>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane); }
+        if (!last) {
+            const int nts[1] = {nt};
+            if (nt == wave) wave_gemm_run<MT, 1, 4>(acc, Dx, ldx, bqr, p.wp + ly.wrt_f4, NCG, nts, C, lane);
+            else wave_gemm_deep<MT, 1, 4>(acc, Dx, ldx, p.wp + ly.wrt_f4, NCG, nts, C, lane);
+        }
         const int c = 16 * nt + (lane & 15);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
