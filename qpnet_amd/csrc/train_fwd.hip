@@ -97,6 +97,9 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
     const float* br = p.bp + ly.biasr;
     const int cpre = 16 * (wave < C / 16 ? wave : 0) + (lane & 15);
     const float bs_pre = bias1[cpre], bt_pre = bias1[C + cpre], bb_pre = br[cpre];
+    // ... and so are the residual-1x1 weight fragments of this wave's n-tile (consumed behind the gate epilogue's barrier)
+    float4 wrq[4][1];
+    if (!last) { const int ntp[1] = {wave < C / 16 ? wave : 0}; wave_b_preload<1, 4>(wrq, p.wp + ly.wr_f4, C / 16, ntp, C, lane); }
     // ---- stage [x_cur | x_past | aux | 0] rows into LDS: 16-byte global loads, 8-byte LDS stores (lda is even, not /4).
     //      All tap rows first, then all row segments, then the LDS stores: two memory round trips per tile, not two per row.
     {
@@ -171,7 +174,8 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][0] = (f32x4){0, 0, 0, 0};
         const int nts[1] = {nt};
-        wave_gemm_deep<MT, 1, 4>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
+        if (nt == wave) wave_gemm_run<MT, 1, 4>(acc, Gs, ldg, wrq, Wr, NCG, nts, C, lane);
+        else wave_gemm_deep<MT, 1, 4>(acc, Gs, ldg, Wr, NCG, nts, C, lane);
         const int c = 16 * nt + (lane & 15);
         const float bb = nt == wave ? bb_pre : br[c];
 #pragma unroll
