@@ -245,13 +245,18 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
     for (int j = 0; j < 2; ++j) { load_tile(w6[j], p.wpk, f.w_skip[6] + (wave + 8 * j) * 256, lane); load_tile(w7[j], p.wpk, f.w_skip[7] + (wave + 8 * j) * 256, lane); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) load_tile(wp1[j], p.wpk, f.w_p1 + (wave * 8 + j) * 256, lane);
-    float bsk[4][2], b1[8];
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bsk[l][j] = p.flat[pp.f_skipb[4 + l] + (wave + 8 * j) * 16 + grp];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b1[j] = p.flat[pp.f_p1b + (wave * 8 + j) * 4 + grps];
+    // the biases live in LDS (5 KB): 16 more registers per lane on top of the 192 of resident tiles spilled to scratch memory, and the
+    // reloads sat in the per-sample loop (scratch_load + s_waitcnt in front of the skip sums and the post-1 epilogue)
+    constexpr int o_bs = o_sk + 2 * 16 * 1024, o_b1 = o_bs + 4 * 256;
+    // layouts: skip biases [layer][wave][grp][j] (one 8-byte read per layer), post-1 biases [grps][wave][j] (two 16-byte reads)
+    for (int i = tid; i < 4 * 256; i += PIPE_NT) {
+        const int l = i >> 8, r = i & 255, j = r & 1, g16 = (r >> 1) & 15, w8 = r >> 5;
+        sm[o_bs + i] = p.flat[pp.f_skipb[4 + l] + (w8 + 8 * j) * 16 + g16];
+    }
+    for (int i = tid; i < 256; i += PIPE_NT) {
+        const int j = i & 7, w8 = (i >> 3) & 7, g4 = i >> 6;
+        sm[o_b1 + i] = p.flat[pp.f_p1b + (w8 * 8 + j) * 4 + g4];
+    }
     const int Ttot = u.n0 + u.n_samples;
     __syncthreads();
     if (Ttot < 3) return;
@@ -263,6 +268,7 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
             if (tid < C) sm[o_g + l * C + tid] = pwait(X + PX_G + l * C + tid, tag, pp.abort, p.status);
             __syncthreads();
             float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
+            const float2 bsl = *(const float2*)(sm + o_bs + ((l * 8 + wave) * 16 + grp) * 2);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float d;
@@ -274,7 +280,7 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
                     d = red4(chunk16(w, x));
                 } else if (l == 2) d = red4(chunk16(w6[j], x));
                 else d = red4(chunk16(w7[j], x));
-                acc2[j] = acc2[j] + (d + bsk[l][j]);
+                acc2[j] = acc2[j] + (d + (j ? bsl.y : bsl.x));
             }
         }
         if (q == 0) {
@@ -292,8 +298,10 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
 #pragma unroll
             for (int j = 0; j < 8; ++j) pa[j] = red16(chunk16(wp1[j], x));
             if (qs == 0) {
+                const float4 bA = *(const float4*)(sm + o_b1 + (grps * 8 + wave) * 8), bB = *(const float4*)(sm + o_b1 + (grps * 8 + wave) * 8 + 4);
+                const float bj[8] = {bA.x, bA.y, bA.z, bA.w, bB.x, bB.y, bB.z, bB.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float v = pa[j] + b1[j]; pst(X + PX_Y2 + (wave * 8 + j) * 4 + grps, tag, v > 0.0f ? v : 0.0f); }
+                for (int j = 0; j < 8; ++j) { const float v = pa[j] + bj[j]; pst(X + PX_Y2 + (wave * 8 + j) * 4 + grps, tag, v > 0.0f ? v : 0.0f); }
             }
         }
         if (tid == 0) smi[o_misc] = __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -459,7 +467,7 @@ int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t st
     }
     pp.xch = h->d_xch + 16; pp.abort = (int*)h->d_xch;
     QPN_HIP(hipMemsetAsync(h->d_xch, 0, xwords * sizeof(unsigned long long), stream));
-    const size_t lds = ((size_t)520 + 2 * 256 * 64) * sizeof(float);                 // role P (the causal tables) is the largest
+    const size_t lds = ((size_t)520 + 2 * 256 * 64 + 5 * 256) * sizeof(float);       // roles P (the causal tables) and K (two layers' skip tiles + biases)
     static bool attr = false;
     if (!attr) { QPN_HIP(hipFuncSetAttribute((const void*)k_decode_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
     const int nchunks = (B + 7) / 8;
