@@ -413,9 +413,15 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
                           if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; } }
                 PIPE_AMAX(0xB1) PIPE_AMAX(0x4E) PIPE_AMAX(0x124) PIPE_AMAX(0x128)   // within rows of 16 lanes: quad perms, row rotations
 #undef PIPE_AMAX
-                for (int sft = 16; sft <= 32; sft <<= 1) {                           // across the four rows
-                    const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
-                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                {   // across the four rows: every lane of a row holds its row's best, so four v_readlane pairs and uniform compares
+                    // replace two ds_bpermute round trips (rows hold ascending class ranges: the lowest index wins ties by order)
+                    float rv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 0)); int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) {
+                        const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bv), 16 * r)); const int oi = __builtin_amdgcn_readlane(bi, 16 * r);
+                        if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+                    }
+                    bv = rv; bi = ri;
                 }
             }
             int next = bi;
