@@ -75,6 +75,7 @@ __device__ __forceinline__ float chunk16_reload(float4 (&w)[4], const float4 (&x
 // stride-halving tree over the R lanes of a row group (R = 1 << logR, lanes contiguous).
 // The spec order is "p_i += p_{i+s} for s = R/2 .. 1"; fp add is commutative, so every lane of the
 // group ends with the same bits whether the partner is reached by xor, rotation or quad permute.
+__device__ __forceinline__ float rl_f(float v, int lane_) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_)); }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -147,7 +148,9 @@ __device__ __forceinline__ int sample_wave_u(int o_lg, int Q, float u, int lane)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { l[j] = j < per ? lg[lane * per + j] : -INFINITY; m = fmaxf(m, l[j]); }
     m = fmaxf(m, dpp_f<0xB1>(m)); m = fmaxf(m, dpp_f<0x4E>(m)); m = fmaxf(m, dpp_f<0x124>(m)); m = fmaxf(m, dpp_f<0x128>(m));
-    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    // (every lane of a 16-lane row now holds the row's maximum: four v_readlane instead of two ds_bpermute round trips; max and
+    //  min are order-independent, so the bits are the spec's)
+    m = fmaxf(fmaxf(rl_f(m, 0), rl_f(m, 16)), fmaxf(rl_f(m, 32), rl_f(m, 48)));
 #pragma unroll
     for (int j = 0; j < 4; ++j) e[j] = j < per ? qexp(l[j] - m) : 0.0f;
     float a = e[0];
@@ -155,14 +158,21 @@ __device__ __forceinline__ int sample_wave_u(int o_lg, int Q, float u, int lane)
     for (int j = 1; j < 4; ++j) if (j < per) a = a + e[j];
     float v = a;
     for (int d = 1; d < 64; d <<= 1) { const float up = __shfl_up(v, d); if (lane >= d) v = v + up; }
-    const float total = __shfl(v, 63);
+    const float total = rl_f(v, 63);
     float c = __shfl_up(v, 1);
     if (lane == 0) c = 0.0f;
     const float th = u * total;
     int idx = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (j < per) { c = c + e[j]; if (idx == 0x7fffffff && c > th) idx = lane * per + j; }
-    for (int s = 32; s >= 1; s >>= 1) { const int o = __shfl_xor(idx, s); idx = o < idx ? o : idx; }
+#define QPN_IMIN(CTRL) { const int o_ = __builtin_amdgcn_update_dpp(0x7fffffff, idx, CTRL, 0xf, 0xf, false); idx = o_ < idx ? o_ : idx; }
+    QPN_IMIN(0xB1) QPN_IMIN(0x4E) QPN_IMIN(0x124) QPN_IMIN(0x128)            // within rows of 16 lanes
+#undef QPN_IMIN
+    {
+        const int i0 = __builtin_amdgcn_readlane(idx, 0), i1 = __builtin_amdgcn_readlane(idx, 16), i2 = __builtin_amdgcn_readlane(idx, 32), i3 = __builtin_amdgcn_readlane(idx, 48);
+        const int a01 = i0 < i1 ? i0 : i1, a23 = i2 < i3 ? i2 : i3;
+        idx = a01 < a23 ? a01 : a23;
+    }
     return idx == 0x7fffffff ? Q - 1 : idx;
 }
 
