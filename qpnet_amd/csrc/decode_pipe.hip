@@ -59,6 +59,20 @@ __device__ __forceinline__ float pwait(const u64* g, unsigned tag, int* abort, i
     }
     return __uint_as_float((unsigned)v);
 }
+// ... for TWO granules of the same step at once: both loads are in flight together (one round trip, not two)
+__device__ __forceinline__ float2 pwait2(const u64* g0, const u64* g1, unsigned tag, int* abort, int* status) {
+    u64 v0 = pld(g0), v1 = pld(g1);
+    unsigned spins = 0;
+    while ((unsigned)(v0 >> 32) != tag || (unsigned)(v1 >> 32) != tag) {
+        if (++spins > PIPE_SPIN || ((spins & 255u) == 0 && __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicOr(status, 4);
+            break;
+        }
+        v0 = pld(g0); v1 = pld(g1);
+    }
+    return make_float2(__uint_as_float((unsigned)v0), __uint_as_float((unsigned)v1));
+}
 __device__ __forceinline__ void rd4(float4 (&x)[4], const float* v) {
     const float4* p = (const float4*)v;
 #pragma unroll
@@ -157,9 +171,9 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
                     if (t == u.n0 - 1) sm[o_t0 + lane] = p.flat[p.causal_w + ((size_t)lane * Q + sc) * 2];     // tap-0 row of the last known sample
                 } else {                                          // picked by P at step t-1: id + its tap-1 row + its tap-0 row (for the next step)
                     const u64* nx = X + PX_NX;
-                    const float t1 = pwait(nx + 1 + lane, (unsigned)t, pp.abort, p.status);
-                    v = sm[o_t0 + lane] + t1;
-                    sm[o_t0 + lane] = pwait(nx + 65 + lane, (unsigned)t, pp.abort, p.status);      // (stored before the tap-1 row: normally no spin)
+                    const float2 rows = pwait2(nx + 1 + lane, nx + 65 + lane, (unsigned)t, pp.abort, p.status);     // tap-1 row, tap-0 row (for the next step)
+                    v = sm[o_t0 + lane] + rows.x;
+                    sm[o_t0 + lane] = rows.y;
                 }
                 v = v + cbias;
                 sm[o_x + lane] = v;
