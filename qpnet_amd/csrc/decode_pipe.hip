@@ -277,9 +277,11 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
     for (int t = u.n0 - 1 > 1 ? u.n0 - 1 : 1; t + 1 < Ttot; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         float acc2[2] = {0.0f, 0.0f};
+        u64 af[2] = {0, 0};                                   // the fixed stack's skip sums (from K0, long before S1 is done): requested early
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             if (tid < C) sm[o_g + l * C + tid] = pwait(X + PX_G + l * C + tid, tag, pp.abort, p.status);
+            if (l == 2 && q == 0) { af[0] = pld(X + PX_ACCF + wave * 16 + grp); af[1] = pld(X + PX_ACCF + (wave + 8) * 16 + grp); }
             __syncthreads();
             float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
             const float2 bsl = *(const float2*)(sm + o_bs + ((l * 8 + wave) * 16 + grp) * 2);
@@ -301,7 +303,8 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = (wave + 8 * j) * 16 + grp;
-                const float tot = pwait(X + PX_ACCF + row, tag, pp.abort, p.status) + acc2[j];     // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
+                const float accf = (unsigned)(af[j] >> 32) == tag ? __uint_as_float((unsigned)af[j]) : pwait(X + PX_ACCF + row, tag, pp.abort, p.status);
+                const float tot = accf + acc2[j];                                               // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
                 sm[o_y1 + row] = tot > 0.0f ? tot : 0.0f;
             }
         }
