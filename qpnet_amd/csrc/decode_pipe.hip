@@ -282,7 +282,7 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
         for (int l = 0; l < 4; ++l) {
             if (tid < C) sm[o_g + l * C + tid] = pwait(X + PX_G + l * C + tid, tag, pp.abort, p.status);
             if (l == 2 && q == 0) { af[0] = pld(X + PX_ACCF + wave * 16 + grp); af[1] = pld(X + PX_ACCF + (wave + 8) * 16 + grp); }
-            __syncthreads();
+            wg_barrier();                                         // LDS only (the polls' / hand-offs' global traffic is not waited for)
             float4 x[4]; rd4(x, sm + o_g + l * C + 16 * q);
             const float2 bsl = *(const float2*)(sm + o_bs + ((l * 8 + wave) * 16 + grp) * 2);
 #pragma unroll
@@ -308,7 +308,7 @@ __device__ __forceinline__ void skip_post1_role(const DecodeParams& p, const Fas
                 sm[o_y1 + row] = tot > 0.0f ? tot : 0.0f;
             }
         }
-        __syncthreads();
+        wg_barrier();                                         // LDS only (the polls' / hand-offs' global traffic is not waited for)
         {
             float4 x[4]; rd4(x, sm + o_y1 + 16 * qs);
             float pa[8];
@@ -402,7 +402,7 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
         float uni = 0.0f;
         if (sampling && wave == 0) uni = sample_uniform(p.seed, (unsigned)urow, (unsigned)i);   // ahead of the wait: independent of the logits
         if (tid < 256) sm[o_y2 + tid] = pwait(X + PX_Y2 + tid, tag, pp.abort, p.status);
-        __syncthreads();
+        wg_barrier();                                         // LDS only (the polls' / hand-offs' global traffic is not waited for)
         {
             float4 x[4]; rd4(x, sm + o_y2 + 16 * qs);
             float pa[8];
@@ -413,7 +413,7 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
                 for (int j = 0; j < 8; ++j) sm[o_lg + (wave * 8 + j) * 4 + grps] = pa[j] + b2[j];
             }
         }
-        __syncthreads();
+        wg_barrier();                                         // LDS only (the polls' / hand-offs' global traffic is not waited for)
         if (wave == 0) {
             int bi;
             if (sampling) bi = sample_wave_u(o_lg, Q, uni, lane);
