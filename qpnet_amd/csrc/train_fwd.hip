@@ -118,23 +118,30 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
             for (int c4 = tc; c4 < K4; c4 += tpr) {
                 const int k0 = c4 * 4;
                 const int kind = k0 < C ? 0 : k0 < 2 * C ? 1 : k0 < 2 * C + Ap ? 2 : 3;
-                const float* base = kind == 0 ? Xin + k0 : kind == 1 ? Xin + (k0 - C) : hup + (kind == 2 ? k0 - 2 * C : 0);
-                const int stride = kind == 2 ? Ap : C;
+                // source array / column / row stride as integer selects (the nested pointer ternary became divergent branches whose
+                // joins carry s_waitcnt vmcnt(0): they waited for every load requested above, taps or not)
+                const bool from_x = kind <= 1;
+                const int col = kind == 0 ? k0 : kind == 1 ? k0 - C : kind == 2 ? k0 - 2 * C : 0;
+                const unsigned long long ax = (unsigned long long)Xin, ah = (unsigned long long)hup;
+                const float* base = (const float*)(from_x ? ax : ah) + col;
+                const int stride = from_x ? C : Ap;
                 float4 v[NR];
 #pragma unroll
-                for (int k = 0; k < NR; ++k) {
+                for (int k = 0; k < NR; ++k) {          // loads only: a select on the loaded value here makes hipcc wait for each load before it issues the next
                     const int r = tr + k * rpp, n = n0 + r;
                     const bool ok = r < TM && n < p.N1 && kind != 3;
                     const int row = ok ? (kind == 1 ? tp[k] : n) : 0;
-                    const float4 t = *(const float4*)(base + (size_t)row * stride);
-                    v[k] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[k] = *(const float4*)(base + (size_t)row * stride);
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
                     const int r = tr + k * rpp;
                     if (r < TM) {
+                        const bool ok = n0 + r < p.N1 && kind != 3;
+                        const float4 w = ok ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f);
                         float* dst = As + (size_t)r * lda + k0;
-                        *(float2*)dst = make_float2(v[k].x, v[k].y); *(float2*)(dst + 2) = make_float2(v[k].z, v[k].w);
+                        *(float2*)dst = make_float2(w.x, w.y); *(float2*)(dst + 2) = make_float2(w.z, w.w);
                     }
                 }
             }
