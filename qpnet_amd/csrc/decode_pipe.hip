@@ -401,7 +401,22 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
         const int i = t - (u.n0 - 1);
         float uni = 0.0f;
         if (sampling && wave == 0) uni = sample_uniform(p.seed, (unsigned)urow, (unsigned)i);   // ahead of the wait: independent of the logits
-        if (tid < 256) sm[o_y2 + tid] = pwait(X + PX_Y2 + tid, tag, pp.abort, p.status);
+        if (wave == 0) {      // ONE wave gathers all 256 granules, four per lane in one poll loop: four waves polling on their own each
+                              // sample their granules once per L2 round trip, and the barrier waited for the unluckiest phase
+            const u64* g = X + PX_Y2 + lane;
+            u64 v0 = pld(g), v1 = pld(g + 64), v2 = pld(g + 128), v3 = pld(g + 192);
+            unsigned spins = 0;
+            while ((unsigned)(v0 >> 32) != tag || (unsigned)(v1 >> 32) != tag || (unsigned)(v2 >> 32) != tag || (unsigned)(v3 >> 32) != tag) {
+                if (++spins > PIPE_SPIN || ((spins & 255u) == 0 && __hip_atomic_load(pp.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_store(pp.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicOr(p.status, 4);
+                    break;
+                }
+                v0 = pld(g); v1 = pld(g + 64); v2 = pld(g + 128); v3 = pld(g + 192);
+            }
+            sm[o_y2 + lane] = __uint_as_float((unsigned)v0); sm[o_y2 + 64 + lane] = __uint_as_float((unsigned)v1);
+            sm[o_y2 + 128 + lane] = __uint_as_float((unsigned)v2); sm[o_y2 + 192 + lane] = __uint_as_float((unsigned)v3);
+        }
         wg_barrier();                                         // LDS only (the polls' / hand-offs' global traffic is not waited for)
         {
             float4 x[4]; rd4(x, sm + o_y2 + 16 * qs);
