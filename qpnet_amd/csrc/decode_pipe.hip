@@ -386,9 +386,23 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
         const int tp = i / (Q * C), r = i - tp * Q * C, s = r / C, c = r - s * C;
         sm[o_tab + i] = p.flat[p.causal_w + ((size_t)c * Q + s) * 2 + tp];
     }
-    float4 wp2[8][4];
+    // post 1x1 #2: this wave's eight rows resident, kept as four PAIRS of rows ({row 2i, row 2i+1} per element) so that the two
+    // independent 16-deep FMA chains of a pair issue as v_pk_fma_f32 -- with two waves per SIMD the 128 scalar FMAs were the phase
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v wpp[4][16];
+    {
+        float4 wa[4], wb[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) load_tile(wp2[j], p.wpk, f.w_p2 + (wave * 8 + j) * 256, lane);
+        for (int i = 0; i < 4; ++i) {
+            load_tile(wa, p.wpk, f.w_p2 + (wave * 8 + 2 * i) * 256, lane);
+            load_tile(wb, p.wpk, f.w_p2 + (wave * 8 + 2 * i + 1) * 256, lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wpp[i][4 * k + 0] = (f2v){wa[k].x, wb[k].x}; wpp[i][4 * k + 1] = (f2v){wa[k].y, wb[k].y};
+                wpp[i][4 * k + 2] = (f2v){wa[k].z, wb[k].z}; wpp[i][4 * k + 3] = (f2v){wa[k].w, wb[k].w};
+            }
+        }
+    }
     float b2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) b2[j] = p.flat[pp.f_p2b + (wave * 8 + j) * 4 + grps];
@@ -422,7 +436,13 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
             float4 x[4]; rd4(x, sm + o_y2 + 16 * qs);
             float pa[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pa[j] = red16(chunk16(wp2[j], x));
+            for (int i = 0; i < 4; ++i) {
+                const float xe[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w, x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+                f2v acc = wpp[i][0] * (f2v){xe[0], xe[0]};                    // the spec's chunk: one product, then 15 fma in k order -- per row, as before
+#pragma unroll
+                for (int e = 1; e < 16; ++e) acc = __builtin_elementwise_fma(wpp[i][e], (f2v){xe[e], xe[e]}, acc);
+                pa[2 * i] = red16(acc.x); pa[2 * i + 1] = red16(acc.y);
+            }
             if (qs == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) sm[o_lg + (wave * 8 + j) * 4 + grps] = pa[j] + b2[j];
