@@ -243,10 +243,7 @@ __device__ __forceinline__ void run_slot(const Ctx& c, int slot, int64_t t, floa
     if (op == OP_ARGMAX) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
-        for (int s = 32; s >= 1; s >>= 1) {
-            const float ov = __shfl_xor(bv, s); const int oi = __shfl_xor(bi, s);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
+        bi = wave_argmax(bv, bi);
         const int64_t i = t - (u.n0 - 1);
         if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
         int next;
@@ -547,10 +544,7 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
         if (wave == 0) {
             float bv = -INFINITY; int bi = 0x7fffffff;
             for (int i = lane; i < Q; i += 64) { const float v = sm[p.o_lg + i]; if (v > bv) { bv = v; bi = i; } }
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            bi = wave_argmax(bv, bi);
             const int i = t - (u.n0 - 1);
             if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
             int next;

@@ -234,10 +234,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
         if (wave == 0) {
             float bv = -INFINITY; int bi = 0x7fffffff;
             for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + i]; if (v > bv) { bv = v; bi = i; } }
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                const float ov = __shfl_xor(bv, sft); const int oi = __shfl_xor(bi, sft);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
+            bi = wave_argmax(bv, bi);
             const int i = t - (u.n0 - 1);
             if (i >= 0 && u.logits && gidx == 0) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[o_lg + k];
             int next;

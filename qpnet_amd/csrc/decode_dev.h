@@ -80,6 +80,22 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// (value, index) maximum over the 64 lanes, lowest index among equal values; every lane returns the winner's index.
+// Four DPP steps inside the 16-lane rows, then four v_readlane pairs and uniform compares across the rows (a butterfly of
+// six ds_bpermute pairs is a ~900-cycle dependent chain on the pick's critical path).
+__device__ __forceinline__ int wave_argmax(float bv, int bi) {
+#define QPN_AMAX(CTRL) { const float ov_ = dpp_f<CTRL>(bv); const int oi_ = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true); \
+                         if (ov_ > bv || (ov_ == bv && oi_ < bi)) { bv = ov_; bi = oi_; } }
+    QPN_AMAX(0xB1) QPN_AMAX(0x4E) QPN_AMAX(0x124) QPN_AMAX(0x128)
+#undef QPN_AMAX
+    float rv = rl_f(bv, 0); int ri = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        const float ov = rl_f(bv, 16 * r); const int oi = __builtin_amdgcn_readlane(bi, 16 * r);
+        if (ov > rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+    }
+    return ri;
+}
 __device__ __forceinline__ float tree_reduce(float acc, int logR) {
     if (logR == 2) {                       // K = 64: two quad permutes, no LDS crossbar
         acc = acc + dpp_f<0x4E>(acc);      // quad_perm [2,3,0,1]  (stride 2)
