@@ -102,20 +102,32 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         float4* dst = (float4*)(sm + o_wres);
         for (int i = tid; i < 4 * 4 * 256; i += PIPE_NT) { const int l = i >> 10; dst[i] = p.wpk[f.w_res[L0 + l] + (i & 1023)]; }
     }
-    // resident tiles: wave w owns tile w of the interleaved current / past matrices of each of its four layers
-    float4 wc[4][4];          // (the past-tap tiles are needed only by prepare(), which runs while the workgroup waits: they stream from L2)
+    // FOUR waves run the stack (waves 4..7 leave after the set-up): lane (wave, grp, q) owns channel ch = 16*wave + grp, i.e. BOTH its
+    // sigma row and its tanh row (rows 2ch, 2ch+1 of the interleaved matrices: tile ch/8, rows 2(ch%8), +1).  The two 16-deep chains
+    // issue as v_pk_fma_f32, the gate needs no cross-lane exchange, and with one wave per SIMD a dependent VALU chain issues every
+    // 4 cycles instead of every 8 (two waves per SIMD take turns): the gate stage was 700 of a layer's 1100 cycles.
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const int zch = (wave & 3) * 16 + grp;
+    const int ztile = zch >> 3, zls = (2 * (zch & 7)) * 4 + q;          // tile, and the lane of load_tile's layout that holds my sigma row (+4: tanh row)
+    f2v wcp[4][16];
 #pragma unroll
-    for (int l = 0; l < 4; ++l) load_tile(wc[l], p.wpk, f.w_cur[L0 + l] + wave * 256, lane);
-    const int zrow = wave * 16 + grp, zch = zrow >> 1, zhalf = zrow & 1, znat = zhalf * C + zch;      // my row of every Z tile
+    for (int l = 0; l < 4; ++l) {
+        const float4* tb = p.wpk + f.w_cur[L0 + l] + ztile * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 a = tb[j * 64 + zls], b = tb[j * 64 + zls + 4];
+            wcp[l][4 * j + 0] = (f2v){a.x, b.x}; wcp[l][4 * j + 1] = (f2v){a.y, b.y}; wcp[l][4 * j + 2] = (f2v){a.z, b.z}; wcp[l][4 * j + 3] = (f2v){a.w, b.w};
+        }
+    }
     float br[4];                                                 // residual biases of my rows (waves 0..3)
-    const int rrow = (wave & 3) * 16 + grp;
+    const int rrow = zch;
 #pragma unroll
     for (int l = 0; l < 4; ++l) br[l] = p.flat[pp.f_resb[L0 + l] + rrow];
     const float cbias = (!ADAPT && tid < C) ? p.flat[p.causal_b + tid] : 0.0f;
     const int Ttot = u.n0 + u.n_samples;
     __syncthreads();
-    if (Ttot < 3) return;
-    float pdv[4], auxv[4];                                       // past-tap dots / aux terms of the coming step, per layer, for my row
+    if (Ttot < 3 || wave >= 4) return;                          // (a finished wave no longer counts at the workgroup's barriers)
+    f2v pdv[4], auxv[4];                                         // past-tap dots / aux terms of the coming step, per layer: {sigma row, tanh row}
     auto prepare = [&](int t) {                                  // everything step t needs that does not depend on step t's own input
         const int ut = aux_time(u, t);
         int fr, j;
@@ -125,7 +137,8 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         const float wj = p.U > 0 ? p.flat[p.up_w + j] : 1.0f;
         const float* pf = u.pproj + (size_t)fr * p.L * 2 * C;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) auxv[l] = __builtin_fmaf(wj, pf[(L0 + l) * 2 * C + znat], p.qb[(L0 + l) * 2 * C + znat]);
+        for (int l = 0; l < 4; ++l) auxv[l] = (f2v){__builtin_fmaf(wj, pf[(L0 + l) * 2 * C + zch], p.qb[(L0 + l) * 2 * C + zch]),
+                                                    __builtin_fmaf(wj, pf[(L0 + l) * 2 * C + C + zch], p.qb[(L0 + l) * 2 * C + C + zch])};
         // past rows x_l[t - off] -> LDS xp
         if (ADAPT) {
             const int widx = t < u.n0 - 1 ? t - (u.n0 - 1) : 0;
@@ -148,10 +161,12 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         __syncthreads();
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
-            float4 x[4], wq[4];
-            load_tile(wq, p.wpk, pp.w_past_il[L0 + l] + wave * 256, lane);
+            float4 x[4], wqs[4], wqt[4];
+            const float4* tb = p.wpk + pp.w_past_il[L0 + l] + ztile * 256;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wqs[j] = tb[j * 64 + zls]; wqt[j] = tb[j * 64 + zls + 4]; }
             rd4(x, sm + o_xp + l * C + 16 * q);
-            pdv[l] = red4(chunk16(wq, x));
+            pdv[l] = (f2v){red4(chunk16(wqs, x)), red4(chunk16(wqt, x))};
         }
     };
     prepare(1);
@@ -195,10 +210,13 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
         for (int l = 0; l < 4; ++l) {
             {
                 float4 x[4]; rd4(x, sm + o_x + l * C + 16 * q);
-                const float acc = red4(chunk16(wc[l], x));
-                const float z = (acc + pdv[l]) + auxv[l];
-                const float zo = dpp_f<0x104>(z);                 // row_shl:4 -> the tanh row of the same channel
-                if (q == 0 && !zhalf) {
+                const float xe[16] = {x[0].x, x[0].y, x[0].z, x[0].w, x[1].x, x[1].y, x[1].z, x[1].w, x[2].x, x[2].y, x[2].z, x[2].w, x[3].x, x[3].y, x[3].z, x[3].w};
+                f2v acc = wcp[l][0] * (f2v){xe[0], xe[0]};                    // the spec's chunk per row: one product, then 15 fma in k order
+#pragma unroll
+                for (int e = 1; e < 16; ++e) acc = __builtin_elementwise_fma(wcp[l][e], (f2v){xe[e], xe[e]}, acc);
+                const float z = (red4(acc.x) + pdv[l].x) + auxv[l].x;         // sigma row
+                const float zo = (red4(acc.y) + pdv[l].y) + auxv[l].y;        // tanh row of the same channel
+                if (q == 0) {
                     const float g = qgate(z, zo);
                     sm[o_g + l * C + zch] = g;
                     if (gen) pst(X + (ADAPT ? PX_G : PX_G0) + l * C + zch, tag, g);
@@ -206,7 +224,7 @@ __device__ __forceinline__ void stack_role(const DecodeParams& p, const FastPara
             }
             // operands of the residual phase that do not depend on the gate: requested before the barrier
             float4 wr4[4]; float xres = 0.0f;
-            const bool do_res = !(ADAPT && l == 3) && wave < 4;
+            const bool do_res = !(ADAPT && l == 3);
             if (do_res) {
                 const float4* tp = (const float4*)(sm + o_wres) + (l * 4 + wave) * 256 + lane;
 #pragma unroll
