@@ -377,3 +377,29 @@ def test_degenerate_lengths_on_every_kernel(kernel, cuda, oracle, monkeypatch):
         assert [len(o) for o in outs] == sorted(ns) == [len(r) for r in refs]
         for o, r in zip(outs, refs):
             np.testing.assert_array_equal(o, r)
+
+
+def test_pipelined_decode_at_full_occupancy(cuda, oracle):
+    """48 ragged utterances in one call: 240 of the 256 CUs hold the five resident roles of an utterance each (the largest batch the
+    pipelined kernel takes).  Mixed F0 scalings, lengths 40..99 frames; six rows against their single-row oracle streams, the
+    whole batch repeatable, shortest-first order kept."""
+    import torch
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    specs = [(100 + b, 40 + (b * 7) % 60, [0.5, 1.0, 1.5][b % 3]) for b in range(48)]
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    xb, hb = torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda)
+    outs = m.batch_fast_generate(xb, hb, list(ns), bd, mode="argmax")
+    assert m.last_decode_kernel_ms > 0
+    order = np.argsort(ns, kind="stable")
+    assert [len(o) for o in outs] == [ns[b] for b in order]
+    for k in (0, 7, 19, 30, 41, 47):
+        b = int(order[k])
+        x, h, d, n = synth.decode_inputs(cfg, specs[b][1], specs[b][0], specs[b][2])
+        maxd = int(np.ceil(np.nanmax(bd)))
+        np.testing.assert_array_equal(outs[k], oracle.decode(cfg, flat, h, d, x, n, maxd=maxd)["samples"], err_msg="row %d" % b)
+    outs2 = m.batch_fast_generate(xb, hb, list(ns), bd, mode="argmax")
+    for a, b2 in zip(outs, outs2):
+        np.testing.assert_array_equal(a, b2)
