@@ -110,6 +110,20 @@ __device__ __forceinline__ float tree_reduce(float acc, int logR) {
         return acc;
     }
     if (logR == 1) return acc + dpp_f<0xB1>(acc);
+    if (logR == 5) {                       // K = 512: the stride-16 partner through v_permlane16_swap_b32 (a VALU op of gfx950), then as K = 256.
+        // swap(a, a) leaves {row0, row0, row2, row2} in the first result and {row1, row1, row3, row3} in the second: the lane's
+        // partner (lane ^ 16) is the second on even rows, the first on odd rows -- no trip through the LDS crossbar (a ds_bpermute
+        // per step was a 5-deep ~120-cycle chain in front of every row of the wide models' matvecs)
+        const int a = __float_as_int(acc);
+        const auto sw = __builtin_amdgcn_permlane16_swap(a, a, false, false);
+        const float partner = __int_as_float((threadIdx.x & 16) ? (int)sw[0] : (int)sw[1]);
+        acc = acc + partner;
+        acc = acc + dpp_f<0x128>(acc);
+        acc = acc + dpp_f<0x124>(acc);
+        acc = acc + dpp_f<0x4E>(acc);
+        acc = acc + dpp_f<0xB1>(acc);
+        return acc;
+    }
     for (int s = (1 << logR) >> 1; s >= 1; s >>= 1) acc = acc + __shfl_xor(acc, s);
     return acc;
 }
