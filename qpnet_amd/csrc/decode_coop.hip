@@ -75,7 +75,14 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
     const int o_xa = o; o += Cp; const int o_xb = o; o += Cp; const int o_xp = o; o += L * Cp; const int o_g = o; o += Cp;
     const int o_y1 = o; o += c.Sp; const int o_y2 = o; o += c.Sp; const int o_lg = o; o += (Q + 3) & ~3;
     const int o_acc = o; o += (2 * SB + 3) & ~3; const int o_aux = o; o += L * 2 * CB; const int o_samp = o; o += 4;
-    for (int i = tid; i < o; i += COOP_NT) sm[i] = 0.0f;
+    // the biases my rows add, in LDS: read from global memory where they are used, each sat behind its own wait right after a row's
+    // reduction (an exposed L2 round trip per tile pass)
+    const int o_bres = o; o += L * CB; const int o_bsk = o; o += L * SB; const int o_bp1 = o; o += SB; const int o_bp2 = o; o += QB;
+    for (int i = tid; i < o_bres; i += COOP_NT) sm[i] = 0.0f;
+    for (int i = tid; i < L * CB; i += COOP_NT) sm[o_bres + i] = p.flat[c.f_resb[i / CB] + c0 + i % CB];
+    for (int i = tid; i < L * SB; i += COOP_NT) sm[o_bsk + i] = p.flat[c.f_skipb[i / SB] + s0 + i % SB];
+    for (int i = tid; i < SB; i += COOP_NT) sm[o_bp1 + i] = p.flat[c.f_p1b + s0 + i];
+    for (int i = tid; i < QB; i += COOP_NT) sm[o_bp2 + i] = p.flat[c.f_p2b + q0 + i];
     __syncthreads();
     const int Ttot = u.n0 + u.n_samples;
     if (Ttot < 3) return;
@@ -149,7 +156,9 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                 const float ap = tree_reduce(chunk16(wqN, xp), logR);
                 const int row = ti * rpt + grp, ch = row >> 1, half = row & 1;
                 const float z = (ac + ap) + sm[o_aux + l * 2 * CB + half * CB + (ch - c0)];
-                const float zo = __shfl_down(z, R);           // the tanh row of the same channel
+                float zo;                                     // the tanh row of the same channel (R lanes up)
+                if (R == 32) { const int zi = __float_as_int(z); const auto sw = __builtin_amdgcn_permlane32_swap(zi, zi, false, false); zo = __int_as_float((int)sw[1]); }
+                else zo = __shfl_down(z, R);
                 if (q == 0 && !half) gr_store(X + c.o_g + (size_t)l * C + ch, tag, qgate(z, zo));
             }
             const bool has_res = l + 1 < L;               // the last block's residual output is unused (qpnet.py:505)
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                     if (i < nres) {
                         const int row = (c0 / rpt + i) * rpt + grp;
                         if (q == 0) {
-                            const float v = (acc + p.flat[c.f_resb[l] + row]) + sm[xin + row];
+                            const float v = (acc + sm[o_bres + l * CB + (row - c0)]) + sm[xin + row];
                             const RingDesc rn = p.rings[l + 1];
                             gr_store(X + c.o_ring[l + 1] + (size_t)((unsigned)t % (unsigned)rn.len) * C + row, tag, v);
                         }
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                         const int row = (s0 / rpt + (i - nres)) * rpt + grp;
                         if (q == 0) {
                             const int a = o_acc + (f.adaptive[l] ? SB : 0) + (row - s0);
-                            sm[a] = sm[a] + (acc + p.flat[c.f_skipb[l] + row]);
+                            sm[a] = sm[a] + (acc + sm[o_bsk + l * SB + (row - s0)]);
                         }
                     }
                 }
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                 if (i != wave) load_tile(wrN, p.wpk, f.w_p1 + ti * 256, lane);
                 const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
-                if (qs == 0) { const float v = acc + p.flat[c.f_p1b + row]; gr_store(X + c.o_y2 + row, tag, v > 0.0f ? v : 0.0f); }
+                if (qs == 0) { const float v = acc + sm[o_bp1 + (row - s0)]; gr_store(X + c.o_y2 + row, tag, v > 0.0f ? v : 0.0f); }
             }
         }
         if (wave < QB / rpts) load_tile(wrN, p.wpk, f.w_p2 + (q0 / rpts + wave) * 256, lane);
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                 if (i != wave) load_tile(wrN, p.wpk, f.w_p2 + ti * 256, lane);
                 const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
-                if (qs == 0) gr_store(X + c.o_lg + row, tag, acc + p.flat[c.f_p2b + row]);
+                if (qs == 0) gr_store(X + c.o_lg + row, tag, acc + sm[o_bp2 + (row - q0)]);
             }
         }
         gather_vec(X + c.o_lg, Q, tag, sm + o_lg, tid, c.abort, p.status);
@@ -294,7 +303,7 @@ int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStre
     }
     c.xch = h->d_xch + 16; c.abort = (int*)h->d_xch;          // first 128 bytes: the abort flag
     // LDS of the kernel
-    int lds = 2 * g.Cp + L * g.Cp + g.Cp + 2 * g.Sp + ((Q + 3) & ~3) + ((2 * c.SB + 3) & ~3) + L * 2 * c.CB + 4;
+    int lds = 2 * g.Cp + L * g.Cp + g.Cp + 2 * g.Sp + ((Q + 3) & ~3) + ((2 * c.SB + 3) & ~3) + L * 2 * c.CB + 4 + L * (c.CB + c.SB) + c.SB + c.QB;
     const size_t lds_bytes = (size_t)lds * sizeof(float);
     if (lds_bytes > 160 * 1024) { qpn_set_error("cooperative decode: %zu KiB of step state per workgroup exceed LDS (use more workgroups per utterance)", lds_bytes >> 10); return QPN_EINVAL; }
     QPN_HIP(hipFuncSetAttribute((const void*)k_decode_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
