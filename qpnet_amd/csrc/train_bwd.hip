@@ -486,8 +486,8 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
 // the matrix-core loop, no branches around the staging loads (out-of-range rows are clamped and zeroed, the three
 // sources of the [x_cur | x_past | aux] operand become one per-thread base/stride), bias column sums taken from the
 // staging registers instead of 32 LDS reads per stage.  k_wgrad2 stays as the generic fallback.
-template <int BMODE, int MPW, int NT>
-__global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
+template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
     extern __shared__ float sm[];
     constexpr int RS = 32, Mp = 64 * MPW, Np = 16 * NT;
     constexpr int ldA = ((Mp + 15) / 32) * 32 + 16, ldB = ((Np + 15) / 32) * 32 + 16;       // tr_ldt
@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     const int64_t per = ((total + nch - 1) / nch + RS - 1) / RS * RS;
     const int rbeg = (int)(per * ch), rend = (int)(per * ch + per < total ? per * ch + per : total);
     const float* A = w.A + (size_t)y * w.A_lstride;
-    const float* A2 = w.A2 ? w.A2 + (size_t)y * w.A_lstride : nullptr;
+    const float* A2 = TWO_A ? w.A2 + (size_t)y * w.A_lstride : nullptr;      // TWO_A: the A operand is the sum of two arrays (a template flag: the second
+                                                                               // staging set costs 32 registers the one-array launches need for a third workgroup per CU)
     const float* B1 = BMODE == 4 ? nullptr : w.B1 + (size_t)y * w.B_lstride;
     const float* B2 = w.B2 ? w.B2 + (size_t)y * w.B_lstride : nullptr;
     const int* tap = BMODE == 3 ? w.tap + w.tap_off[y] : nullptr;      // BMODE 3: a tap table for every layer (the launcher checks)
@@ -533,7 +534,6 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
     int tpv[NB];
-    bool a_ok[NA];
 
     // rows of a stage: r in [0,32); rows at or past rend are clamped to the last valid row and zeroed
     auto rowsplit = [&](int rr, int& b, int& i) { if (multi) { b = (int)((unsigned)rr / uR); i = rr - b * (int)uR; } else { b = 0; i = rr; } };
@@ -558,9 +558,8 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
             int b, i; rowsplit(rr, b, i);
             const size_t o = ((size_t)b * w.rowsA + row0A + i) * w.lda + a_col;
             const float4 v = *(const float4*)(A + o);
-            if (A2) ra2[k] = *(const float4*)(A2 + o);          // summed when the stage goes to LDS: no wait between the passes' loads
+            if (TWO_A) ra2[k] = *(const float4*)(A2 + o);       // summed when the stage goes to LDS: no wait between the passes' loads
             ra[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            a_ok[k] = ok;
         }
         if (b_act) {
 #pragma unroll
@@ -593,7 +592,7 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             float4 v = ra[k];
-            if (A2 && a_ok[k]) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
+            if (TWO_A && rs + a_row0 + k * ARS < rend) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
             cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;
             *(float4*)(As + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
         }
@@ -649,6 +648,13 @@ __global__ __launch_bounds__(256) void k_wgrad3(Wg2 w, int nch) {
     }
 }
 
+template <int BMODE, int MPW, int NT, bool TWO_A>
+static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t stream) {
+    // the 256 x 64 one-array launches (post-net, skip 1x1) sit two registers above the three-workgroups-per-CU line: ask for it
+    constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? 3 : 1;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+}
 template <int BMODE, int MPW, int NT>
 static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     const int Ng = w.N / w.ncol_groups;
@@ -656,8 +662,8 @@ static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4) || !w.tap)) return false;
     if (BMODE == 3) for (int l = 0; l < w.nlayers; ++l) if (w.tap_off[l] < 0) return false;      // the kernel loads taps unconditionally
     const size_t lds = (size_t)32 * (tr_ldt(64 * MPW) + tr_ldt(16 * NT)) * sizeof(float);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    if (w.A2) launch_wgrad3_k<BMODE, MPW, NT, true>(w, nch, lds, stream);
+    else launch_wgrad3_k<BMODE, MPW, NT, false>(w, nch, lds, stream);
     return true;
 }
 static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
