@@ -996,7 +996,7 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
                        h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.L, h->d_pproj);
     p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
     p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
-    p.stamps = (getenv("QPN_STAMPS") || getenv("QPN_PIPE_STAMPS")) ? (long long*)(h->d_status + 16) : nullptr;
+    p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
     if (coopG) {
@@ -1054,12 +1054,6 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
     int status = 0;
     QPN_HIP(hipMemcpy(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
     QPN_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-    if (getenv("QPN_PIPE_STAMPS")) {  // dev aid: per-role cycles of the pipelined kernel, utterance 0: waiting for the input / input -> hand-off
-        long long st[9];
-        QPN_HIP(hipMemcpy(st, h->d_status + 16, sizeof(st), hipMemcpyDeviceToHost));
-        const char* nm[4] = {"S0 (layers 0-3)", "S1 (layers 4-7)", "K (skip + post1)", "P (post2 + pick)"};
-        for (int r = 0; r < 4; ++r) fprintf(stderr, "pipe role %-18s wait %12lld cycles   service %12lld cycles\n", nm[r], st[2 * r], st[2 * r + 1]);
-    } else
     if (getenv("QPN_STAMPS")) {      // dev aid: stamp times (cycles, relative to the first stamp of wave 0) of step 3000
         std::vector<long long> st((size_t)120 * QPN_NW);
         QPN_HIP(hipMemcpy(st.data(), h->d_status + 16, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
