@@ -456,9 +456,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 3 if args.mode == "decode" else 50
+        args.steps = 3 if args.mode == "decode" else 200
     if args.warmup is None:
-        args.warmup = 1 if args.mode == "decode" else 5
+        args.warmup = 1 if args.mode == "decode" else 20
     self_launch(args.gpus)
     rank, local, world = dist_setup(args.gpus)
     if args.gpus != world and rank == 0:
