@@ -1,0 +1,60 @@
+"""Register / scratch budget of the hot kernels, read from hipcc's resource report (no GPU needed).
+
+A value that spills to scratch memory is re-read inside the per-sample or per-chunk loop with an s_waitcnt in front of it: the
+pipelined decode kernel lost 10 % to seven such reloads before its biases moved to LDS, the GEMM loader
+80 bytes per lane per chunk before its staging registers became scalars (section 5b).  This pins the state they are in now."""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qpnet_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# kernel-name fragment -> (file, max scratch bytes per lane, min waves per SIMD)
+BUDGET = {
+    "k_decode_pipe": ("decode_pipe.hip", 0, 2),
+    "k_layer_fwdILi1E": ("train_fwd.hip", 0, 5),          # five 16-row workgroups per CU must be co-resident
+    "k_post_fwdILi1E": ("train_fwd.hip", 0, 5),
+    "k_layer_bwdILi1E": ("train_bwd.hip", 0, 5),
+    "k_wgrad3ILi1ELi4ELi4ELb0ELi3E": ("train_bwd.hip", 0, 3),      # post-net weight gradients: three workgroups per CU
+    "k_wgrad3ILi2ELi4ELi4ELb0ELi3E": ("train_bwd.hip", 0, 3),      # skip 1x1
+    "k_wgrad3ILi3ELi2ELi11ELb0": ("train_bwd.hip", 0, 2),
+    "k_gemm_nnILi0ELi1E": ("train_gemm.hip", 0, 3),
+    "k_gemm_nnILi1ELi4E": ("train_gemm.hip", 0, 3),
+    "k_gemm_tnILi3E": ("train_gemm.hip", 0, 3),
+}
+
+
+def _report(fname):
+    out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-c",
+                          os.path.join(CSRC, fname), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1); kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+?):\s+(\d+)", line)
+        if m and cur:
+            kernels[cur][m.group(1).strip()] = int(m.group(2))
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_stay_within_their_register_budget():
+    files = sorted({v[0] for v in BUDGET.values()})
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        reports = dict(zip(files, ex.map(_report, files)))
+    for frag, (fname, max_scratch, min_occ) in BUDGET.items():
+        hits = {k: v for k, v in reports[fname].items() if frag in k}
+        assert hits, "no kernel matching %s in %s: %s" % (frag, fname, sorted(reports[fname]))
+        for name, r in hits.items():
+            scratch = r.get("ScratchSize [bytes/lane]", -1)
+            occ = r.get("Occupancy [waves/SIMD]", -1)
+            assert 0 <= scratch <= max_scratch, "%s spills %d bytes per lane to scratch memory" % (name, scratch)
+            assert occ >= min_occ, "%s: %d waves per SIMD, needs %d" % (name, occ, min_occ)
