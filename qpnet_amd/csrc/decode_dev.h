@@ -187,9 +187,12 @@ __device__ __forceinline__ int sample_wave_u(int o_lg, int Q, float u, int lane)
 #pragma unroll
     for (int j = 1; j < 4; ++j) if (j < per) a = a + e[j];
     float v = a;
-    for (int d = 1; d < 64; d <<= 1) { const float up = __shfl_up(v, d); if (lane >= d) v = v + up; }
+    {   // d = 1 through the wave-wide DPP shift (wave_shr:1, lane 0 reads 0), the wider strides through the LDS crossbar
+        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); if (lane >= 1) v = v + up;
+    }
+    for (int d = 2; d < 64; d <<= 1) { const float up = __shfl_up(v, d); if (lane >= d) v = v + up; }
     const float total = rl_f(v, 63);
-    float c = __shfl_up(v, 1);
+    float c = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
     if (lane == 0) c = 0.0f;
     const float th = u * total;
     int idx = 0x7fffffff;
