@@ -76,7 +76,7 @@ __global__ void k_gather_f(const float* __restrict__ flat, const int* __restrict
     if (i < n) { int m = map[i]; out[i] = m >= 0 ? flat[m] : 0.0f; }
 }
 // the per-step refresh of everything derived from the parameters, in ONE launch: weight blocks (fragment order or K-major), the
-// transposed causal table, the packed bias sums; also clears the status word and the loss accumulator of the coming step
+// transposed causal table, the packed bias sums; also clears the loss accumulator of the coming step
 __global__ void k_refresh(const float* __restrict__ flat, const int* __restrict__ wmap, float* __restrict__ wout, int64_t nw,
                           const int* __restrict__ ctmap, float* __restrict__ ct, int64_t nct,
                           const int* __restrict__ bstart, const int* __restrict__ blist, float* __restrict__ bp, int nb,
@@ -88,8 +88,10 @@ __global__ void k_refresh(const float* __restrict__ flat, const int* __restrict_
     i -= nct;
     if (i < nb) { float a = 0.f; for (int j = bstart[i]; j < bstart[i + 1]; ++j) a += flat[blist[j]]; bp[i] = a; return; }
     i -= nb;
-    if (i < 16) status[i] = 0;
-    else if (i < 16 + 64) loss[i - 16] = 0.0;
+    // (the status word is STICKY: kernels OR into it, only qpn_train_status clears it when it reads it -- a check every N steps
+    //  then still sees an out-of-range tap / target of any step in between; the reference asserts on every step)
+    (void)status;
+    if (i >= 16 && i < 16 + 64) loss[i - 16] = 0.0;
 }
 __global__ void k_bias_pack(const float* __restrict__ flat, const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,6 +274,7 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_gsrc, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
+    QPN_HIP(hipMemset(t->d_status, 0, 64));
     QPN_HIP(hipMalloc(&t->d_loss, 64 * sizeof(double)));
     if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -447,6 +450,7 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     QPN_HIP(hipStreamSynchronize((hipStream_t)stream_));
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) QPN_HIP(hipMemset(h->train->d_status, 0, sizeof(int)));          // sticky until read: reported once
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;

@@ -56,47 +56,74 @@ def decode_generator(feats, fs, feat_ids=None, wav_transform=None, feat_transfor
 
 
 class _SampleWindow:
-    """The trainer's running window over the concatenated utterance stream: one waveform-rate array pair (samples,
-    dilated factors) and one frame-rate array (features), consumed from the front by explicit offsets.  Storage is
-    compacted only when the consumed prefix outweighs the live part, so appending an utterance costs its own length."""
+    """The trainer's running window over the concatenated utterance stream, kept as a queue of per-utterance segments
+    (samples, frame-rate dilated factors + their suffix maxima, features) and consumed from the front by a frame offset.
+    Appending an utterance is O(1): nothing is concatenated until a chunk is actually cut (`front`), and the largest
+    dilated factor still in the window -- which sets the receptive field after every append -- comes from the suffix
+    maxima instead of a pass over the sample-rate array.  Every utterance holds exactly U samples per frame
+    (harness.validate_length), so the window's sample offset is always U times its frame offset."""
 
-    def __init__(self, n_feat, feat_dtype):
-        self.x = np.empty(0, dtype=np.float32)
-        self.d = np.empty(0, dtype=np.float64)          # float32 buffer + float64 factors promote to float64 upstream too
-        self.h = np.empty((0, n_feat), dtype=np.result_type(np.float32, feat_dtype))
-        self.s0 = 0                                     # first live sample
-        self.f0 = 0                                     # first live frame
-
-    def append(self, x, h, d):
-        if self.s0 > len(self.x) - self.s0:             # drop the consumed prefix
-            self.x, self.d, self.h = self.x[self.s0:], self.d[self.s0:], self.h[self.f0:]
-            self.s0 = self.f0 = 0
-        self.x = np.concatenate([self.x, np.asarray(x, dtype=np.float32)])
-        self.d = np.concatenate([self.d, np.asarray(d, dtype=np.float64)])
-        self.h = np.concatenate([self.h, h.astype(self.h.dtype, copy=False)])
+    def __init__(self, n_feat, feat_dtype, U):
+        import collections
+        self.U = int(U)
+        self.segs = collections.deque()                 # [x (F*U,) f32, d (F,) f64, sufmax (F,) f64, h (F, D)]
+        self.f0 = 0                                     # frames of the first segment already consumed
+        self.n_frames = 0                               # live frames / samples in the window
+        self.h_dtype = np.result_type(np.float32, feat_dtype)
+        self.n_feat = n_feat
 
     @property
     def n_samples(self):
-        return len(self.x) - self.s0
+        return self.n_frames * self.U
 
-    @property
-    def n_frames(self):
-        return len(self.h) - self.f0
+    def append(self, x, h, d_frames):
+        d = np.asarray(d_frames, dtype=np.float64)      # float32 buffer + float64 factors promote to float64 upstream too
+        assert len(x) == len(d) * self.U == h.shape[0] * self.U
+        if len(d) == 0:
+            return
+        sufmax = np.maximum.accumulate(d[::-1])[::-1]
+        self.segs.append((np.asarray(x, dtype=np.float32), d, sufmax, h.astype(self.h_dtype, copy=False)))
+        self.n_frames += len(d)
 
     def max_factor(self):
-        return self.d[self.s0:]
+        """largest dilated factor among the live samples (what np.nanmax over the reference's d_buffer returns)."""
+        m = -np.inf
+        for k, seg in enumerate(self.segs):
+            m = max(m, seg[2][self.f0 if k == 0 else 0])
+        return m
 
     def front(self, frames, samples):
-        return (self.x[self.s0:self.s0 + samples], self.h[self.f0:self.f0 + frames], self.d[self.s0:self.s0 + samples])
+        """first `frames` feature rows and `samples` (= frames*U + 1) samples / sample-rate factors of the window."""
+        U = self.U
+        xs, ds, hs = [], [], []
+        need_s, need_f, off = samples, frames, self.f0
+        for x, d, _, h in self.segs:
+            if need_s <= 0:
+                break
+            take_s = min(need_s, len(x) - off * U)
+            take_fd = -(-take_s // U)                   # frames whose factors those samples repeat
+            xs.append(x[off * U:off * U + take_s])
+            ds.append(np.repeat(d[off:off + take_fd], U)[:take_s])
+            if need_f > 0:
+                take_f = min(need_f, len(d) - off)
+                hs.append(h[off:off + take_f]); need_f -= take_f
+            need_s -= take_s
+            off = 0
+        cat = lambda parts: parts[0] if len(parts) == 1 else np.concatenate(parts)      # noqa: E731
+        return cat(xs), cat(hs), cat(ds)
 
     def advance(self, frames, samples):
+        assert samples == frames * self.U
+        self.n_frames -= frames
         self.f0 += frames
-        self.s0 += samples
+        while self.segs and self.f0 >= len(self.segs[0][1]):
+            self.f0 -= len(self.segs[0][1])
+            self.segs.popleft()
 
 
 def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_receptiveA, fs, wav_transform=None,
                     feat_transform=None, dense_factor=8, batch_length=20000, batch_size=1, max_length=23070,
-                    f0_threshold=0, upsampling_factor=80, shuffle=True, device=None, epochs=None):
+                    f0_threshold=0, upsampling_factor=80, shuffle=True, device=None, epochs=None, shard=None):
     """Chunked teacher-forcing batches over a stream of utterances (reference generator: src/bin/qpnet_train.py:200-335).
 
     utterances: list of (x float waveform in [-1,1], h (F, n_aux)) pairs, or zero-argument callables returning such a
@@ -106,8 +133,15 @@ def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_r
     that survives epoch boundaries; after each appended utterance the receptive field is taken from the largest dilated
     factor still in the window, the batch length is cut to fit max_length and a whole number of frames, and chunks of
     RF + BL (+1 sample for the input/target shift) are cut while MORE than `slots_left` chunks' worth of frames and
-    samples remain, each advancing the window by BL (so consecutive chunks overlap by RF)."""
+    samples remain, each advancing the window by BL (so consecutive chunks overlap by RF).
+
+    shard = (rank, world): data-parallel ranks walk the SAME stream (same seed, same chunk boundaries) but only batch
+    numbers rank, rank + world, ... are materialised and yielded; for the others the window just advances -- no mu-law
+    encoding, scaling or tensor is made for a chunk another rank consumes (no counterpart in the reference, whose only
+    multi-GPU path is a dead DataParallel wrapper, qpnet_train.py:416-423)."""
     U = int(upsampling_factor)
+    rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
+    n_batches = 0                                       # batches cut so far, over all ranks
     n_files = len(utterances)
     order = np.random.permutation(n_files) if shuffle else np.arange(n_files)
     win = None
@@ -121,30 +155,36 @@ def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_r
             x, h = harness.validate_length(np.array(x, dtype=np.float32), np.asarray(h), U)
             d = harness.dilated_factor(harness.batch_f0(h, f0_threshold), fs, dense_factor)
             if win is None:
-                win = _SampleWindow(h.shape[1], h.dtype)
-            win.append(x, h, np.repeat(d, U))
+                win = _SampleWindow(h.shape[1], h.dtype, U)
+            win.append(x, h, d)
             rf = harness.receptive_field(model_receptiveCausal, model_receptiveF, model_receptiveA, win.max_factor())
             bl, frames, samples = harness.chunk_plan(rf, batch_length, max_length, U)
             hop_frames = bl // U
             while win.n_frames > slots_left * frames and win.n_samples > slots_left * samples:
-                xs, hs, ds = win.front(frames, samples)
-                if wav_transform is not None:
-                    xs = wav_transform(xs)
-                if feat_transform is not None:
-                    hs = feat_transform(hs)
-                xs = torch.from_numpy(np.asarray(xs)).long()
-                rows.append((xs[:-1], torch.from_numpy(np.asarray(hs)).float().transpose(0, 1), xs[1:],
-                             torch.from_numpy(np.asarray(ds)).float()[:-1], bl))
+                mine = n_batches % world == rank
+                if mine:
+                    xs, hs, ds = win.front(frames, samples)
+                    if wav_transform is not None:
+                        xs = wav_transform(xs)
+                    if feat_transform is not None:
+                        hs = feat_transform(hs)
+                    xs = torch.from_numpy(np.asarray(xs)).long()
+                    rows.append((xs[:-1], torch.from_numpy(np.asarray(hs)).float().transpose(0, 1), xs[1:],
+                                 torch.from_numpy(np.asarray(ds)).float()[:-1], bl))
+                else:
+                    rows.append(None)
                 slots_left -= 1
                 win.advance(hop_frames, hop_frames * U)
                 if len(rows) == batch_size:
-                    out = tuple(torch.stack([r[k] for r in rows]) for k in range(4)) + (torch.tensor([r[4] for r in rows]),)
-                    if device is not None:
-                        out = tuple(o.to(device) for o in out)
-                    yield out
+                    if mine:
+                        out = tuple(torch.stack([r[k] for r in rows]) for k in range(4)) + (torch.tensor([r[4] for r in rows]),)
+                        if device is not None:
+                            out = tuple(o.to(device) for o in out)
+                        yield out
                     rows, slots_left = [], batch_size
+                    n_batches += 1
         if shuffle:
-            order = np.random.permutation(n_files)
+            order = order[np.random.permutation(n_files)]      # the reference re-shuffles the ALREADY shuffled list (:331-335)
         epoch += 1
 
 

@@ -17,7 +17,6 @@ all-reduced once per step; decode splits the utterance list over ranks with no c
 With --n_gpus N > 1 and no torchrun environment the entry point re-launches itself as N ranks (before any GPU call).
 """
 import argparse
-import itertools
 import logging
 import os
 import queue
@@ -115,7 +114,10 @@ def _utterance_loaders(wav_list, feat_list, feature_type):
     return [make(w, f) for w, f in zip(wav_list, feat_list)]
 
 
-def _batches(args, conf, model, shuffle, epochs, device):
+def _batches(args, conf, model, shuffle, epochs, device, rank=0, world=1):
+    """Training / validation batches on `device`.  With world > 1 rank r takes chunks r, r+N, ... of the generator's
+    stream (same seed on every rank: identical shuffles and chunk boundaries) INSIDE the generator: a rank encodes,
+    scales, takes ceil(max d) of and copies to its GPU only its own chunks."""
     wavs, feats = loaders.file_lists(args.waveforms, args.feats, conf.feature_format)
     logging.info("number of utterances = %d." % len(wavs))
     scaler = loaders.read_scaler_stats(args.stats, conf.feature_type)
@@ -124,7 +126,8 @@ def _batches(args, conf, model, shuffle, epochs, device):
         _utterance_loaders(wavs, feats, conf.feature_type), model.receptiveCausal_field, model.receptiveF_field,
         model.receptiveA_field, fs, wav_transform=loaders.mu_law_transform(conf.n_quantize), feat_transform=scaler,
         dense_factor=conf.dense_factor, batch_length=args.batch_length, batch_size=args.batch_size, max_length=args.max_length,
-        f0_threshold=args.f0_threshold, upsampling_factor=conf.upsampling_factor, shuffle=shuffle, epochs=epochs)
+        f0_threshold=args.f0_threshold, upsampling_factor=conf.upsampling_factor, shuffle=shuffle, epochs=epochs,
+        shard=(rank, world) if world > 1 else None)
 
     def with_maxd():            # ceil(max d) is known on the host here: the fused step then needs no device read-back
         for bx, bh, bt, bd, bb in gen:
@@ -206,8 +209,7 @@ def run_train(argv=None, update=False):
         logging.info("updating based on %s." % args.pretrain)
     from .train import ensure_flat
     parallel.broadcast_parameters(ensure_flat(model, dev))
-    stream = _batches(args, conf, model, True, None, dev)
-    stream = Prefetcher(itertools.islice(stream, rank, None, world))      # rank r: chunks r, r+N, r+2N, ...
+    stream = Prefetcher(_batches(args, conf, model, True, None, dev, rank, world))      # rank r: chunks r, r+N, r+2N, ...
     loss = total = 0.0
     logging.info("training start!")
     for i in range(iterations, args.iters):
@@ -251,7 +253,18 @@ def run_validate(argv=None):
     p.add_argument("--verbose", default=1, type=int)
     args = p.parse_args(sys.argv[1:] if argv is None else argv)
     _setup_logging(args.verbose)
-    rank, world, dev = dist_context()
+    # validation is one forward-only pass over the list (reference qpnet_validate.py:409-437): a single process.  --n_gpus is
+    # accepted for command-line compatibility; under a multi-rank launcher rank 0 evaluates and writes the yml, the other
+    # ranks leave at once (no process group is created, nothing to tear down)
+    if int(os.environ.get("RANK", "0")) != 0:
+        return 0
+    if args.n_gpus > 1:
+        logging.warning("validation runs on one GPU; --n_gpus %d ignored" % args.n_gpus)
+    if not torch.cuda.is_available():
+        raise RuntimeError("qpnet_amd needs an AMD GPU: there is no CPU fallback for the hot path")
+    local = 0 if os.environ.get("QPN_BENCH_ONE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     _fix_seed(args.seed)
     conf = loaders.load_model_conf(args.config)
     from .train import FusedTrainer

@@ -6,7 +6,7 @@ data (seeds, small inputs, expected outputs) and are what travels to the GPU box
 Inputs are regenerated from seeds by qpnet_amd.synth (np.random.RandomState: frozen streams),
 so fixtures store only what cannot be regenerated: the reference's outputs.
 
-    python tests/golden/make_golden.py [--only decode|decode2|forward|train|kat]
+    python tests/golden/make_golden.py [--only decode|decode2|decode_d|forward|train|kat|default]
 """
 import argparse
 import os
@@ -27,7 +27,7 @@ import qpnet as ref  # noqa: E402  (the reference module)
 from qpnet_amd import synth  # noqa: E402
 from qpnet_amd.config import TINY, PAPER, QPNetConfig  # noqa: E402
 sys.path.insert(0, HERE)
-from cases import (DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, FORWARD_CASES_D, TRAIN_CASES_D,  # noqa: E402
+from cases import (DECODE_CASES, DECODE_CASES2, DECODE_CASES_D, FORWARD_CASES, TRAIN_CASES, FORWARD_CASES_D, TRAIN_CASES_D,  # noqa: E402
                    decode2_inputs)
 
 torch.set_num_threads(8)
@@ -75,10 +75,10 @@ def gen_kat():
 
 
 
-def gen_decode():
+def gen_decode(cases=DECODE_CASES, fname="decode.npz"):
     from qpnet_amd import harness
     out = {}
-    for name, cfg, wseed, utts, extra in DECODE_CASES:
+    for name, cfg, wseed, utts, extra in cases:
         flat = synth.make_weights(cfg, wseed)
         m = build_ref(cfg, flat)
         xs, hs, ds, ns = [], [], [], []
@@ -96,8 +96,8 @@ def gen_decode():
             out["%s_out%d" % (name, i)] = np.asarray(s).astype(np.int16)
         out[name + "_nleft"] = np.array(nlist, dtype=np.int64)
         print(name, [len(s) for s in streams], "n_samples_list after:", nlist)
-    np.savez_compressed(os.path.join(HERE, "decode.npz"), **out)
-    print("decode.npz written")
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written")
 
 
 
@@ -182,7 +182,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = [a.only] if a.only else ["kat", "decode", "decode2", "forward", "train", "default"]
+    todo = [a.only] if a.only else ["kat", "decode", "decode2", "decode_d", "forward", "train", "default"]
     for t in todo:
         {"kat": gen_kat, "decode": gen_decode, "decode2": gen_decode2, "forward": gen_forward, "train": gen_train,
+         "decode_d": lambda: gen_decode(DECODE_CASES_D, "decode_d.npz"),
          "default": lambda: (gen_forward(FORWARD_CASES_D, "forward_d.npz"), gen_train(TRAIN_CASES_D, "train_d.npz", 2000))}[t]()

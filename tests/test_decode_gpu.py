@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from cases import DECODE_CASES, DECODE_CASES2, decode2_inputs
+from cases import DECODE_CASES, DECODE_CASES2, DECODE_CASES_D, decode2_inputs
 from qpnet_amd import synth
 import util
 
@@ -301,6 +301,23 @@ def test_default_geometry_decode_vs_oracle(cuda, oracle):
     assert [len(o) for o in outs] == sorted(ns)
     for a, b in zip(outs, o_outs):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", DECODE_CASES_D, ids=[c[0] for c in DECODE_CASES_D])
+def test_default_geometry_decode_matches_reference_streams(case, cuda, golden_dir):
+    """the repo-default geometry against greedy streams made by the REFERENCE itself (decode_d.npz: 2 199 samples at
+    B=1; B=2 of unequal lengths at F0 x 1.5), bit-exact, completion order and list consumption included."""
+    import torch
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode_d.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, bd, mode="argmax")
+    assert nlist == list(g[name + "_nleft"])
+    assert len(outs) == len(utts)
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="HIP vs reference stream, row %d" % i)
 
 
 # ---------------------------------------------------------------- four pipelined workgroups per utterance, resident weights (decode_pipe.hip)

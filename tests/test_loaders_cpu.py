@@ -91,3 +91,97 @@ def test_hdf5_helpers_fail_loudly_without_h5py():
         pytest.skip("h5py present")
     with pytest.raises(ImportError):
         loaders.read_hdf5("nope.h5", "/world")
+
+
+def test_train_generator_shards_are_the_round_robin_of_the_full_stream():
+    """data-parallel ranks walk the same stream; rank r materialises batches r, r+N, ... only (runners._batches)."""
+    cfg = TINY
+    U = cfg.upsampling_factor
+    rs = np.random.RandomState(3)
+    utts = [(rs.uniform(-1, 1, 70 * U + 3).astype(np.float32), synth.make_features(70, 300 + i)) for i in range(4)]
+    calls = {"n": 0}
+
+    def counting_mu_law(x):
+        calls["n"] += 1
+        return loaders.mu_law_transform(256)(x)
+
+    def run(shard):
+        np.random.seed(7)                       # same seed on every rank: identical shuffles
+        calls["n"] = 0
+        gen = loaders.train_generator(utts, cfg.receptiveCausal_field, cfg.receptiveF_field, cfg.receptiveA_field, 22050,
+                                      wav_transform=counting_mu_law, batch_length=1500, max_length=4000,
+                                      upsampling_factor=U, shuffle=True, epochs=2, shard=shard)
+        return list(gen), calls["n"]
+    full, n_full = run(None)
+    assert len(full) >= 8 and n_full == len(full)
+    for world in (2, 3):
+        total = 0
+        for rank in range(world):
+            part, n_part = run((rank, world))
+            assert n_part == len(part)          # nothing is encoded for a chunk another rank consumes
+            want = full[rank::world]
+            assert len(part) == len(want)
+            for a, b in zip(part, want):
+                assert all(torch.equal(u, v) for u, v in zip(a, b))
+            total += len(part)
+        assert total == len(full)
+
+
+# ---------------------------------------------------------------- pinned to the reference's own generators (generators.npz)
+def _sk_scaler(mean, scale):
+    from sklearn.preprocessing import StandardScaler
+    sc = StandardScaler()
+    sc.mean_, sc.scale_ = mean, scale
+    return sc.transform
+
+
+import pytest                                                                      # noqa: E402
+from cases import GEN_TRAIN_CASES, GEN_DECODE_CASES, generator_corpus, crc        # noqa: E402
+
+
+@pytest.mark.parametrize("case", GEN_TRAIN_CASES, ids=[c["name"] for c in GEN_TRAIN_CASES])
+def test_train_generator_equals_reference_generator(case, golden_dir):
+    """chunk for chunk: shapes, batch_length_current and the bytes of x / h / t / d equal what the reference's
+    train_generator (src/bin/qpnet_train.py:200-335) yielded on the same utterances, incl. a wav shorter than its
+    frames, batch_length shrunk by max_length, per-chunk receptive fields and the epoch wrap with re-shuffles."""
+    gold = np.load(golden_dir + "/generators.npz")["train_" + case["name"]]
+    pcm, feats, mean, scale = generator_corpus(case["corpus_seed"], case["frames"], case["sample_slack"], case["f0"], case["U"])
+    utts = [(p.astype(np.float32) / 32768, f) for p, f in zip(pcm, feats)]
+    np.random.seed(case["np_seed"])
+    gen = loaders.train_generator(utts, case["rc"], case["rf"], case["ra"], 22050, wav_transform=loaders.mu_law_transform(256),
+                                  feat_transform=_sk_scaler(mean, scale), dense_factor=8, batch_length=case["batch_length"],
+                                  batch_size=case["batch_size"], max_length=case["max_length"], f0_threshold=case["f0_threshold"],
+                                  upsampling_factor=case["U"], shuffle=case["shuffle"])
+    for k in range(case["n_batches"]):
+        bx, bh, bt, bd, bb = next(gen)
+        assert bx.dtype == torch.int64 and bh.dtype == torch.float32 and bd.dtype == torch.float32
+        row = [bx.shape[0], bx.shape[1], bh.shape[2], int(bb[0]), crc(bx.numpy()), crc(bh.numpy()), crc(bt.numpy()),
+               crc(bd.numpy()), int(bb.sum())]
+        assert row == gold[k].tolist(), "batch %d differs from the reference generator's" % k
+
+
+@pytest.mark.parametrize("case", GEN_DECODE_CASES, ids=[c["name"] for c in GEN_DECODE_CASES])
+def test_decode_generator_equals_reference_generator(case, golden_dir):
+    """batch composition, order, n_samples_list and the bytes of x / h / d equal the reference's decode_generator
+    (src/bin/qpnet_decode.py:122-209)."""
+    g = np.load(golden_dir + "/generators.npz")
+    gold = g["decode_" + case["name"]]
+    _, feats, mean, scale = generator_corpus(case["corpus_seed"], case["frames"], None, case["f0"], case["U"])
+    ids = ["%d" % i for i in range(len(feats))]
+    gen = loaders.decode_generator(feats, 22050, ids, wav_transform=loaders.mu_law_transform(256),
+                                   feat_transform=_sk_scaler(mean, scale), dense_factor=8, batch_size=case["batch_size"],
+                                   upsampling_factor=case["U"], f0_factor=float(str(case["f0_factor"])), f0_dim_index=1,
+                                   extra_memory=case["extra_memory"])
+    order, ns_all = [], []
+    for k, (feat_ids, bx, bh, ns, bd) in enumerate(gen):
+        bdn = bd.numpy() if case["extra_memory"] else bd
+        assert bdn.dtype == (np.float32 if case["extra_memory"] else np.float64)
+        row = [len(feat_ids), bx.shape[1], bh.shape[2], bdn.shape[1], crc(bx.numpy()), crc(bh.numpy()), crc(bdn)]
+        assert row == gold[k].tolist(), "decode batch %d differs from the reference generator's" % k
+        order += [int(s) for s in feat_ids]; ns_all += list(ns)
+    assert k + 1 == len(gold)
+    assert order == g["decode_" + case["name"] + "_order"].tolist()
+    assert ns_all == g["decode_" + case["name"] + "_ns"].tolist()
+    # the caller's feature arrays are not modified by the F0 scaling
+    _, feats2, _, _ = generator_corpus(case["corpus_seed"], case["frames"], None, case["f0"], case["U"])
+    assert all(np.array_equal(a, b) for a, b in zip(feats, feats2))

@@ -3,7 +3,7 @@ reference (tests/golden/make_golden.py).  This is what pins the oracle (SURVEY.m
 import numpy as np
 import pytest
 
-from cases import DECODE_CASES, DECODE_CASES2, FORWARD_CASES, TRAIN_CASES, decode2_inputs
+from cases import DECODE_CASES, DECODE_CASES2, DECODE_CASES_D, FORWARD_CASES, TRAIN_CASES, decode2_inputs
 from qpnet_amd import synth
 import util
 
@@ -51,6 +51,21 @@ def test_oracle_decode_equals_reference_streams(case, oracle, golden_dir):
     bx, bh, bd, ns = util.decode_batch(cfg, utts)
     nlist = list(ns)
     outs = oracle.batch_fast_generate(cfg, flat, bx, bh, nlist, bd.astype(np.float32) if extra else bd)
+    assert nlist == list(g[name + "_nleft"])
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64))
+
+
+@pytest.mark.parametrize("case", DECODE_CASES_D, ids=[c[0] for c in DECODE_CASES_D])
+def test_oracle_default_geometry_decode_equals_reference_streams(case, oracle, golden_dir):
+    """the repo-default geometry (C=512, 12 fixed + 4 adaptive layers: what runQP.py builds) pinned directly to the
+    reference's greedy streams: 2 199 samples at B=1 and a B=2 batch of unequal lengths at F0 x 1.5 (decode_d.npz)."""
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode_d.npz")
+    flat = synth.make_weights(cfg, wseed)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = oracle.batch_fast_generate(cfg, flat, bx, bh, nlist, bd)
     assert nlist == list(g[name + "_nleft"])
     for i, s in enumerate(outs):
         np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64))

@@ -1,0 +1,123 @@
+"""GPU parity of the data-parallel compute path -- the kernels every rank runs at N > 1:
+qpn_train_backward_ex (gradient weighted by the rank's row count n_r, n_r appended as the buffer's trailer) and
+qpn_adam_step_ex (divides by the summed row count it reads from the trailer ON THE DEVICE), through
+FusedTrainer(world_size > 1) exactly as run_train / bench.py --gpus N drive them (qpnet_amd/train.py).
+
+Replaces the reference's dead DataParallel wrapper (src/bin/qpnet_train.py:416-423); semantics = SURVEY.md §8e:
+the update is the gradient of the mean CE over ALL ranks' rows even when batch_length differs across ranks.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from qpnet_amd import synth
+from qpnet_amd.config import TINY, PAPER
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _to(dev, *arrs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in arrs]
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_world2_without_exchange_equals_world1(cfgname, cuda):
+    """No process group: the exchange is the identity, so the buffer holds n_r * g_r | n_r and Adam divides by n_r.
+    world_size=2 must then reproduce world_size=1 step for step (loss identical, weights to fp32 rounding of
+    (n*g)/n) -- a wrong trailer offset, a denominator read from the wrong word or a missing scale shows at once."""
+    from qpnet_amd.train import FusedTrainer
+    cfg = TINY if cfgname == "tiny" else PAPER
+    bl = 600 if cfgname == "tiny" else 1500
+    flat = synth.make_weights(cfg, 5)
+    m1 = util.build_model(cfg, flat, cuda).train()
+    m2 = util.build_model(cfg, flat, cuda).train()
+    t1 = FusedTrainer(m1, lr=1e-4, world_size=1)
+    t2 = FusedTrainer(m2, lr=1e-4, world_size=2)
+    for step in range(3):
+        x, h, t, d, b = synth.train_inputs(cfg, bl + 37 * step, 70 + step, 30000)
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        l1 = t1.step(xt, ht, tt, dt, bt)
+        l2 = t2.step(xt, ht, tt, dt, bt)
+        assert l1 == l2
+        BL = int(b[0])
+        n = m1.flat_parameters().numel()
+        g1 = t1.g[:n].cpu().numpy().astype(np.float64)
+        g2 = t2.g[:n].cpu().numpy().astype(np.float64)
+        trailer = t2.g[n:].cpu().numpy()
+        np.testing.assert_array_equal(trailer, np.array([x.shape[0] * BL, 0, 0, 0], np.float32))
+        # the weighted gradient is n_r * g_r up to one fp32 rounding per element
+        np.testing.assert_allclose(g2, g1 * (x.shape[0] * BL), rtol=3e-7, atol=0)
+    w1 = m1.flat_parameters().cpu().numpy()
+    w2 = m2.flat_parameters().cpu().numpy()
+    # Adam normalises the step by sqrt(v): one rounding of g changes an update by < 1e-6 * lr
+    np.testing.assert_allclose(w2, w1, atol=3e-9, rtol=0)
+    assert np.abs(w1 - flat).max() > 1e-5          # the three steps did move the weights
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank = int(sys.argv[1]); world = int(sys.argv[2]); out = sys.argv[3]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from qpnet_amd import synth, parallel
+from qpnet_amd.config import TINY
+from qpnet_amd.train import FusedTrainer, ensure_flat
+import util
+cfg = TINY
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+m = util.build_model(cfg, synth.make_weights(cfg, 3 + rank), dev).train()      # deliberately different: broadcast must fix it
+parallel.broadcast_parameters(ensure_flat(m, dev), 0)
+tr = FusedTrainer(m, lr=1e-4, world_size=world)
+bls = [300, 410, 350, 280]                                                       # unequal batch_length across ranks
+losses = []
+for ci in parallel.shard_indices(4, rank, world):
+    x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
+    xs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, h, t, d, b)]
+    losses.append(tr.step(*xs))
+np.savez(out, w=m.flat_parameters().cpu().numpy(), losses=np.array(losses))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cuda, tmp_path):
+    """Two fresh child processes share GPU 0 and exchange over gloo (RCCL refuses two ranks on one device); each runs the
+    product's FusedTrainer(world_size=2) on chunks of unequal batch_length.  Final weights must be bit-identical across
+    the ranks and equal the numpy oracle trained on the UNION batch of every step (row-weighted mean)."""
+    from oracle import train_oracle as TO
+    port = 29500 + os.getpid() % 2000
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / ("r%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r]], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=420) == 0
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    np.testing.assert_array_equal(r0["w"], r1["w"])                 # replicas stay bit-identical
+    cfg = TINY
+    flat = synth.make_weights(cfg, 3)
+    opt = TO.Adam(flat.size)
+    bls = [300, 410, 350, 280]
+    for step in range(2):
+        gs, ns, ls = [], [], []
+        for ci in (2 * step, 2 * step + 1):
+            x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
+            lg, caches = TO.forward(cfg, flat, x, h, d, b)
+            BL = int(b[0])
+            loss, dl = TO.ce_loss(lg, t[:, -BL:])
+            gs.append(TO.backward(cfg, flat, caches, dl)); ns.append(BL); ls.append(loss)
+        assert abs(r0["losses"][step] - ls[0]) < 1e-4 and abs(r1["losses"][step] - ls[1]) < 1e-4     # north_star tolerance
+        g = (gs[0] * ns[0] + gs[1] * ns[1]) / (ns[0] + ns[1])
+        opt.step(flat, g.astype(np.float32))
+    np.testing.assert_allclose(r0["w"], flat, atol=2e-6, rtol=0)    # same bound as the single-rank fixture test
