@@ -205,6 +205,7 @@ def run_decode(args, rank, local, world):
                      "cus_busy": min(cus, 256) / 256.0,
                      "kernel": kernel, "kernel_ms": k_ms, "note": note},
     }
+    out["plan"] = getattr(m, "last_decode_plan", "")
     if world == 1 and not args.no_cpu:
         # the reference decode script's default mode (softmax + draw, qpnet_decode.py:312-314): one untimed-in-`value` launch
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -484,6 +485,14 @@ def main():
                 d5 = run_decode(a5, rank, local, world)
                 out["decode"]["f0_scaled"]["x%.1f" % fac] = {"value": d5["value"], "unit": d5["unit"], "us_per_sample_per_utterance": d5["roofline"]["achieved"],
                                                               "kernel": d5["roofline"]["kernel"]}
+            # decode_batch_size is the caller's choice (--batch_size, src/bin/qpnet_decode.py:52): the chip full (48 x 5 CUs) and beyond
+            # one pipelined launch's capacity (rows beside it on one-CU kernels, or further launches; plan reported)
+            out["decode"]["larger_batches"] = {}
+            for Bx in (48, 49, 64):
+                a6 = copy.copy(a3); a6.batch = Bx; a6.steps, a6.warmup = 1, 0
+                d6 = run_decode(a6, rank, local, world)
+                out["decode"]["larger_batches"]["batch%d" % Bx] = {"value": d6["value"], "unit": d6["unit"], "ms_per_step": d6["ms_per_step"],
+                                                                  "plan": d6.get("plan")}
             os.environ["QPN_DECODE_PIPE"] = "0"          # the one-CU-per-utterance kernel on the same workload, for comparison
             try:
                 a4 = copy.copy(a2); a4.no_cpu = True; a4.steps, a4.warmup = 1, 0

@@ -62,7 +62,8 @@ void qpn_destroy(qpn_handle* h);
 
 /* load_state_dict / .cuda() (reference bin/qpnet_decode.py:286-293): bind the flat fp32
  * parameter vector (device memory, n == qpn_param_count) and (re)pack the decode tiles.
- * The vector is read again by every later call; call again after the values change. */
+ * The vector is read again by every later call; call again after the values change.
+ * Stream-ordered, no host synchronisation. */
 int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream);
 
 /* mode of qpn_decode */
@@ -70,8 +71,17 @@ int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream);
 #define QPN_MODE_SAMPLING 1
 
 /*
- * QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), all batch rows at once,
- * one persistent workgroup per utterance, ONE kernel launch for the whole call.
+ * QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), all batch rows at once: persistent kernels that loop
+ * over all samples of their utterances, launched once per call.  The launch plan is sized from the device's CU count
+ * (hipDeviceAttributeMultiprocessorCount), nothing assumes a whole 256-CU chip:
+ *   paper-size geometry   five resident workgroups per utterance (decode_pipe.hip) for up to (CUs / 40) * 8 rows per launch;
+ *                         more rows run as further equal-sized launches, or -- when they are short enough -- on one-CU
+ *                         kernels beside the first launch (rows are assigned longest first);
+ *   n_resch > 128         G workgroups per utterance (decode_coop.hip), G * rows <= CUs per launch;
+ *   other geometries      one workgroup (one CU) per utterance.
+ * Every wait between workgroups is bounded; when a multi-workgroup launch gives up (its workgroups were not co-resident:
+ * CU-masked or shared GPU) qpn_decode / qpn_decode_finish re-run the call once with a smaller footprint (one-CU kernels,
+ * or half the workgroups per utterance) before returning QPN_ENODEV.
  *   B          batch rows                         n_x   seed samples per row (x is B x n_x)
  *   F          frames of h (h is B x n_aux x F; if upsampling_factor==0, F = samples)
  *   Td         columns of the dilated factors (B x Td), float64 or float32 (d_is_f32)
@@ -88,8 +98,10 @@ int qpn_decode(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
                const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
                const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream);
 
-/* Same, split for stream/graph use: enqueue returns after launching; finish synchronises
- * the stream and returns the device-side status (QPN_ERANGE ...). */
+/* Same, split for stream use: enqueue only enqueues (no host synchronisation: the utterance descriptors are staged in
+ * pinned memory owned by the handle) and returns; finish synchronises the stream and returns the device-side status
+ * (QPN_ERANGE ...).  One decode in flight per handle: a second enqueue before finish returns QPN_ESTATE; the caller's
+ * buffers must stay valid until finish (it may re-run the call, see above). */
 int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
                        const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
                        const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
@@ -99,6 +111,10 @@ int qpn_decode_finish(qpn_handle* h, void* stream);
 /* Device time (ms) of the persistent decode kernel of the last finished qpn_decode call,
  * measured with HIP events on the launch stream (bench.py roofline). */
 float qpn_last_decode_kernel_ms(qpn_handle* h);
+
+/* The launch plan of the last decode call as text, e.g. "pipe rows=48 waves=1 x 48; one-cu rows=16 (beside)"
+ * (diagnostics / bench.py; owned by the handle, valid until the next decode call). */
+const char* qpn_last_decode_plan(qpn_handle* h);
 
 /*
  * QPNet.forward (reference src/nets/qpnet.py:239-312), teacher forced, fused fp32-MFMA kernels.

@@ -34,6 +34,7 @@ SYMBOLS = [
     ("qpn_decode_enqueue", _i, _DECODE_ARGS),
     ("qpn_decode_finish", _i, [_vp, _vp]),
     ("qpn_last_decode_kernel_ms", C.c_float, [_vp]),
+    ("qpn_last_decode_plan", C.c_char_p, [_vp]),
     ("qpn_train_forward", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     ("qpn_train_backward", _i, [_vp, _vp, _vp, _vp]),
     ("qpn_train_backward_ex", _i, [_vp, _vp, _vp, C.c_float, _i, _vp]),

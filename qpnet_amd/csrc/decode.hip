@@ -36,7 +36,8 @@ __global__ void k_pack_gather(const float* __restrict__ flat, const int* __restr
 // one workgroup of 64*k lanes per layer; aux tiles packed natural-row, R = Ap/16.
 __global__ void k_fold_bias(const float4* __restrict__ wpk, const float* __restrict__ flat, const BiasDesc* __restrict__ bd,
                             int aux_woff4_layer0, int aux_tiles_per_layer, int logRa, int A, int Ap, int C,
-                            float up_b, float* __restrict__ qb) {
+                            const float* __restrict__ up_b_ptr, float* __restrict__ qb) {
+    const float up_b = up_b_ptr ? *up_b_ptr : 0.0f;      // read on the device: qpn_set_weights needs no read-back
     extern __shared__ float4 smem4[];
     float* sm = (float*)smem4;
     const int l = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -248,7 +249,7 @@ __device__ __forceinline__ void run_slot(const Ctx& c, int slot, int64_t t, floa
         if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
         int next;
         if (i >= 0) {
-            if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, blockIdx.x, (unsigned)i, lane);
+            if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, (unsigned)u.row, (unsigned)i, lane);
             next = bi;
             if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
             if (lane == 0) u.out[i] = bi;
@@ -549,7 +550,7 @@ __device__ __forceinline__ void fast_steps(const DecodeParams& p, const FastPara
             if (i >= 0 && u.logits) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[p.o_lg + k];
             int next;
             if (i >= 0) {
-                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, blockIdx.x, (unsigned)i, lane);
+                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(p.o_lg, Q, p.seed, (unsigned)u.row, (unsigned)i, lane);
                 next = bi;
                 if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
                 if (lane == 0) u.out[i] = bi;
@@ -830,6 +831,12 @@ static int build_program(qpn_handle* h) {
     return QPN_OK;
 }
 
+bool qpn_pipe_supported(const Geom& g);
+int qpn_pipe_rows_resident(int n_cus);
+int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream);
+int qpn_coop_group_size(const Geom& g, int limit);
+int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
+
 extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     if (!out) { qpn_set_error("null out"); return QPN_EINVAL; }
     *out = nullptr;
@@ -841,6 +848,7 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     h->d_pproj = nullptr; h->pproj_cap = 0; h->d_ring = nullptr; h->ring_cap = 0; h->d_known = nullptr; h->known_cap = 0;
     h->d_xch = nullptr; h->xch_cap = 0; h->single_cu_ok = true;
     h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
+    h->n_cus = 0; h->pipe_rows = 0; h->h_utts_pinned = nullptr; h->h_utts_cap = 0; h->dec_side = nullptr; h->dec_fork = h->dec_join = nullptr;
     rc = build_program(h);
     h->decode_ok = rc == QPN_OK;
     if (rc != QPN_OK) h->decode_err = g_err;            // reported by the decode entry points; the training path has its own limits
@@ -850,6 +858,9 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
         h->device = -1; *out = h; return QPN_OK;
     }
     QPN_HIP(hipGetDevice(&h->device));
+    QPN_HIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    if (h->n_cus < 1) h->n_cus = 1;
+    h->pipe_rows = qpn_pipe_rows_resident(h->n_cus);
     *out = h;
     return QPN_OK;
 }
@@ -862,6 +873,10 @@ extern "C" void qpn_destroy(qpn_handle* h) {
         qpn_train_destroy(h->train);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->h_utts_pinned) (void)hipHostFree(h->h_utts_pinned);
+        if (h->dec_side) (void)hipStreamDestroy(h->dec_side);
+        if (h->dec_fork) (void)hipEventDestroy(h->dec_fork);
+        if (h->dec_join) (void)hipEventDestroy(h->dec_join);
     }
     delete h;
 }
@@ -901,14 +916,10 @@ extern "C" int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, voi
     }
     h->d_flat = d_flat;
     hipLaunchKernelGGL(k_pack_gather, dim3((unsigned)((nmap + 255) / 256)), dim3(256), 0, stream, d_flat, h->d_map, h->d_wpk, (int64_t)nmap);
-    float up_b = 0.0f;
-    if (g.U > 0) QPN_HIP(hipMemcpyAsync(&up_b, d_flat + g.up_b, sizeof(float), hipMemcpyDeviceToHost, stream));
-    QPN_HIP(hipStreamSynchronize(stream));
     hipLaunchKernelGGL(k_fold_bias, dim3(g.L), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_flat, h->d_bd,
-                       h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, up_b, h->d_qb);
+                       h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.U > 0 ? d_flat + g.up_b : (const float*)nullptr, h->d_qb);
     QPN_HIP(hipGetLastError());
-    QPN_HIP(hipStreamSynchronize(stream));
-    h->have_weights = true;
+    h->have_weights = true;                              // (stream-ordered: later decode calls on this stream see the packed tiles)
     return QPN_OK;
 }
 
@@ -923,22 +934,47 @@ static int grow(T** p, size_t* cap, size_t need) {
     return QPN_OK;
 }
 
-bool qpn_pipe_supported(const Geom& g);
-int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream);
-int qpn_coop_group_size(const Geom& g, int limit);
-int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
-
-extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
-                                  const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
-                                  const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
-                                  const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream_) {
-    int rc = need_device(h); if (rc) return rc;
-    if (!h->have_weights) { qpn_set_error("qpn_set_weights must be called before qpn_decode"); return QPN_ESTATE; }
-    if (B < 1 || n_x < 1 || F < 1 || !d_x || !d_h || !d_dfac || !h_n_samples || !d_out || maxd < 1) { qpn_set_error("bad decode arguments"); return QPN_EINVAL; }
-    if (mode != QPN_MODE_ARGMAX && mode != QPN_MODE_SAMPLING) { qpn_set_error("mode must be QPN_MODE_ARGMAX or QPN_MODE_SAMPLING"); return QPN_EINVAL; }
-    if (mode == QPN_MODE_SAMPLING && (h->g.Q % 64 || h->g.Q > 256)) { qpn_set_error("sampling needs n_quantize in {64,128,192,256}"); return QPN_EINVAL; }
+// One launch of the one-CU kernels (one 1024-thread workgroup per utterance) over the descriptors p.utts[0 .. n)
+static int launch_one_cu(qpn_handle* h, DecodeParams& p, int n, hipStream_t stream) {
     const Geom& g = h->g;
-    hipStream_t stream = (hipStream_t)stream_;
+    const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
+    const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;
+    // the specialised kernel does not use the task table: the residual-1x1 tiles of layers 0..L-2 take its place (and more) when they fit
+    const int stamp_floats = p.stamps ? 120 * QPN_NW : 0;
+    const int nres_tiles = (g.C * g.C / 1024) * (g.L - 1);
+    p.o_wres = (p.o_tasks + 3) & ~3;
+    const bool resl = (fast64 || fast32) && g.L >= 2 && !getenv("QPN_DECODE_NO_RESL") &&
+                      ((size_t)p.o_wres + (size_t)nres_tiles * 1024 + stamp_floats) * sizeof(float) <= 160 * 1024;
+    const int use_floats = resl ? p.o_wres + nres_tiles * 1024 : p.lds_floats;
+    p.o_stamp = use_floats;
+    const size_t lds_bytes = ((size_t)use_floats + stamp_floats) * sizeof(float);
+    const void* kfn = fast64 ? (resl ? (const void*)k_decode_fast<64, 256, 256, 16, true> : (const void*)k_decode_fast<64, 256, 256, 16, false>)
+                    : fast32 ? (resl ? (const void*)k_decode_fast<32, 32, 256, 16, true> : (const void*)k_decode_fast<32, 32, 256, 16, false>)
+                    : (const void*)k_decode;
+    if (lds_bytes > 48 * 1024) QPN_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (fast64) {
+        if (resl) hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, true>), dim3(n), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, false>), dim3(n), dim3(1024), lds_bytes, stream, p, h->fp);
+    } else if (fast32) {
+        if (resl) hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, true>), dim3(n), dim3(1024), lds_bytes, stream, p, h->fp);
+        else hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, false>), dim3(n), dim3(1024), lds_bytes, stream, p, h->fp);
+    } else
+        hipLaunchKernelGGL(k_decode, dim3(n), dim3(QPN_NT), lds_bytes, stream, p);
+    QPN_HIP(hipGetLastError());
+    return QPN_OK;
+}
+
+// measured per-sample times of the two paper-size kernels (profiles/r02_bench_line.json): only their RATIO is used, to decide
+// whether the rows beyond one pipelined launch's capacity run beside it on one-CU kernels or as further pipelined launches
+static const double T_PIPE_US = 8.3, T_ONE_US = 14.3;
+
+// force_one_cu: the retry of qpn_decode_finish (a multi-workgroup launch gave up) -- one-CU kernels only
+static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+                               const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+                               const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+                               const int64_t* d_teacher, int64_t* d_out, float* d_logits, hipStream_t stream, bool force_one_cu, int coop_limit) {
+    const Geom& g = h->g;
+    int rc;
     int64_t max_n = 0;
     for (int b = 0; b < B; ++b) {
         int64_t n = h_n_samples[b];
@@ -966,30 +1002,65 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     // several workgroups per utterance when one CU cannot hold the step state (or QPN_DECODE_COOP=<G> asks for it)
     int coopG = 0;
     if (const char* e = getenv("QPN_DECODE_COOP")) coopG = atoi(e) > 0 ? atoi(e) : 0;
-    if (!h->single_cu_ok && coopG == 0) coopG = 256;
+    if (!h->single_cu_ok && coopG == 0) coopG = h->n_cus;
+    if (force_one_cu && h->single_cu_ok) coopG = 0;
     if (coopG > 0) {
-        int cap = coopG; if (B < 256 && 256 / B < cap) cap = 256 / B;       // the whole batch in one launch when it fits the chip
+        int cap = coopG; if (B < h->n_cus && h->n_cus / B < cap) cap = h->n_cus / B;       // the whole batch in one launch when it fits the chip
+        if (coop_limit > 0 && cap > coop_limit) cap = coop_limit;                          // retry with fewer workgroups per utterance
         coopG = qpn_coop_group_size(g, cap < 1 ? 1 : cap);
     }
-    if (!coopG) { rc = grow(&h->d_ring, &h->ring_cap, ring_floats * B); if (rc) return rc; }
+    // ---- launch plan.  Rows are handed to the kernels longest first (descriptors are a permutation of the batch):
+    //   PIPE  rows [0, n_pipe) in waves of <= pipe_rows (five resident workgroups per utterance, decode_pipe.hip)
+    //   ONE   rows [n_pipe, B) on one-CU kernels, on a side stream BESIDE the first pipelined wave when there is one
+    std::vector<int> order(B);
+    for (int b = 0; b < B; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return h_n_samples[a] > h_n_samples[b2]; });
+    const char* epipe = getenv("QPN_DECODE_PIPE");
+    const bool pipe_ok = !coopG && !force_one_cu && (epipe ? atoi(epipe) != 0 : true) && qpn_pipe_supported(g) && !getenv("QPN_DECODE_GENERIC") && h->pipe_rows >= 1;
+    int n_pipe = 0, n_waves = 0, wave_rows = 0;
+    if (pipe_ok) {
+        const int cap = h->pipe_rows;
+        if (B <= cap) { n_pipe = B; n_waves = 1; wave_rows = B; }
+        else {
+            // (a) every row pipelined, in ceil(B / cap) waves of equal size: time = sum over waves of the wave's longest row
+            const int nw = (B + cap - 1) / cap, per = (B + nw - 1) / nw;
+            double t_waves = 0.0;
+            for (int w = 0; w < nw; ++w) t_waves += T_PIPE_US * (double)h_n_samples[order[std::min(w * per, B - 1)]];
+            // (b) the longest `cap` rows pipelined, the (shorter) rest on the CUs that launch leaves free, at the same time
+            const int free_cus = h->n_cus - 5 * cap, rest = B - cap;
+            double t_hybrid = 1e300;
+            if (rest <= free_cus) t_hybrid = std::max(T_PIPE_US * (double)h_n_samples[order[0]], T_ONE_US * (double)h_n_samples[order[cap]]);
+            if (t_hybrid <= t_waves) { n_pipe = cap; n_waves = 1; wave_rows = cap; }
+            else { n_pipe = B; n_waves = nw; wave_rows = per; }
+        }
+    }
+    const int n_one = coopG ? 0 : B - n_pipe;
+    if (!coopG) { rc = grow(&h->d_ring, &h->ring_cap, ring_floats * (size_t)B); if (rc) return rc; }      // pitch-tap histories (one-CU kernels; role S1 of the pipelined one)
     rc = grow(&h->d_pproj, &h->pproj_cap, (size_t)B * F * g.L * 2 * g.C); if (rc) return rc;
     rc = grow(&h->d_known, &h->known_cap, (size_t)B * n0); if (rc) return rc;
     rc = grow(&h->d_utts, &h->utts_cap, (size_t)B); if (rc) return rc;
-    std::vector<UttDesc> utts(B);
-    for (int b = 0; b < B; ++b) {
-        UttDesc& u = utts[b];
+    if ((size_t)B > h->h_utts_cap) {
+        if (h->h_utts_pinned) (void)hipHostFree(h->h_utts_pinned);
+        h->h_utts_pinned = nullptr; h->h_utts_cap = 0;
+        QPN_HIP(hipHostMalloc((void**)&h->h_utts_pinned, (size_t)B * sizeof(UttDesc), hipHostMallocDefault));
+        h->h_utts_cap = (size_t)B;
+    }
+    UttDesc* utts = h->h_utts_pinned;      // pinned and owned by the handle (one decode in flight per handle): no host synchronisation here
+    for (int k = 0; k < B; ++k) {
+        const int b = order[k];
+        UttDesc& u = utts[k];
         u.pproj = (int64_t)b * F * g.L * 2 * g.C;
         u.dfac = (int64_t)b * Td;
         u.known = (int64_t)b * n0;
         u.teacher = d_teacher ? (int64_t)b * max_n : -1;
         u.out = (int64_t)b * max_n;
         u.logits = d_logits ? (int64_t)b * max_n * g.Q : -1;
-        u.ring = (int64_t)b * ring_floats;
+        u.ring = (int64_t)k * ring_floats;
         u.n_pad = (int)n_pad; u.n0 = (int)n0; u.n_samples = (int)h_n_samples[b]; u.d_is_f32 = d_is_f32; u.F = F;
+        u.row = b; u.pad_ = 0;
     }
-    QPN_HIP(hipMemcpyAsync(h->d_utts, utts.data(), B * sizeof(UttDesc), hipMemcpyHostToDevice, stream));
-    QPN_HIP(hipStreamSynchronize(stream));   // utts is a host temporary
-    if (!coopG) QPN_HIP(hipMemsetAsync(h->d_ring, 0, ring_floats * B * sizeof(float), stream));
+    QPN_HIP(hipMemcpyAsync(h->d_utts, utts, (size_t)B * sizeof(UttDesc), hipMemcpyHostToDevice, stream));
+    if (!coopG) QPN_HIP(hipMemsetAsync(h->d_ring, 0, ring_floats * (size_t)B * sizeof(float), stream));
     QPN_HIP(hipMemsetAsync(h->d_status, 0, 64, stream));
     hipLaunchKernelGGL(k_known, dim3((unsigned)((n0 + 255) / 256), B), dim3(256), 0, stream, d_x, n_x, (int)n_pad, g.Q, h->d_known);
     hipLaunchKernelGGL(k_aux_project, dim3((unsigned)F, B), dim3(256), g.Ap * sizeof(float), stream, (const float4*)h->d_wpk, d_h, F,
@@ -999,51 +1070,64 @@ extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int6
     p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
+    char plan[160];
     if (coopG) {
         rc = qpn_launch_decode_coop(h, p, B, coopG, stream); if (rc) return rc;
-        QPN_HIP(hipEventRecord(h->ev1, stream));
-        h->pending = true;
-        return QPN_OK;
-    }
-    // paper-size geometry: four pipelined workgroups per utterance with resident weights (decode_pipe.hip) unless QPN_DECODE_PIPE=0
-    {
-        const char* e = getenv("QPN_DECODE_PIPE");
-        const bool want = e ? atoi(e) != 0 : true;
-        if (want && qpn_pipe_supported(g) && B <= 48 && !getenv("QPN_DECODE_GENERIC")) {     // 5 resident workgroups per utterance
-            rc = qpn_launch_decode_pipe(h, p, B, stream); if (rc) return rc;
-            QPN_HIP(hipEventRecord(h->ev1, stream));
-            h->pending = true;
-            return QPN_OK;
+        snprintf(plan, sizeof(plan), "coop G=%d rows=%d", coopG, B);
+        h->call.multi_wg = coopG > 1 ? 2 : 0; h->call.coopG = coopG;
+    } else {
+        const bool beside = n_pipe > 0 && n_one > 0;       // hybrid: the one-CU rows run on the side stream while the pipelined wave runs
+        if (beside) {
+            if (!h->dec_side) {
+                QPN_HIP(hipStreamCreateWithFlags(&h->dec_side, hipStreamNonBlocking));
+                QPN_HIP(hipEventCreateWithFlags(&h->dec_fork, hipEventDisableTiming));
+                QPN_HIP(hipEventCreateWithFlags(&h->dec_join, hipEventDisableTiming));
+            }
+            QPN_HIP(hipEventRecord(h->dec_fork, stream));
+            QPN_HIP(hipStreamWaitEvent(h->dec_side, h->dec_fork, 0));
         }
+        for (int w = 0; w < n_waves; ++w) {
+            const int first = w * wave_rows, n = std::min(wave_rows, n_pipe - first);
+            if (n <= 0) break;
+            DecodeParams pw = p; pw.utts = h->d_utts + first;
+            rc = qpn_launch_decode_pipe(h, pw, n, stream); if (rc) return rc;
+        }
+        if (n_one > 0) {
+            DecodeParams po = p; po.utts = h->d_utts + n_pipe;
+            rc = launch_one_cu(h, po, n_one, beside ? h->dec_side : stream); if (rc) return rc;
+        }
+        if (beside) {
+            QPN_HIP(hipEventRecord(h->dec_join, h->dec_side));
+            QPN_HIP(hipStreamWaitEvent(stream, h->dec_join, 0));
+        }
+        snprintf(plan, sizeof(plan), "pipe rows=%d waves=%d x %d; one-cu rows=%d%s", n_pipe, n_waves, wave_rows, n_one, beside ? " (beside)" : "");
+        h->call.multi_wg = n_pipe > 0 ? 1 : 0; h->call.coopG = 0;
     }
-    const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
-    const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;
-    // the specialised kernel does not use the task table: the residual-1x1 tiles of layers 0..L-2 take its place (and more) when they fit
-    const int stamp_floats = p.stamps ? 120 * QPN_NW : 0;
-    const int nres_tiles = (g.C * g.C / 1024) * (g.L - 1);
-    p.o_wres = (p.o_tasks + 3) & ~3;
-    const bool resl = (fast64 || fast32) && g.L >= 2 && !getenv("QPN_DECODE_NO_RESL") &&
-                      ((size_t)p.o_wres + (size_t)nres_tiles * 1024 + stamp_floats) * sizeof(float) <= 160 * 1024;
-    const int use_floats = resl ? p.o_wres + nres_tiles * 1024 : p.lds_floats;
-    p.o_stamp = use_floats;
-    const size_t lds_bytes = ((size_t)use_floats + stamp_floats) * sizeof(float);
-    const void* kfn = fast64 ? (resl ? (const void*)k_decode_fast<64, 256, 256, 16, true> : (const void*)k_decode_fast<64, 256, 256, 16, false>)
-                    : fast32 ? (resl ? (const void*)k_decode_fast<32, 32, 256, 16, true> : (const void*)k_decode_fast<32, 32, 256, 16, false>)
-                    : (const void*)k_decode;
-    if (lds_bytes > 48 * 1024) QPN_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (fast64) {
-        if (resl) hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, true>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-        else hipLaunchKernelGGL((k_decode_fast<64, 256, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-    } else if (fast32) {
-        if (resl) hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, true>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-        else hipLaunchKernelGGL((k_decode_fast<32, 32, 256, 16, false>), dim3(B), dim3(1024), lds_bytes, stream, p, h->fp);
-    } else
-        hipLaunchKernelGGL(k_decode, dim3(B), dim3(QPN_NT), lds_bytes, stream, p);
-    QPN_HIP(hipGetLastError());
+    h->plan = plan;
     QPN_HIP(hipEventRecord(h->ev1, stream));
     h->pending = true;
     return QPN_OK;
 }
+
+extern "C" int qpn_decode_enqueue(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
+                                  const int64_t* d_x, const float* d_h, const void* d_dfac, int d_is_f32,
+                                  const int64_t* h_n_samples, int maxd, int mode, uint64_t seed,
+                                  const int64_t* d_teacher, int64_t* d_out, float* d_logits, void* stream_) {
+    int rc = need_device(h); if (rc) return rc;
+    if (!h->have_weights) { qpn_set_error("qpn_set_weights must be called before qpn_decode"); return QPN_ESTATE; }
+    if (h->pending) { qpn_set_error("one decode in flight per handle: call qpn_decode_finish first"); return QPN_ESTATE; }
+    if (B < 1 || n_x < 1 || F < 1 || !d_x || !d_h || !d_dfac || !h_n_samples || !d_out || maxd < 1) { qpn_set_error("bad decode arguments"); return QPN_EINVAL; }
+    if (mode != QPN_MODE_ARGMAX && mode != QPN_MODE_SAMPLING) { qpn_set_error("mode must be QPN_MODE_ARGMAX or QPN_MODE_SAMPLING"); return QPN_EINVAL; }
+    if (mode == QPN_MODE_SAMPLING && (h->g.Q % 64 || h->g.Q > 256)) { qpn_set_error("sampling needs n_quantize in {64,128,192,256}"); return QPN_EINVAL; }
+    qpn_handle::DecodeCall& c = h->call;
+    c.B = B; c.n_x = n_x; c.F = F; c.Td = Td; c.d_x = d_x; c.d_h = d_h; c.d_dfac = d_dfac; c.d_is_f32 = d_is_f32;
+    c.n_samples.assign(h_n_samples, h_n_samples + B); c.maxd = maxd; c.mode = mode; c.seed = seed;
+    c.d_teacher = d_teacher; c.d_out = d_out; c.d_logits = d_logits; c.multi_wg = 0; c.coopG = 0;
+    return decode_enqueue_impl(h, B, n_x, F, Td, d_x, d_h, d_dfac, d_is_f32, c.n_samples.data(), maxd, mode, seed, d_teacher, d_out, d_logits,
+                               (hipStream_t)stream_, false, 0);
+}
+
+extern "C" const char* qpn_last_decode_plan(qpn_handle* h) { return h ? h->plan.c_str() : ""; }
 
 extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
     int rc = need_device(h); if (rc) return rc;
@@ -1054,6 +1138,25 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
     int status = 0;
     QPN_HIP(hipMemcpy(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
     QPN_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    if ((status & 4) && h->call.multi_wg) {
+        // A multi-workgroup launch gave up: its workgroups were not all resident together (CU-masked or shared GPU, another
+        // kernel holding CUs).  Every wait in those kernels is bounded, the grid has drained; run the batch again with a
+        // smaller footprint -- the one-CU kernels for the paper-size geometry, half the workgroups per utterance otherwise.
+        const qpn_handle::DecodeCall c = h->call;
+        const bool to_one_cu = h->single_cu_ok;
+        if (to_one_cu || c.coopG >= 2) {
+            const std::string first_plan = h->plan;
+            h->call.multi_wg = 0;
+            rc = decode_enqueue_impl(h, c.B, c.n_x, c.F, c.Td, c.d_x, c.d_h, c.d_dfac, c.d_is_f32, c.n_samples.data(), c.maxd, c.mode, c.seed,
+                                     c.d_teacher, c.d_out, c.d_logits, stream, to_one_cu, to_one_cu ? 0 : c.coopG / 2);
+            if (rc) return rc;
+            QPN_HIP(hipStreamSynchronize(stream));
+            h->pending = false;
+            h->plan = first_plan + " -> timed out, retried: " + h->plan;
+            QPN_HIP(hipMemcpy(&status, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+            float ms2 = 0.f; QPN_HIP(hipEventElapsedTime(&ms2, h->ev0, h->ev1)); h->last_ms += ms2;
+        }
+    }
     if (getenv("QPN_STAMPS")) {      // dev aid: stamp times (cycles, relative to the first stamp of wave 0) of step 3000
         std::vector<long long> st((size_t)120 * QPN_NW);
         QPN_HIP(hipMemcpy(st.data(), h->d_status + 16, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
@@ -1063,7 +1166,7 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
             fprintf(stderr, "\n");
         }
     }
-    if (status & 4) { qpn_set_error("cooperative decode: a workgroup timed out waiting for its peers (is another job holding CUs of this GPU?)"); return QPN_ENODEV; }
+    if (status & 4) { qpn_set_error("decode: a workgroup timed out waiting for its peers (is another job holding CUs of this GPU?)"); return QPN_ENODEV; }
     if (status & 1) { qpn_set_error("pitch-dependent tap left its ring buffer (dilated factor <= 0.5 or > maxd)"); return QPN_ERANGE; }
     return QPN_OK;
 }

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             if (i >= 0 && u.logits && gidx == 0) for (int k = lane; k < Q; k += 64) u.logits[(size_t)i * Q + k] = sm[o_lg + k];
             int next;
             if (i >= 0) {
-                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg, Q, p.seed, (unsigned)b, (unsigned)i, lane);
+                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg, Q, p.seed, (unsigned)u.row, (unsigned)i, lane);
                 next = bi;
                 if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
                 if (lane == 0 && gidx == 0) u.out[i] = bi;
@@ -292,7 +292,7 @@ int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStre
     o = (o + 15) & ~15L;
     if (o >= (1L << 31)) { qpn_set_error("cooperative decode: exchange block too large"); return QPN_EINVAL; }
     c.utt_stride = o; c.f_p1b = (int)g.post1_b; c.f_p2b = (int)g.post2_b;
-    const int per_launch = 256 / G > 0 ? 256 / G : 1;        // all workgroups of a launch must be resident together (256 CUs)
+    const int per_launch = h->n_cus / G > 0 ? h->n_cus / G : 1;        // all workgroups of a launch must be resident together (one per CU)
     const int nb = B < per_launch ? B : per_launch;
     const size_t xwords = (size_t)o * nb + 16;
     if (xwords > h->xch_cap) {

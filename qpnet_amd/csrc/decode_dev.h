@@ -215,7 +215,7 @@ __device__ __forceinline__ int sample_wave(int o_lg, int Q, unsigned long long s
 
 struct UttView {            // per-utterance pointers derived from kernel-argument bases (global address space)
     const float* pproj; const void* dfac; const int* known; const int64_t* teacher; int64_t* out; float* logits; float* ring;
-    int n_pad, n0, n_samples, d_is_f32;
+    int n_pad, n0, n_samples, d_is_f32, row;
 };
 __device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDesc& d) {
     UttView u;
@@ -226,7 +226,7 @@ __device__ __forceinline__ UttView make_view(const DecodeParams& p, const UttDes
     u.out = p.out + d.out;
     u.logits = d.logits >= 0 ? p.logits + d.logits : nullptr;
     u.ring = p.ring + d.ring;
-    u.n_pad = d.n_pad; u.n0 = d.n0; u.n_samples = d.n_samples; u.d_is_f32 = d.d_is_f32;
+    u.n_pad = d.n_pad; u.n0 = d.n0; u.n_samples = d.n_samples; u.d_is_f32 = d.d_is_f32; u.row = d.row;
     return u;
 }
 

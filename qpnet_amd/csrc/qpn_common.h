@@ -77,6 +77,7 @@ struct UttDesc {            // offsets into the base pointers of DecodeParams (k
     int64_t ring;           // floats: ring block of this utterance (zeroed before launch)
     int n_pad, n0, n_samples, d_is_f32;
     int64_t F;
+    int row, pad_;          // row of the caller's batch (the descriptors of a launch are a permuted slice of the batch): Philox key
 };
 
 // per-layer tile / bias locations for the specialised straight-line decode kernel (k_decode_fast)

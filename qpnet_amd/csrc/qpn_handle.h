@@ -26,6 +26,21 @@ struct qpn_handle {
     UttDesc* d_utts; size_t utts_cap;
     hipEvent_t ev0, ev1; float last_ms;
     bool pending;
+    // device facts queried at qpn_create (nothing assumes a 256-CU chip that is all ours)
+    int n_cus;                       // hipDeviceAttributeMultiprocessorCount
+    int pipe_rows;                   // utterances one pipelined launch can hold resident (5 workgroups each), a multiple of 8
+    // pinned staging of the utterance descriptors (enqueue does not synchronise) + the side stream of a hybrid launch
+    UttDesc* h_utts_pinned; size_t h_utts_cap;
+    hipStream_t dec_side; hipEvent_t dec_fork, dec_join;
+    struct DecodeCall {              // arguments of the decode in flight: qpn_decode_finish re-runs it on the one-CU kernel when a
+        int B, n_x; int64_t F, Td;   // multi-workgroup launch gave up (peers not co-resident: masked / shared GPU)
+        const int64_t* d_x; const float* d_h; const void* d_dfac; int d_is_f32;
+        std::vector<int64_t> n_samples; int maxd, mode; uint64_t seed;
+        const int64_t* d_teacher; int64_t* d_out; float* d_logits;
+        int multi_wg;                // 0: one-CU kernels only, 1: pipelined launch(es) involved, 2: cooperative (G > 1)
+        int coopG;
+    } call;
+    std::string plan;                // human-readable launch plan of the last decode (qpn_last_decode_plan)
     bool single_cu_ok;               // the step state fits one CU's LDS (decode.hip kernels); otherwise decode_coop.hip only
     int w_past_il[QPN_MAX_LAYERS];   // channel-interleaved past-tap tiles (cooperative kernel)
     unsigned long long* d_xch; size_t xch_cap;   // exchange granules of the cooperative kernel

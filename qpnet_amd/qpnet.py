@@ -121,6 +121,7 @@ class QPNet(nn.Module):
         self._handle = None
         self._handle_dev = None
         self.last_decode_kernel_ms = 0.0
+        self.last_decode_plan = ""
         self.sampling_seed = None          # set to an int to pin the sampling-mode random stream
         self._n_generate_calls = 0
         self.last_sampling_seed = None
@@ -154,6 +155,17 @@ class QPNet(nn.Module):
     def flat_parameters(self):
         """fp32 parameter vector in state_dict order (the layout qpn_set_weights expects)."""
         return torch.cat([p.detach().reshape(-1) for p in self.parameters()]).float().contiguous()
+
+    def _bind_decode_weights(self, L, hd, dev, stream):
+        """qpn_set_weights on the model's flat parameter buffer.  The parameters are views of ONE flat buffer
+        (train.ensure_flat: built once, re-built only if .to()/.cuda() replaced the storages), so a decode call costs no
+        2-96 MB concatenation; the library's tile re-pack is stream-ordered with no host synchronisation (one gather pass
+        over the weights, ~0.1 ms for the 96 MB geometry) and is done on every call -- cheaper than any scheme that has to
+        notice writes made through `p.data`, which torch's version counters do not see."""
+        from .train import ensure_flat
+        flat = ensure_flat(self, dev)
+        _lib.check(L.qpn_set_weights(hd, flat.data_ptr(), flat.numel(), stream))
+        return flat
 
     # ------------------------------------------------------------------ training forward
     def forward(self, x, h, dilated_factors, blength):
@@ -196,7 +208,6 @@ class QPNet(nn.Module):
         ns = [int(n) for n in n_samples_list]
         max_n = max(ns)
         out = torch.empty((B, max(max_n, 1)), dtype=torch.int64, device=dev)
-        flat = self.flat_parameters()
         stream = torch.cuda.current_stream(dev).cuda_stream
         # sampling: a counter-based generator keyed by torch's seed (torch.manual_seed(args.seed) in the reference
         # decode script, qpnet_decode.py:236-239) plus a per-call counter; draws are reproducible, but they are not
@@ -206,12 +217,13 @@ class QPNet(nn.Module):
         self.last_sampling_seed = seed
         t_start = time.time()
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_set_weights(hd, flat.data_ptr(), flat.numel(), stream))
+            self._bind_decode_weights(L, hd, dev, stream)
             arr = (C.c_int64 * B)(*ns)
             _lib.check(L.qpn_decode(hd, B, xd.shape[1], hd_.shape[2], d_dev.shape[1],
                                     xd.data_ptr(), hd_.data_ptr(), d_dev.data_ptr(), d_is_f32,
                                     arr, maxd, 1 if mode == "sampling" else 0, seed, None, out.data_ptr(), None, stream))
             self.last_decode_kernel_ms = float(L.qpn_last_decode_kernel_ms(hd))
+            self.last_decode_plan = L.qpn_last_decode_plan(hd).decode("utf-8", "replace")
         out_np = out.cpu().numpy()
         if intervals is not None and intervals > 0 and max_n > 0:
             # progress lines of the reference loop (qpnet.py:519-524).  The whole call is one persistent launch, so they are
@@ -240,11 +252,10 @@ class QPNet(nn.Module):
         out = torch.empty((B, n_samples), dtype=torch.int64, device=dev)
         logits = torch.empty((B, n_samples, self.n_quantize), dtype=torch.float32, device=dev)
         tch = teacher.to(dev, torch.int64).contiguous()
-        flat = self.flat_parameters()
         xd = x.to(dev, torch.int64).contiguous(); hh = h.to(dev, torch.float32).contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_set_weights(hd, flat.data_ptr(), flat.numel(), stream))
+            self._bind_decode_weights(L, hd, dev, stream)
             arr = (C.c_int64 * B)(*([n_samples] * B))
             _lib.check(L.qpn_decode(hd, B, xd.shape[1], hh.shape[2], d_dev.shape[1], xd.data_ptr(), hh.data_ptr(),
                                     d_dev.data_ptr(), 0, arr, maxd, 0, 0, tch.data_ptr(), out.data_ptr(),

@@ -420,3 +420,110 @@ def test_pipelined_decode_at_full_occupancy(cuda, oracle):
     outs2 = m.batch_fast_generate(xb, hb, list(ns), bd, mode="argmax")
     for a, b2 in zip(outs, outs2):
         np.testing.assert_array_equal(a, b2)
+
+
+# ---------------------------------------------------------------- launch plans beyond one pipelined launch (round 3)
+def _paper_batch(B, lo=6, span=9, seed0=300):
+    from qpnet_amd.config import PAPER
+    specs = [(seed0 + b, lo + (b * 5) % span, [1.0, 0.5, 1.5][b % 3]) for b in range(B)]
+    return PAPER, specs
+
+
+@pytest.mark.parametrize("B,mode", [(49, "argmax"), (64, "sampling"), (100, "argmax")])
+def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
+    """decode_batch_size is a free parameter of the reference (--batch_size, src/bin/qpnet_decode.py:52).  More rows than one
+    pipelined launch holds resident (48 on a 256-CU device) run as several launches / beside it on one-CU kernels; whatever
+    the plan, EVERY row equals its single-row oracle stream (sampling: the Philox key is the caller's row number)."""
+    import torch
+    cfg, specs = _paper_batch(B)
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    m.sampling_seed = 4242
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode=mode)
+    import re
+    mt = re.match(r"pipe rows=(\d+) waves=(\d+) x (\d+); one-cu rows=(\d+)", m.last_decode_plan)
+    assert mt, m.last_decode_plan
+    n_pipe, n_waves, per, n_one = map(int, mt.groups())
+    assert n_pipe + n_one == B and n_pipe >= 48 and per <= 48 and n_waves * per >= n_pipe, m.last_decode_plan
+    if B == 49:
+        assert n_one == 1 and "(beside)" in m.last_decode_plan      # the shortest row rides on a free CU beside the 48-row launch
+    if B == 100:
+        assert n_one == 0 and n_waves == 3                          # 52 extra rows do not fit the CUs a 48-row launch leaves free
+    order = np.argsort(ns, kind="stable")
+    assert [len(o) for o in outs] == [ns[b] for b in order]
+    maxd = int(np.ceil(np.nanmax(bd)))
+    for k in range(B):
+        b = int(order[k])
+        x, h, d, n = synth.decode_inputs(cfg, specs[b][1], specs[b][0], specs[b][2])
+        r = oracle.decode(cfg, flat, h, d, x, n, maxd=maxd, mode=mode, seed=4242, row=b)
+        np.testing.assert_array_equal(outs[k], r["samples"], err_msg="row %d (%s)" % (b, m.last_decode_plan))
+
+
+def test_equal_length_rows_beyond_capacity_run_as_equal_waves(cuda, oracle):
+    """80 rows of one length: 32 more than one launch holds and more than the 16 CUs it leaves free, so the plan is two
+    pipelined launches of 40 (equal waves: each wave's time is set by its longest row)."""
+    import torch
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    specs = [(500 + b % 4, 8, 1.0) for b in range(80)]
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    assert "pipe rows=80 waves=2 x 40; one-cu rows=0" in m.last_decode_plan, m.last_decode_plan
+    ref = {}
+    for k in range(80):
+        key = specs[k][0]
+        if key not in ref:
+            x, h, d, n = synth.decode_inputs(cfg, 8, key, 1.0)
+            ref[key] = oracle.decode(cfg, flat, h, d, x, n, maxd=int(np.ceil(np.nanmax(bd))))["samples"]
+        np.testing.assert_array_equal(outs[k], ref[key])
+
+
+def test_pipelined_launch_that_gives_up_is_rerun_on_one_cu_kernels(cuda, oracle, monkeypatch):
+    """a multi-workgroup launch whose workgroups are not co-resident (CU-masked / shared GPU) times out and drains; the call
+    is then re-run on the one-CU kernel instead of failing with QPN_ENODEV.  The give-up is injected."""
+    import torch
+    cfg, specs = _paper_batch(5)
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    monkeypatch.setenv("QPN_TEST_PIPE_GIVES_UP", "1")
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    assert "timed out, retried" in m.last_decode_plan and "pipe rows=0" in m.last_decode_plan.split("retried:")[1], m.last_decode_plan
+    monkeypatch.delenv("QPN_TEST_PIPE_GIVES_UP")
+    order = np.argsort(ns, kind="stable")
+    maxd = int(np.ceil(np.nanmax(bd)))
+    for k in range(5):
+        b = int(order[k])
+        x, h, d, n = synth.decode_inputs(cfg, specs[b][1], specs[b][0], specs[b][2])
+        np.testing.assert_array_equal(outs[k], oracle.decode(cfg, flat, h, d, x, n, maxd=maxd)["samples"])
+
+
+def test_enqueue_is_asynchronous_and_single_flight(cuda):
+    """qpn_decode_enqueue returns without synchronising (descriptors staged in pinned memory); a second enqueue before
+    qpn_decode_finish is refused."""
+    import ctypes as C
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    m = util.build_model(cfg, synth.make_weights(cfg, 13), cuda)
+    L, hd = m._native(cuda)
+    x, h, d, n = synth.decode_inputs(cfg, 60, 5, 1.0)
+    xt = torch.from_numpy(x[None]).to(cuda); ht = torch.from_numpy(h[None]).to(cuda); dt = torch.from_numpy(d[None]).to(cuda)
+    out = torch.empty((1, n), dtype=torch.int64, device=cuda)
+    stream = torch.cuda.current_stream(cuda).cuda_stream
+    m._bind_decode_weights(L, hd, cuda, stream)
+    arr = (C.c_int64 * 1)(n)
+    maxd = int(np.ceil(d.max()))
+    torch.cuda.synchronize()
+    args = (hd, 1, 1, h.shape[1], d.shape[0], xt.data_ptr(), ht.data_ptr(), dt.data_ptr(), 0, arr, maxd, 0, 0, None, out.data_ptr(), None, stream)
+    _lib.check(L.qpn_decode_enqueue(*args))
+    busy = not torch.cuda.current_stream(cuda).query()            # 6.6 k samples at >= 7 us each: still running when enqueue returns
+    rc = L.qpn_decode_enqueue(*args)
+    assert rc == -5 and b"in flight" in L.qpn_last_error()
+    _lib.check(L.qpn_decode_finish(hd, stream))
+    assert busy, "qpn_decode_enqueue blocked until the decode had finished"
+    assert int(out[0, -1]) >= 0

@@ -44,19 +44,26 @@ def test_world2_without_exchange_equals_world1(cfgname, cuda):
         xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
         l1 = t1.step(xt, ht, tt, dt, bt)
         l2 = t2.step(xt, ht, tt, dt, bt)
-        assert l1 == l2
+        assert abs(l1 - l2) < 1e-6          # (the loss is summed with double atomics: order differs run to run)
         BL = int(b[0])
         n = m1.flat_parameters().numel()
         g1 = t1.g[:n].cpu().numpy().astype(np.float64)
         g2 = t2.g[:n].cpu().numpy().astype(np.float64)
         trailer = t2.g[n:].cpu().numpy()
         np.testing.assert_array_equal(trailer, np.array([x.shape[0] * BL, 0, 0, 0], np.float32))
-        # the weighted gradient is n_r * g_r up to one fp32 rounding per element
-        np.testing.assert_allclose(g2, g1 * (x.shape[0] * BL), rtol=3e-7, atol=0)
+        # the weighted gradient is n_r * g_r (the adaptive blocks' scatter-add uses float atomics, so two runs of the same
+        # backward differ by reassociation: tolerance relative to the largest gradient)
+        nrow = x.shape[0] * BL
+        np.testing.assert_allclose(g2, g1 * nrow, rtol=0, atol=2e-6 * np.abs(g1).max() * nrow)
+        # Adam's update is invariant to a constant scale of g, its first moment is not: m = (1 - b1) * g / denominator pins
+        # the division by the trailer's row count inside qpn_adam_step_ex
+        mm1 = t1.m.cpu().numpy().astype(np.float64); mm2 = t2.m.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(mm2, mm1, rtol=0, atol=2e-6 * np.abs(mm1).max())
+        vv1 = t1.v.cpu().numpy().astype(np.float64); vv2 = t2.v.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(vv2, vv1, rtol=0, atol=4e-6 * np.abs(vv1).max())
     w1 = m1.flat_parameters().cpu().numpy()
     w2 = m2.flat_parameters().cpu().numpy()
-    # Adam normalises the step by sqrt(v): one rounding of g changes an update by < 1e-6 * lr
-    np.testing.assert_allclose(w2, w1, atol=3e-9, rtol=0)
+    np.testing.assert_allclose(w2, w1, atol=2e-7, rtol=0)
     assert np.abs(w1 - flat).max() > 1e-5          # the three steps did move the weights
 
 
