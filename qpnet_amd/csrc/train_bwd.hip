@@ -278,6 +278,154 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     }
 }
 
+// ------------------------------------------------------------------------------------------ layer backward, persistent form (n_resch = 64)
+// Same arithmetic as k_layer_bwd, organised like k_layer_fwd_p (train_fwd.hip): 2 workgroups per CU walk contiguous ranges of
+// 16-row tiles with the layer's TRANSPOSED weights resident in registers -- wave w owns column tile w of dg = dXout . Wr and
+// column tiles {w, w + 4, w + 8} of d[x_cur | x_past | aux] = dZ . W1 (4 + 3 x 8 fragment float4s per lane) -- and the next
+// tile's rows (dXout parts, saved gate halves, skip-path gate grads) and scatter targets in flight under the current tile.
+template <int NTK>      // NTK = Ktp / 16 column tiles of the input gradient (11 for n_resch 64, n_aux 39)
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles) {     // flags: bit 0 last layer, bit 1 XCD swizzle
+    constexpr int C = 64, C4 = C / 4, NIT = (16 * C4) / 256;       // one float4 item per thread and array
+    constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2;
+    constexpr int NJ = (NTK + 3) / 4;                              // column tiles of the second contraction per wave
+    static_assert(NIT == 1, "16 rows x 16 float4 = one item per thread");
+    extern __shared__ float sm[];
+    // per buffer: Dx | Sg | Th | Dg, [16][ldx] each; then Dz [16][ldz]
+    float* Dz = sm + 8 * 16 * ldx;                               // staging buffers: sm, sm + 4 * 16 * ldx
+    const TrLayer ly = p.layers[l];
+    const int last = flags & 1, Ap = p.Ap, N1 = p.N1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    const int g = tr_xcd_tile(blockIdx.x, gridDim.x, flags & 2), G = gridDim.x;
+    const int base = tiles / G, rem = tiles - base * G;
+    const int t_first = g * base + (g < rem ? g : rem), t_count = base + (g < rem ? 1 : 0);
+    if (t_count <= 0) return;
+    const size_t rb = (size_t)b * N1;
+    const size_t nDX = (size_t)p.B * N1 * C;
+    const float* DAin = bw.DXA[0] + (size_t)(l + 1) * nDX + rb * C; const float* DBin = bw.DXB[0] + (size_t)(l + 1) * nDX + rb * C;
+    float* DAout = bw.DXA[0] + (size_t)l * nDX + rb * C; float* DBout = bw.DXB[0] + (size_t)l * nDX + rb * C;
+    const float* SG = p.SG + ((size_t)(l * p.B + b) * N1) * C;
+    const float* TH = p.TH + ((size_t)(l * p.B + b) * N1) * C;
+    const int win0 = N1 - p.BL;
+    const float* DGS = bw.DGS + (size_t)b * p.BL * p.LC + (size_t)l * C;
+    float* DZg = bw.DZ + ((size_t)l * p.B * N1 + rb) * 2 * C;
+    float* DH = bw.DHUP + rb * Ap;
+    const int* taps = p.TAP + ly.tap_off + rb;
+    // ---- resident weight fragments
+    const float4* Wrt = p.wp + ly.wrt_f4; const float4* W1t = p.wp + ly.w1t_f4;
+    float4 wr[4], w1[NJ][8];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wr[ks] = last ? make_float4(0.f, 0.f, 0.f, 0.f) : Wrt[((size_t)ks * 4 + wave) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nt = wave + 4 * j < NTK ? wave + 4 * j : NTK - 1;          // (a wave without a j-th tile keeps a copy it never uses)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w1[j][ks] = W1t[((size_t)ks * NTK + nt) * 64 + lane];
+    }
+    // ---- staging: thread -> (row, 4 columns) of the four [16][C] arrays
+    const int srow = tid / C4, scol = (tid - srow * C4) * 4;
+    float4 ra, rb2, rsg, rth, rdg;
+    auto load_rows = [&](int t) {
+        const int n = ly.s_out + t * 16 + srow;
+        const int nn = n < N1 ? n : N1 - 1;
+        const size_t o = (size_t)nn * C + scol;
+        ra = *(const float4*)(DAin + o); rb2 = *(const float4*)(DBin + o);          // (rows of the last layer: finite garbage, not used)
+        rsg = *(const float4*)(SG + o); rth = *(const float4*)(TH + o);
+        const int nw = nn >= win0 ? nn - win0 : 0;
+        rdg = *(const float4*)(DGS + (size_t)nw * p.LC + scol);
+    };
+    auto store_rows = [&](int t, float* B) {
+        const int n = ly.s_out + t * 16 + srow;
+        const bool in = n < N1;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dx = (in && !last) ? make_float4(ra.x + rb2.x, ra.y + rb2.y, ra.z + rb2.z, ra.w + rb2.w) : z;
+        const float4 sg = in ? rsg : z, th = in ? rth : z, dg = (in && n >= win0) ? rdg : z;
+        float* d0 = B + (size_t)srow * ldx + scol;
+        *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
+        float* d1 = d0 + 16 * ldx; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
+        float* d2 = d1 + 16 * ldx; *(float2*)d2 = make_float2(th.x, th.y); *(float2*)(d2 + 2) = make_float2(th.z, th.w);
+        float* d3 = d2 + 16 * ldx; *(float2*)d3 = make_float2(dg.x, dg.y); *(float2*)(d3 + 2) = make_float2(dg.z, dg.w);
+    };
+    int tprow[4], tpnext[4];
+    auto load_taps = [&](int t, int (&tp)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * (lane >> 4) + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
+    };
+    load_rows(t_first);
+    load_taps(t_first, tprow);
+    store_rows(t_first, sm);
+    const int arow = lane & 15, ak = lane >> 4;
+    const int c = 16 * wave + (lane & 15);
+    for (int ti = 0; ti < t_count; ++ti) {
+        const int t = t_first + ti, n0 = ly.s_out + t * 16;
+        float* Dx = sm + (ti & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
+        if (ti + 1 < t_count) { load_rows(t + 1); load_taps(t + 1, tpnext); }
+        TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz free (readers: previous trip's second contraction)
+        // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
+        f32x4 a0 = (f32x4){0, 0, 0, 0};
+        if (!last) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float* ap = Dx + (size_t)arow * ldx + 16 * ks + ak;
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], wr[ks].x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], wr[ks].y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], wr[ks].z, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], wr[ks].w, a0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * (lane >> 4) + i, n = n0 + r;
+            const float dg = a0[i] + Dg[(size_t)r * ldx + c];
+            const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
+            const float dzs = dg * th * sg * (1.0f - sg);
+            const float dzt = dg * sg * (1.0f - th * th);
+            if (n < N1) { DZg[(size_t)n * 2 * C + c] = dzs; DZg[(size_t)n * 2 * C + C + c] = dzt; }
+            Dz[(size_t)r * ldz + c] = dzs; Dz[(size_t)r * ldz + C + c] = dzt;
+        }
+        TR_LDS_BARRIER();
+        // ---- d[x_cur | x_past | aux] = dZ . W1
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float* zp = Dz + (size_t)arow * ldz + 16 * ks + ak;
+            const float z0 = zp[0], z1 = zp[4], z2 = zp[8], z3 = zp[12];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, w1[j][ks].x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z1, w1[j][ks].y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z2, w1[j][ks].z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3, w1[j][ks].w, acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nt = wave + 4 * j;
+            if (nt >= NTK) continue;                               // wave-uniform
+            const int k = 16 * nt + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (lane >> 4) + i, n = n0 + r;
+                if (n >= N1) continue;
+                const float v = acc[j][i];
+                if (k < C) DAout[(size_t)n * C + k] = v + Dx[(size_t)r * ldx + k];              // + residual path
+                else if (k < 2 * C) {
+                    if (ly.adaptive) atomicAdd(&DBout[(size_t)tprow[i] * C + (k - C)], v);      // gather backward (collisions)
+                    else DBout[(size_t)tprow[i] * C + (k - C)] = v;                             // unique writer
+                } else if (k < 2 * C + Ap) atomicAdd(&DH[(size_t)n * Ap + (k - 2 * C)], v);     // unique writer per layer, layers in order
+            }
+        }
+        if (ti + 1 < t_count) {
+            store_rows(t + 1, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradients, v2
 // One launch covers every layer (blockIdx.y) and every time chunk (blockIdx.x).  A workgroup (4 waves)
 // computes the WHOLE output block dW[M][N] of its layer for its chunk of rows: wave w owns m-tiles
@@ -966,10 +1114,18 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     const int cut_row = split ? tr_split_cut(p) : 0;
     const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
     if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
+    // (opt-in, QPN_LAYER_BWD_PERSIST=1: first form measured 0.205 vs 0.197 ms per step for the tile-per-workgroup launches)
+    const bool persist = C == 64 && p.Ktp == 176 && !split && getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 1;
+    const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
-        if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
+        if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)
+            const int tiles = (rows + 15) / 16;
+            int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+            const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C)) * sizeof(float);
+            hipLaunchKernelGGL((k_layer_bwd_p<11>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, (l == L - 1 ? 1 : 0) | (swz ? 2 : 0), tiles);
+        } else if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
             const size_t lds1 = lds_layer / MT;
             if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
             const int tiles = (rows + 15) / 16, lastf = l == L - 1 ? 1 : 0;

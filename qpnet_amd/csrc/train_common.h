@@ -51,6 +51,7 @@ struct TrainParams {
     // fused cross entropy in the post-net kernel (qpn_train_forward_loss): targets = last BL columns of ce_tgt rows; nullptr = off
     const int64_t* ce_tgt; int64_t ce_stride; float* ce_dlogits; double* ce_loss;
     int* status;
+    float* scratch_rows;      // [B * 1024 workgroups][2][128] floats nobody reads: target of the persistent kernels' out-of-range row stores
     // post-net packed blocks
     int ws_f4, p1_f4, p2_f4;          // fwd: [LC x S], [S x S], [S x Q]
     int wst_f4, p1t_f4, p2t_f4;       // bwd: [S x LC], [S x S], [Q x S]
@@ -103,6 +104,14 @@ struct TrainGemm {
     long w1[TR_MAXL], w1t[TR_MAXL], wr[TR_MAXL], wrt[TR_MAXL];
     long ws, wst, p1, p1t, p2, p2t;
 };
+
+// Workgroup barrier that orders LDS traffic only.  hipcc's __syncthreads() also drains vmcnt: every global load / store the wave
+// has in flight -- in the persistent kernels that is the NEXT tile's prefetch, requested a moment earlier precisely so that it
+// flies under this tile's contractions -- would be waited for at every barrier.  The LDS writes of this wave are complete
+// (lgkmcnt(0)) before it arrives; registers still being loaded are tracked by the compiler's own s_waitcnt at their first use.
+#define TR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+int qpn_num_cus();                                   // compute units of the current device (cached per device)
 
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)
 enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE, PG_COUNT };

@@ -16,8 +16,9 @@
 
 // gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32): ~6 instructions each instead of
 // the ~50 of libm's expf/tanhf, which made the epilogue as long as the GEMM; abs error ~1e-7 (tolerance: loss 1e-4)
-__device__ __forceinline__ float sigmoidf_(float z) { return __frcp_rn(1.0f + __expf(-z)); }
-__device__ __forceinline__ float tanhf_(float z) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * z)) - 1.0f; }
+// (__frcp_rn is a correctly rounded division: div_scale / rcp / 4 fma / div_fmas / div_fixup, 11 instructions; v_rcp_f32 is 1 ulp)
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float tanhf_(float z) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f; }
 
 // Elementwise over (row, 4 channels): every access is a coalesced 16-byte load / store, no per-row serialisation.
 //   items [0, N1*C/4)                : X0[n][c..c+3] = tap-0 row of class x[n] + tap-1 row of class x[n+1] + bias  (transposed table p.ct)
@@ -201,6 +202,189 @@ template <int MT>
 __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {      // last: bit 0 last layer, bit 1 XCD swizzle, bits 4.. first tile
     extern __shared__ float sm[];
     layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + ((last >> 4) + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2)) * 16 * MT, sm);
+}
+
+// ------------------------------------------------------------------------------------------------ persistent form, n_resch = 64
+// One launch per layer as before, but 2 workgroups per CU that each walk a contiguous range of 16-row tiles, and the layer's
+// weights live in REGISTERS for the whole launch: wave w owns gate column tiles {w (sigma), 4 + w (tanh)} and residual column
+// tile w, i.e. KS x 2 + 4 fragment float4s per lane (104 registers at KS = 11), read from L2 once per workgroup instead of once
+// per tile (115 MB -> 27 MB per launch) -- the contraction loop has no global load in it.  Around it:
+//  * the rows of tile t+1 are requested before the matrix cores start on tile t and go to the other LDS buffer behind them
+//    (their tap-table entry one tile earlier still): neither round trip of the pitch-dependent gather is exposed after tile 0;
+//    every thread's three row pieces have a FIXED source (x_cur | x_past | aux): straight-line address code, no divergence;
+//  * sigma, tanh and the block output leave through LDS: a thread stores 8-byte pieces of whole 256-byte rows (full cache
+//    lines, one address per array and tile) instead of 64-byte column strips straight from the accumulator layout;
+//  * barriers order LDS only (TR_LDS_BARRIER): the prefetch and the stores stay in flight across them.
+// (reference: the fixed / adaptive gated block of src/nets/qpnet.py:626-670; same arithmetic as layer_fwd_tile above.)
+// dev aid (build with -DQPN_ENABLE_STAMPS, run with QPN_FWDP_STAMPS=1): s_memtime of wave 0 at the phase boundaries of a few workgroups
+#ifdef QPN_ENABLE_STAMPS
+#define FWDP_STAMP(i) do { if (stamps && lane == 0 && wave == 0 && (blockIdx.x & 63) == 5 && (i) < 64) stamps[(blockIdx.x >> 6) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FWDP_STAMP(i) do { } while (0)
+#endif
+// tile range of workgroup `orig` (hardware id) of a grid of G over `tiles` tiles: ranges are contiguous in the XCD-aware order
+// g = tr_xcd_tile(orig) and as even as possible; the `rem` workgroups that take one tile more are the ones with the LOWEST
+// hardware ids -- with two workgroups per CU dealt in id order, a CU then gets (base + 1) + base tiles rather than 2 (base + 1)
+__device__ __forceinline__ void tr_tile_range(int orig, int G, int tiles, int swz, int& t_first, int& t_count) {
+    const int base = tiles / G, rem = tiles - base * G;
+    if (!swz || G <= 8) { t_first = orig * base + (orig < rem ? orig : rem); t_count = base + (orig < rem ? 1 : 0); return; }
+    const int q = G / 8, r = G % 8, xcd = orig % 8, j = orig / 8;
+    const int g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;          // = tr_xcd_tile(orig, G, 1)
+    int before = 0;                                                                       // workgroups with an extra tile among g' < g
+    for (int x = 0; x < xcd; ++x) before += rem > x ? (rem - x + 7) / 8 : 0;
+    const int mine = rem > xcd ? (rem - xcd + 7) / 8 : 0;
+    before += j < mine ? j : mine;
+    t_first = g * base + before; t_count = base + (orig < rem ? 1 : 0);
+}
+template <int KS, bool LAST>
+__global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy, long long* stamps) {     // flags: bit 1 XCD swizzle
+    constexpr int C = 64, Ktp = 16 * KS;
+    constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;     // tr_lda: conflict-free fragment reads, 8-byte aligned rows
+    extern __shared__ float sm[];
+    float* Gs = sm + 32 * lda;                                   // As buffers: sm, sm + 16 * lda
+    float* SGs = Gs + 16 * ldg; float* THs = SGs + 16 * ldg; float* Xs = THs + 16 * ldg;
+    const TrLayer ly = p.layers[l];
+    const int Ap = p.Ap, N1 = p.N1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y;
+    int t_first, t_count;
+    tr_tile_range(blockIdx.x, gridDim.x, tiles, flags & 2, t_first, t_count);
+    if (t_count <= 0) return;
+    const int t_last = t_first + t_count - 1;
+    const float* Xin = p.X + ((size_t)(l * p.B + b) * N1) * C;
+    const float* hup = p.HUP + (size_t)b * N1 * Ap;
+    const int* taps = p.TAP + ly.tap_off + (size_t)b * N1;
+    float* SG = p.SG + ((size_t)(l * p.B + b) * N1) * C;
+    float* TH = p.TH + ((size_t)(l * p.B + b) * N1) * C;
+    float* Xout = p.X + ((size_t)((l + 1) * p.B + b) * N1) * C;
+    // ---- resident weight fragments and biases
+    const float4* W1 = p.wp + ly.w1_f4; const float4* Wr = p.wp + ly.wr_f4;
+    float4 w1[KS][2], wr[4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { w1[ks][0] = W1[((size_t)ks * 8 + wave) * 64 + lane]; w1[ks][1] = W1[((size_t)ks * 8 + 4 + wave) * 64 + lane]; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wr[ks] = LAST ? make_float4(0.f, 0.f, 0.f, 0.f) : Wr[((size_t)ks * 4 + wave) * 64 + lane];
+    const int c = 16 * wave + (lane & 15);
+    const float bs = p.bp[ly.bias1 + c], bt = p.bp[ly.bias1 + C + c], bb = p.bp[ly.biasr + c];
+    // ---- staging in: thread -> row srow, 16-byte piece sc4 of x_cur, of x_past (row tap[n]) and -- threads with sc4 < 12 -- of the
+    //      aux columns (zero beyond n_aux).  staging out: thread -> 8-byte pieces (row orow, orow + 8; column oc2) of a [16][64] tile.
+    //      The tile loop is STRAIGHT-LINE code: every load and store is unconditional (rows past the chunk end are clamped on
+    //      the way in and redirected to a scratch row on the way out), so hipcc's s_waitcnt vmcnt(N) before the use of a prefetched
+    //      register counts the younger stores exactly instead of draining them (a guarded store is "maybe zero stores" to the pass)
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
+    const int orow = tid >> 5, oc2 = (tid & 31) * 2;
+    float* const dmy = dummy + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + oc2;       // two scratch rows per workgroup
+    int tp; float4 rc, rp, rx;
+    auto load_tap = [&](int t) { const int n = ly.s_out + t * 16 + srow; tp = taps[n < N1 ? n : N1 - 1]; };
+    auto load_rows = [&](int t) {
+        const int n = ly.s_out + t * 16 + srow, nn = n < N1 ? n : N1 - 1;
+        rc = *(const float4*)(Xin + (size_t)nn * C + 4 * sc4);
+        rp = *(const float4*)(Xin + (size_t)tp * C + 4 * sc4);
+        rx = *(const float4*)(hup + (size_t)nn * Ap + (aux_real ? 4 * sc4 : 0));
+    };
+    auto store_rows = [&](int t, float* As) {
+        const bool in = ly.s_out + t * 16 + srow < N1;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vc = in ? rc : z, vp = in ? rp : z, vx = (in && aux_real) ? rx : z;
+        float* d = As + (size_t)srow * lda + 4 * sc4;
+        *(float2*)d = make_float2(vc.x, vc.y); *(float2*)(d + 2) = make_float2(vc.z, vc.w);
+        *(float2*)(d + C) = make_float2(vp.x, vp.y); *(float2*)(d + C + 2) = make_float2(vp.z, vp.w);
+        if (aux_thread) { *(float2*)(d + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(d + 2 * C + 2) = make_float2(vx.z, vx.w); }
+    };
+    auto store_out = [&](const float* T, float* dst, int n0, bool live) {      // a [16][64] LDS tile -> rows n0.. of a [N1][64] array, whole rows
+        const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
+        float* d0 = dst + ((size_t)n0 + orow) * C + oc2;
+        float* d1 = d0 + 8 * C;
+        d0 = (live && n0 + orow < N1) ? d0 : dmy;
+        d1 = (live && n0 + orow + 8 < N1) ? d1 : dmy + C;
+        *(float2*)d0 = v0; *(float2*)d1 = v1;
+    };
+    // ---- prologue: rows of the first tile, tap of the second
+    FWDP_STAMP(0);
+    load_tap(t_first);
+    load_rows(t_first);
+    store_rows(t_first, sm);
+    load_tap(t_first + 1 < t_last ? t_first + 1 : t_last);
+    FWDP_STAMP(1);
+    const int arow = lane & 15, ak = lane >> 4;
+    for (int ti = 0; ti < t_count; ++ti) {
+        const int t = t_first + ti, n0 = ly.s_out + t * 16;
+        float* As = sm + (ti & 1) * 16 * lda;
+        FWDP_STAMP(2 + 8 * ti);
+        load_rows(t + 1 < t_last ? t + 1 : t_last);              // in flight under this tile's contractions (past the range: a harmless reload)
+        load_tap(t + 2 < t_last ? t + 2 : t_last);
+        FWDP_STAMP(3 + 8 * ti);
+        TR_LDS_BARRIER();                                          // As[ti & 1] complete (written at the end of the previous trip); Xs of the previous tile complete
+        FWDP_STAMP(4 + 8 * ti);
+        if (!LAST) store_out(Xs, Xout, n0 - 16, ti > 0);
+        float xa[KS][4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* ap = As + (size_t)arow * lda + 16 * ks + ak;
+            xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12];
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // all fragment reads of the tile issued before the first MFMA (hipcc otherwise
+                                                                  // sinks each read to its use: an LDS round trip in front of every second MFMA pair)
+        f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][0].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][1].x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][0].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][1].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][0].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][1].z, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][0].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][1].w, a1, 0, 0, 0);
+        }
+        FWDP_STAMP(5 + 8 * ti);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (4 * (lane >> 4) + i) * ldg + c;
+            const float sg = sigmoidf_(a0[i] + bs), th = tanhf_(a1[i] + bt);
+            Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
+        }
+        FWDP_STAMP(6 + 8 * ti);
+        TR_LDS_BARRIER();
+        FWDP_STAMP(7 + 8 * ti);
+        if (!LAST) {                                              // the last block's residual output is never used (qpnet.py:306-309)
+            float ga[4][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float* gp = Gs + (size_t)arow * ldg + 16 * ks + ak;
+                ga[ks][0] = gp[0]; ga[ks][1] = gp[4]; ga[ks][2] = gp[8]; ga[ks][3] = gp[12];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 ar0 = (f32x4){0, 0, 0, 0}, ar1 = (f32x4){0, 0, 0, 0};     // two chains: a dependent 16x16x4 pair is 40 cycles apart, the pipe issues every 32
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][0], wr[ks].x, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][0], wr[ks + 1].x, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][1], wr[ks].y, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][1], wr[ks + 1].y, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][2], wr[ks].z, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][2], wr[ks + 1].z, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
+            }
+            store_out(SGs, SG, n0, true);                         // (under the residual contraction)
+            store_out(THs, TH, n0, true);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (lane >> 4) + i;
+                Xs[r * ldg + c] = ((ar0[i] + ar1[i]) + bb) + As[(size_t)r * lda + c];      // leaves after the next barrier
+            }
+        } else {
+            store_out(SGs, SG, n0, true);
+            store_out(THs, TH, n0, true);
+        }
+        FWDP_STAMP(8 + 8 * ti);
+#ifdef QPN_ENABLE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stamped build only: how long until every load / store in flight has landed
+        FWDP_STAMP(40 + ti);
+#endif
+        // the next tile's rows have had a whole tile of matrix work to arrive: into the OTHER buffer (its last readers were
+        // the previous trip's contractions, two barriers ago)
+        store_rows(t + 1, sm + ((ti + 1) & 1) * 16 * lda);
+        FWDP_STAMP(9 + 8 * ti);
+    }
+    if (!LAST) {
+        TR_LDS_BARRIER();
+        store_out(Xs, Xout, ly.s_out + t_last * 16, true);
+    }
 }
 
 // dynamic LDS: St[TM][lda(S)] | Yt[TM][max(lda(S), 2 lda(C))]  (the two G_l staging buffers alias Yt)
@@ -533,9 +717,33 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
         const int flags0 = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2;
         const int cut_row = split ? tr_split_cut(p) : 0;
         if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
+        // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
+        const bool persist = C == 64 && p.Ktp == 176 && !split && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);
+        const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
         for (int l = 0; l < p.L; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
-            if (lmt == 1) {
+            if (persist) {
+                const int tiles = (rows + 15) / 16;
+                int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+                const size_t ldsp = (size_t)(32 * tr_lda(176) + 4 * 16 * tr_lda(64)) * sizeof(float);
+                static long long* d_stamps = nullptr;
+                const bool stamp = getenv("QPN_FWDP_STAMPS") != nullptr;
+                if (stamp && !d_stamps) { QPN_HIP(hipMalloc(&d_stamps, 16 * 64 * sizeof(long long))); }
+                if (stamp) QPN_HIP(hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream));
+                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr);
+                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr);
+                if (stamp && l == 5) {      // dev aid: print the stamps of one adaptive layer's launch (cycles relative to the first stamp of each sampled workgroup)
+                    static int printed = 0;
+                    long long hs[16 * 64];
+                    QPN_HIP(hipStreamSynchronize(stream));
+                    QPN_HIP(hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost));
+                    if (printed++ == 30) for (int w = 0; w < 8; ++w) {
+                        fprintf(stderr, "fwdp stamps wg %d:", 64 * w + 5);
+                        for (int i = 0; i < 46; ++i) fprintf(stderr, " %lld", hs[w * 64 + i] ? hs[w * 64 + i] - hs[w * 64] : -1LL);
+                        fprintf(stderr, "\n");
+                    }
+                }
+            } else if (lmt == 1) {
                 size_t lds1 = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float); if (pad > lds1) lds1 = pad;
                 if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
                 const int tiles = (rows + 15) / 16, fl = (l == p.L - 1 ? 1 : 0) | flags0;

@@ -38,6 +38,14 @@ struct TrainState {
     TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
 };
 
+int qpn_num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256; cached[dev] = n; }
+    return cached[dev];
+}
+
 // ---- per-group timing
 struct Prof { bool on = false; std::vector<hipEvent_t> ev; std::vector<int> grp; size_t used = 0; };
 static thread_local Prof g_prof;
@@ -367,7 +375,8 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     TrainBwd& bw = t->bw;
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
     const size_t nXC = (size_t)B * (N1 + 1);
-    size_t need = nX + 2 * nG + nH + 2 * (nS + 16 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
+    const size_t nScr = (size_t)B * 1024 * 2 * 128;
+    size_t need = nScr + nX + 2 * nG + nH + 2 * (nS + 16 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -388,6 +397,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     bw.DXA[0] = carve((size_t)(L + 1) * nDX); bw.DXB[0] = carve((size_t)(L + 1) * nDX); bw.DXA[1] = bw.DXB[1] = nullptr;   // DXB directly follows DXA (one memset)
     bw.DZ = carve((size_t)L * nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
     p.XC = (int*)carve(nXC);
+    p.scratch_rows = carve(nScr);
     if (t->use_gemm) t->gm.G = carve(nG);
     p.TAP = t->d_tap; p.status = t->d_status;
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
