@@ -276,3 +276,54 @@ __device__ __forceinline__ void wave_gemm2(f32x4 (&acc)[MT][2], const float* __r
     if constexpr (PD <= 1) wave_gemm<MT, 2>(acc, A_lds, lda, Bp, NT, nts, K, lane);
     else wave_gemm_ring<MT, 2, PD>(acc, A_lds, lda, Bp, NT, nts, K, lane);
 }
+
+// ---- wide post-net tiles (k_post_fwd_w / k_post_bwd_w): a wave owns two column tiles and 16 MT rows
+template <int MT>
+__device__ __forceinline__ void post_load_a(float (&x)[MT][4], const float* __restrict__ A, int lda, int ks, int arow, int ak) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const float* ap = A + (size_t)(16 * mt + arow) * lda + 16 * ks + ak;
+        x[mt][0] = ap[0]; x[mt][1] = ap[4]; x[mt][2] = ap[8]; x[mt][3] = ap[12];
+    }
+}
+template <int MT>
+__device__ __forceinline__ void post_mfma(f32x4 (&acc)[MT][2], const float (&x)[MT][4], const float4& b0, const float4& b1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][0], b0.x, acc[mt][0], 0, 0, 0); acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][0], b1.x, acc[mt][1], 0, 0, 0);
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][1], b0.y, acc[mt][0], 0, 0, 0); acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][1], b1.y, acc[mt][1], 0, 0, 0);
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][2], b0.z, acc[mt][0], 0, 0, 0); acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][2], b1.z, acc[mt][1], 0, 0, 0);
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][3], b0.w, acc[mt][0], 0, 0, 0); acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[mt][3], b1.w, acc[mt][1], 0, 0, 0);
+    }
+}
+// acc += A[16 MT][K] . B[:, two column tiles].  Software pipeline, one 16-deep step ahead on BOTH operands: the weight fragments
+// (global, b) and the A fragments (LDS, x) of step ks+1 are requested before step ks's 8 MT MFMAs, every group pinned in place with
+// scheduling barriers -- left alone hipcc sinks each ds_read2_b32 to its use and reuses ONE register pair for all of them: an LDS
+// round trip in front of every fourth MFMA (the matrix cores 0.6 busy).  b holds step 0 on entry and, on return, the first step
+// of the FOLLOWING contraction (address `next`), so no contraction starts with an exposed L2 round trip.
+template <int MT>
+__device__ __forceinline__ void post_gemm(f32x4 (&acc)[MT][2], const float* __restrict__ A, int lda, const float4* __restrict__ Bp, int NT, int nt0, int nk,
+                                          int lane, float4 (&b)[2], const float4* __restrict__ next) {
+    const int arow = lane & 15, ak = lane >> 4;
+    float x0[MT][4], x1[MT][4];
+    post_load_a<MT>(x0, A, lda, 0, arow, ak);
+    for (int ks = 0; ks < nk; ks += 2) {                          // nk is even (K a multiple of 32)
+#ifdef POSTW_TEST_NOB      // timing experiment only (wrong results): no weight-fragment loads inside the contraction
+        float4 c0 = b[0], c1 = b[1];
+#else
+        float4 c0 = Bp[((size_t)(ks + 1) * NT + nt0) * 64 + lane], c1 = Bp[((size_t)(ks + 1) * NT + nt0 + 1) * 64 + lane];
+#endif
+        post_load_a<MT>(x1, A, lda, ks + 1, arow, ak);
+        __builtin_amdgcn_sched_barrier(0);
+        post_mfma<MT>(acc, x0, b[0], b[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef POSTW_TEST_NOB
+        const float4* nx = ks + 2 < nk ? Bp + ((size_t)(ks + 2) * NT + nt0) * 64 + lane : next;
+        b[0] = nx[0]; b[1] = nx[64];
+#endif
+        post_load_a<MT>(x0, A, lda, ks + 2 < nk ? ks + 2 : ks, arow, ak);      // (past the end: a harmless re-read)
+        __builtin_amdgcn_sched_barrier(0);
+        post_mfma<MT>(acc, x1, c0, c1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}

@@ -637,6 +637,150 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ post-net, wide tiles (S = Q = 256)
+// k_post_fwd streams the post-net's 1 MB of weight fragments from L2 once per 16-row tile: 1250 tiles = 1.25 GB per launch, and a
+// 16-deep step's two fragment loads feed only 8 MFMAs (256 cycles) -- the launch runs at the L2's pace, 0.5 of the matrix-core rate.
+// Here a workgroup takes 16 * MT rows (MT = 5: 80 rows, so a 20 000-row chunk is 250 workgroups = ONE round on 256 CUs): the same
+// two loads feed 8 * MT MFMAs, weight traffic drops MT-fold, and the K = L*C skip sum runs as one continuous fragment stream with
+// the gate rows of layer l+1 landing in the other LDS buffer under layer l's contraction.  One [16 MT][S] LDS tile is reused IN
+// PLACE by the three stages (every wave holds its outputs in registers across the barrier that ends the reads), and relu(s0) /
+// relu(y0) leave from it as whole rows -- the backward only needs their sign (the ReLU mask) and the rectified values (weight
+// gradients), so the rectified values are what is stored.   (reference: _postprocess, src/nets/qpnet.py:566-571, 283-309)
+template <int MT>
+__global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
+    constexpr int TM = 16 * MT, S = 256, Q = 256, C = 64, NTS = S / 16;
+    constexpr int lds = ((S + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;
+    constexpr int NG = (TM * (C / 2) + 511) / 512;               // float2 pairs of a [TM][C] gate tile per thread
+    extern __shared__ float sm[];
+    float* T = sm;                                                // [TM][lds]; gate staging: T + TM*lds + {0, TM*ldg}
+    float* Gb = sm + TM * lds;
+    const int L = p.L, b = blockIdx.y, t0 = blockIdx.x * TM;
+    const int nbase = p.N1 - p.BL + t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt0 = 2 * wave;                                     // this wave's two column tiles (of 16) in every stage
+    const int c0 = 16 * nt0 + (lane & 15), c1 = c0 + 16;
+    const float bs0 = p.bp[p.bias_s + c0], bs1 = p.bp[p.bias_s + c1], bp10 = p.bp[p.bias_p1 + c0], bp11 = p.bp[p.bias_p1 + c1],
+                bp20 = p.bp[p.bias_p2 + c0], bp21 = p.bp[p.bias_p2 + c1];
+    const float4* Ws = p.wp + p.ws_f4; const float4* P1 = p.wp + p.p1_f4; const float4* P2 = p.wp + p.p2_f4;
+    float4 bq[2] = {Ws[(size_t)nt0 * 64 + lane], Ws[(size_t)(nt0 + 1) * 64 + lane]};
+    // ---- gate rows of one layer: thread -> NG (row, column pair) items; sigma and tanh halves multiplied on the way into LDS
+    float2 ga[NG], gt[NG];
+    auto gfetch = [&](int l) {
+        const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
+        const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
+            const bool ok = idx < TM * (C / 2) && t0 + r < p.BL;
+            const size_t o = ok ? (size_t)(nbase + r) * C + kk : 0;
+            ga[k] = *(const float2*)(SG + o); gt[k] = *(const float2*)(TH + o);
+        }
+    };
+    auto gstore = [&](float* G) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
+            if (idx < TM * (C / 2)) *(float2*)(G + (size_t)r * ldg + kk) = t0 + r < p.BL ? make_float2(ga[k].x * gt[k].x, ga[k].y * gt[k].y) : make_float2(0.f, 0.f);
+        }
+    };
+    // a finished stage: rectified outputs into T (in place: every wave has passed the barrier that ends the stage's reads) ...
+    auto put = [&](const f32x4 (&acc)[MT][2], float bias0, float bias1, bool relu) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * mt + 4 * (lane >> 4) + i;
+                float v0 = acc[mt][0][i] + bias0, v1 = acc[mt][1][i] + bias1;
+                if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+                T[(size_t)r * lds + c0] = v0; T[(size_t)r * lds + c1] = v1;
+            }
+    };
+    // ... and from there to a [BL][256] array as whole 1 KB rows
+    auto rows_out = [&](float* dst) {
+#ifdef POSTW_TEST_NOOUT     // timing experiment only
+        if (p.BL > 0) return;
+#endif
+        for (int idx = tid; idx < TM * (S / 2); idx += 512) {
+            const int r = idx / (S / 2), kk = (idx - r * (S / 2)) * 2;
+            if (t0 + r < p.BL) *(float2*)(dst + ((size_t)b * p.BL + t0 + r) * S + kk) = *(const float2*)(T + (size_t)r * lds + kk);
+        }
+    };
+    f32x4 acc[MT][2];
+#define POSTW_ZERO() _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
+    // ---------- skip sum: one K = L*C contraction, layer l's gates in Gb[l & 1]
+    POSTW_ZERO();
+    gfetch(0);
+    for (int l = 0; l < L; ++l) {
+        float* G = Gb + (l & 1) * TM * ldg;
+        gstore(G);
+        TR_LDS_BARRIER();                                          // G complete; the other buffer's readers (layer l-1) are done
+        if (l + 1 < L) gfetch(l + 1);
+        post_gemm<MT>(acc, G, ldg, Ws + (size_t)l * (C / 16) * NTS * 64, NTS, nt0, C / 16, lane, bq,
+                      l + 1 < L ? Ws + ((size_t)(l + 1) * (C / 16) * NTS + nt0) * 64 + lane : P1 + (size_t)nt0 * 64 + lane);
+    }
+    put(acc, bs0, bs1, true);
+    TR_LDS_BARRIER();
+    rows_out(p.S0);                                               // relu(s0): sign = the backward's mask, value = the weight gradient's operand
+    // ---------- post 1x1 #1
+    POSTW_ZERO();
+    post_gemm<MT>(acc, T, lds, P1, NTS, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
+    TR_LDS_BARRIER();                                              // every wave (and rows_out) is done reading T
+    put(acc, bp10, bp11, true);
+    TR_LDS_BARRIER();
+    rows_out(p.Y0);
+    // ---------- post 1x1 #2
+    POSTW_ZERO();
+    post_gemm<MT>(acc, T, lds, P2, Q / 16, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
+    TR_LDS_BARRIER();
+    put(acc, bp20, bp21, false);
+    TR_LDS_BARRIER();
+#undef POSTW_ZERO
+    if (p.logits)
+        for (int idx = tid; idx < TM * (Q / 2); idx += 512) {
+            const int r = idx / (Q / 2), kk = (idx - r * (Q / 2)) * 2;
+            if (t0 + r < p.BL) *(float2*)(p.logits + ((size_t)b * p.BL + t0 + r) * Q + kk) = *(const float2*)(T + (size_t)r * lds + kk);
+        }
+#ifdef POSTW_TEST_NOOUT
+    if (p.BL > 0) return;
+#endif
+    if (!p.ce_tgt) return;
+    // ---------- fused torch.nn.CrossEntropyLoss() (mean) and its gradient while the logits are in LDS (same arithmetic as k_ce)
+    {
+        const int64_t rows = (int64_t)p.B * p.BL;
+        const float inv = 1.0f / (float)rows;
+        double lsum = 0.0;
+        for (int r = wave; r < TM; r += 8) {
+            if (t0 + r >= p.BL) break;
+            const float* lg = T + (size_t)r * lds;
+            const int64_t row = (int64_t)b * p.BL + t0 + r;
+            int64_t tg = p.ce_tgt[(size_t)b * p.ce_stride + (p.ce_stride - p.BL) + t0 + r];
+            if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
+            const int q = lane * 4;
+            const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2);
+            float m = fmaxf(fmaxf(v01.x, v01.y), fmaxf(v23.x, v23.y));
+            for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+            float se = (__expf(v01.x - m) + __expf(v01.y - m)) + (__expf(v23.x - m) + __expf(v23.y - m));
+            for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+            const float lse = logf(se) + m;
+            if (p.ce_dlogits) {
+                float4 gq = make_float4(__expf(v01.x - lse), __expf(v01.y - lse), __expf(v23.x - lse), __expf(v23.y - lse));
+                const int dq = (int)tg - q;
+                if (dq == 0) gq.x -= 1.0f; else if (dq == 1) gq.y -= 1.0f; else if (dq == 2) gq.z -= 1.0f; else if (dq == 3) gq.w -= 1.0f;
+                *(float4*)(p.ce_dlogits + (size_t)row * Q + q) = make_float4(gq.x * inv, gq.y * inv, gq.z * inv, gq.w * inv);
+            }
+            lsum += (double)(lse - lg[tg]);
+        }
+        double* part = (double*)Gb;                               // the gate staging is dead
+        if (lane == 0) part[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) {
+            double sacc = 0.0;
+            for (int w8 = 0; w8 < 8; ++w8) sacc += part[w8];
+            atomicAdd(p.ce_loss + (blockIdx.x & 63), sacc / (double)rows);
+        }
+    }
+}
+
 // mean cross entropy + its gradient, one wave per row, rpw rows per wave (reference qpnet_train.py:430,526-528)
 __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, const int64_t* __restrict__ tgt, int64_t tgt_stride,
                                             int BL, int Q, int64_t rows, float* __restrict__ dlogits, double* __restrict__ loss, int rpw, int* __restrict__ status) {
@@ -763,7 +907,14 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
         if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     }
     qpn_prof_mark(PG_LAYER_FWD, stream);
-    if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
+    // wide post-net tiles (S = Q = 256, n_resch 64): 16 * MT rows per workgroup, MT chosen so that the chunk is one round of workgroups
+    const bool post_wide = S == 256 && p.Q == 256 && C == 64 && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
+    if (post_wide) {
+        constexpr int MTW = 5;
+        const size_t ldsw = (size_t)16 * MTW * (tr_lda(256) + 2 * tr_lda(64)) * sizeof(float);
+        QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
+        hipLaunchKernelGGL((k_post_fwd_w<MTW>), dim3((p.BL + 16 * MTW - 1) / (16 * MTW), p.B), dim3(512), ldsw, stream, p);
+    } else if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
         const size_t lds1 = lds_post / MT;
         if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
         hipLaunchKernelGGL((k_post_fwd<1>), dim3((p.BL + 15) / 16, p.B), dim3(512), lds1, stream, p);

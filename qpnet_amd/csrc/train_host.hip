@@ -376,7 +376,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
     const size_t nXC = (size_t)B * (N1 + 1);
     const size_t nScr = (size_t)B * 1024 * 2 * 128;
-    size_t need = nScr + nX + 2 * nG + nH + 2 * (nS + 16 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
+    size_t need = nScr + nX + 2 * nG + nH + 2 * (nS + 96 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -393,7 +393,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     }
     float* w = t->d_ws;
     auto carve = [&](size_t n) { float* r = w; w += (n + 63) & ~(size_t)63; return r; };
-    p.X = carve(nX); p.SG = carve(nG); p.TH = carve(nG); p.HUP = carve(nH); p.S0 = carve(nS + 16 * (size_t)S); p.Y0 = carve(nS + 16 * (size_t)S);       // + one tile of rows: the post-net backward prefetches its masks unclamped
+    p.X = carve(nX); p.SG = carve(nG); p.TH = carve(nG); p.HUP = carve(nH); p.S0 = carve(nS + 96 * (size_t)S); p.Y0 = carve(nS + 96 * (size_t)S);       // + one (80-row) tile of rows: the post-net backward prefetches its masks unclamped
     bw.DXA[0] = carve((size_t)(L + 1) * nDX); bw.DXB[0] = carve((size_t)(L + 1) * nDX); bw.DXA[1] = bw.DXB[1] = nullptr;   // DXB directly follows DXA (one memset)
     bw.DZ = carve((size_t)L * nDZ); bw.DS0 = carve(nS); bw.DY0 = carve(nS); bw.DGS = carve(nDGS); bw.DHUP = carve(nH); bw.slab = carve(nSlab);
     p.XC = (int*)carve(nXC);
