@@ -147,6 +147,13 @@ int64_t qpn_train_generation(qpn_handle* h);
  * pitch-dependent tap left its layer input: reference assert qpnet.py:294). */
 int qpn_train_status(qpn_handle* h, void* stream);
 
+/* The same check without draining the stream: _enqueue copies the status word (sticky: kernels OR into it, only a read
+ * clears it) to pinned memory behind the work enqueued so far and returns; _collect waits for that copy alone and
+ * reports it.  The module calls _collect at the start of a forward and _enqueue behind it: an out-of-range tap of
+ * step i is raised at step i+1 (reference: assert at step i, qpnet.py:294), and no step is serialised for it. */
+int qpn_train_status_enqueue(qpn_handle* h, void* stream);
+int qpn_train_status_collect(qpn_handle* h);
+
 /* torch.nn.CrossEntropyLoss() (mean) on the logits above and, optionally, its gradient
  * (reference src/bin/qpnet_train.py:430,526-528; a target outside [0, n_quantize) is clamped and flagged: qpn_train_status
  * returns QPN_ERANGE, the reference asserts at :525).  d_targets is the (B x tgt_stride) int64 target

@@ -27,6 +27,7 @@ struct TrainState {
     float* d_ws; size_t ws_cap;               // one arena, carved per call
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
+    int* h_status_pinned; hipEvent_t ev_status; bool status_pending;      // qpn_train_status_enqueue / _collect: the deferred check
     bool fwd_valid;
     bool loss_clear;                          // the loss accumulator is zero (cleared by the forward's refresh kernel, consumed by one CE call)
     bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
@@ -283,6 +284,9 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
     QPN_HIP(hipMemset(t->d_status, 0, 64));
+    t->h_status_pinned = nullptr; t->ev_status = nullptr; t->status_pending = false;
+    QPN_HIP(hipHostMalloc((void**)&t->h_status_pinned, 64, hipHostMallocDefault));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_status, hipEventDisableTiming));
     QPN_HIP(hipMalloc(&t->d_loss, 64 * sizeof(double)));
     if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -323,6 +327,8 @@ void qpn_train_destroy(TrainState* t) {
     if (!t) return;
     void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
+    if (t->ev_status) (void)hipEventDestroy(t->ev_status);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -454,6 +460,7 @@ extern "C" int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream_) {
     return QPN_OK;
 }
 
+static int status_to_rc(int st);
 extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!h->train) { qpn_set_error("no training call yet"); return QPN_ESTATE; }
@@ -461,9 +468,38 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) QPN_HIP(hipMemset(h->train->d_status, 0, sizeof(int)));          // sticky until read: reported once
+    h->train->status_pending = false;
+    return status_to_rc(st);
+}
+
+static int status_to_rc(int st) {
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;
+}
+
+// The same check without draining the stream: _enqueue copies the (sticky) status word to pinned memory behind the work
+// enqueued so far and returns; _collect -- typically at the start of the NEXT forward -- waits for that copy only (long done)
+// and reports it.  An out-of-range tap / target of step i is then raised at step i+1 instead of serialising every step.
+extern "C" int qpn_train_status_enqueue(qpn_handle* h, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train) { qpn_set_error("no training call yet"); return QPN_ESTATE; }
+    TrainState* t = h->train;
+    if (t->status_pending) { rc = qpn_train_status_collect(h); if (rc) return rc; }
+    QPN_HIP(hipMemcpyAsync(t->h_status_pinned, t->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    QPN_HIP(hipEventRecord(t->ev_status, (hipStream_t)stream_));
+    t->status_pending = true;
+    return QPN_OK;
+}
+extern "C" int qpn_train_status_collect(qpn_handle* h) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train || !h->train->status_pending) return QPN_OK;
+    TrainState* t = h->train;
+    QPN_HIP(hipEventSynchronize(t->ev_status));
+    t->status_pending = false;
+    const int st = *t->h_status_pinned;
+    if (st) QPN_HIP(hipMemset(t->d_status, 0, sizeof(int)));          // sticky until read: reported once
+    return status_to_rc(st);
 }
 
 extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,

@@ -78,9 +78,12 @@ class QPNetFunction(torch.autograd.Function):
         logits = torch.empty((B, BL, model.n_quantize), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
+            # the reference asserts on the gather bounds inside forward (qpnet.py:294); here the device-side check of the
+            # PREVIOUS forward is collected (no stream drain) and this one's is enqueued behind the kernels: raised one call late
+            _lib.check(L.qpn_train_status_collect(hd))
             _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                            x.data_ptr(), h.data_ptr(), d.data_ptr(), logits.data_ptr(), stream))
-            _lib.check(L.qpn_train_status(hd, stream))       # reference asserts on the gather bounds (qpnet.py:294)
+            _lib.check(L.qpn_train_status_enqueue(hd, stream))
         ctx.model = model
         ctx.generation = int(L.qpn_train_generation(hd))
         ctx.keep = (x, h, d)                                  # inputs must outlive backward (the workspace points into them)
@@ -105,14 +108,34 @@ class QPNetFunction(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(_split_like(model, g))
 
 
+def forward_maxd(model, T, F, Td, BL, dilated_factors):
+    """ceil(max d) as QPNet.forward needs it (reference qpnet.py:254-262: it sets the receptive field RF = RF_A * maxd +
+    RF_F + 1 and the chunk's last RF + BL samples are used) WITHOUT reading the factors back from the device.
+
+    The largest maxd the chunk's shapes admit is used instead: RF_A * maxd + RF_F + 1 + BL <= min(T, Td + 1, F * U + 1).  Any
+    maxd >= the true ceil(max d) gives the same logits -- the extra leading rows are context the last BL outputs do not see,
+    and the pitch taps are positions counted from the END of the chunk -- while a true maximum that does NOT fit the chunk
+    is what the reference's gather assert (qpnet.py:294) catches; here the device-side bound check reports it.  The
+    reference trainer cuts chunks of exactly RF + BL samples (qpnet_train.py:268-284), for which this IS ceil(max d).
+    `model.read_back_maxd = True` restores the device read-back (one stream synchronisation per forward)."""
+    recA, recF = model.receptiveA_field, model.receptiveF_field
+    if getattr(model, "read_back_maxd", False) or recA <= 0:
+        return int(torch.max(dilated_factors.ceil()))
+    U = model.upsampling_factor
+    avail = min(int(T), int(Td) + 1, (int(F) * U if U > 0 else int(F)) + 1)
+    return max((avail - recF - 1 - int(BL)) // recA, 1)
+
+
 def qpnet_forward(model, x, h, dilated_factors, blength):
     """QPNet.forward (reference qpnet.py:239-262 for the argument handling)."""
     dev = x.device
     if dev.type != "cuda":
         raise RuntimeError("qpnet_amd.QPNet runs on an AMD GPU only (tensors are on %s); there is no CPU fallback" % dev)
-    assert torch.all(blength == blength[0])
-    BL = int(blength[0])
-    maxd = int(torch.max(dilated_factors.ceil()))
+    # (one read-back when blength lives on the device, as in the reference trainer; a host tensor / array costs nothing)
+    bl_host = blength.tolist() if hasattr(blength, "tolist") else list(blength)
+    assert all(v == bl_host[0] for v in bl_host)
+    BL = int(bl_host[0])
+    maxd = forward_maxd(model, x.shape[1], h.shape[2], dilated_factors.shape[1], BL, dilated_factors)
     x = x.to(dev, torch.int64).contiguous()
     h = h.to(dev, torch.float32).contiguous()
     d = dilated_factors.to(dev, torch.float32).contiguous()

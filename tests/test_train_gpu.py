@@ -498,3 +498,50 @@ def test_fused_forward_loss_equals_forward_then_ce(cfgname, cuda, monkeypatch):
     _lib.check(L.qpn_train_forward_loss(*args, tt.data_ptr(), tt.shape[1], lg2.data_ptr(), 0, dl2.data_ptr(), stream))
     _lib.check(L.qpn_train_loss(hd, C.byref(l1), stream))
     assert torch.equal(dl2, dl0) and torch.equal(lg2, lg0) and abs(l0.value - l1.value) < 1e-12
+
+
+def test_forward_needs_no_maxd_read_back(cuda):
+    """QPNet.forward derives maxd from the chunk's SHAPES (train.forward_maxd) instead of reading ceil(max d) back from the
+    device.  A chunk that is longer than RF + batch_length (here: a smaller batch_length on the same chunk) makes that bound
+    larger than the true ceil(max d): the logits must not change (extra leading context only)."""
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import forward_maxd
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 41, 30000)
+    xt, ht, dt, _ = _to(cuda, x, h, d, b)
+    b2 = torch.tensor([int(b[0]) - 137])                       # host tensor: no read-back at all
+    true_maxd = int(np.ceil(d).max())
+    # (synth.train_inputs sizes the chunk for the largest factor of the whole utterance: the bound may already exceed this chunk's own)
+    assert forward_maxd(m, x.shape[1], h.shape[2], d.shape[1], int(b[0]), dt) >= true_maxd
+    assert forward_maxd(m, x.shape[1], h.shape[2], d.shape[1], int(b2[0]), dt) > true_maxd + 30
+    with torch.no_grad():
+        lg_bound = m(xt, ht, dt, b2).cpu().numpy()
+        m.read_back_maxd = True
+        lg_exact = m(xt, ht, dt, b2).cpu().numpy()
+        m.read_back_maxd = False
+        full = m(xt, ht, dt, torch.from_numpy(b)).cpu().numpy()
+    np.testing.assert_allclose(lg_bound, lg_exact, atol=1e-6, rtol=0)
+    np.testing.assert_allclose(lg_bound, full[:, 137:], atol=1e-6, rtol=0)      # the last rows of the longer window are the same rows
+
+
+def test_forward_status_is_raised_one_call_late(cuda):
+    """the gather-bounds check of forward i (reference: assert inside forward, qpnet.py:294) is collected without a stream
+    drain at forward i+1 (qpn_train_status_enqueue / _collect)."""
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 41, 30000)
+    xt, ht, dt, bt = _to(cuda, x, h, d, b)
+    bad = dt * 40.0                                               # taps far outside the chunk
+    with torch.no_grad():
+        m(xt, ht, bad, torch.from_numpy(b))                       # returns: nothing has been read back yet
+        with pytest.raises(_lib.QpnError) as e:
+            m(xt, ht, dt, torch.from_numpy(b))
+        assert e.value.code == -4
+        lg = m(xt, ht, dt, torch.from_numpy(b))                   # reported once; the module keeps working
+        m(xt, ht, dt, torch.from_numpy(b))
+    assert np.isfinite(lg.cpu().numpy()).all()
