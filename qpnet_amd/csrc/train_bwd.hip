@@ -948,6 +948,26 @@ __global__ void k_reduce_grad(const float* __restrict__ slab, const int* __restr
     g[i] = a * scale;
 }
 
+// The same reduction walked in SLAB order: a wave reads 64 consecutive floats of each partial slab (the flat order is a
+// permutation of it -- transposed blocks, interleaved taps -- so the gather above touches scattered 4-byte words of 64 slabs),
+// and the sum goes to the parameter(s) it feeds; entries nothing feeds are zeroed, the trailer appended.
+__global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __restrict__ gdst, const int* __restrict__ gdst_list, const int* __restrict__ gzero, int n_gzero,
+                                int nch, int gstage, int64_t n, float* __restrict__ g, float scale, int append_scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < gstage) {
+        const int k0 = gdst[i], k1 = gdst[i + 1];
+        if (k0 == k1) return;                                // padding of the slab layout
+        float a = 0.f;
+        for (int c = 0; c < nch; ++c) a += slab[(size_t)c * gstage + i];
+        a *= scale;
+        for (int k = k0; k < k1; ++k) g[gdst_list[k]] = a;
+        return;
+    }
+    const int64_t j = i - gstage;
+    if (j < n_gzero) g[gzero[j]] = 0.f;
+    else if (append_scale && j < n_gzero + 4) g[n + (j - n_gzero)] = j == n_gzero ? scale : 0.f;
+}
+
 // causal conv weight grad: dW[c][q][tap] = sum over rows whose sample == q; LDS table per channel block
 __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, int rows_per_wg) {
     extern __shared__ float tab[];                 // [2][Q][CB]
@@ -1075,6 +1095,10 @@ void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t st
 // contraction owns it, upsampling kernel)
 int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
+    if (bw.gdst && !getenv("QPN_REDUCE_FLAT_ORDER"))
+        hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + bw.n_gzero + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
+                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
+    else
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
     {
         const int64_t total = (int64_t)B * N1;

@@ -70,6 +70,8 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     float* slab;                      // [NCH][gstage] split-time partial weight grads
     const int* gsrc;                  // [n_params] gather map flat-grad <- slab space (-1: owned by a special kernel)
     const int* gsrc2;                 // second source (adaptive conv biases share one gradient), -1 if none
+    const int* gdst; const int* gdst_list;   // inverse map in CSR form: slab element s feeds flat-grad entries gdst_list[gdst[s] .. gdst[s+1])
+    const int* gzero; int n_gzero;    // flat-grad entries no slab element feeds (written by their own kernels afterwards): zeroed by the reduction
     int nch, gstage;
     int64_t n_params;
     // slab offsets (floats) of every weight-grad block

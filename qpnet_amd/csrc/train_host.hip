@@ -20,7 +20,7 @@ struct TrainState {
     std::vector<int> h_bstart, h_blist;       // CSR of the packed biases
     std::vector<int> h_gsrc, h_gsrc2;
     int* d_wmap; float* d_wp; int* d_bstart; int* d_blist; float* d_bp; int n_bias;
-    int* d_gsrc; int* d_gsrc2;
+    int* d_gsrc; int* d_gsrc2; int* d_gdst; int* d_gdst_list; int* d_gzero; int n_gzero;
     TrainParams tp;                           // template with block offsets filled in
     TrainBwd bw;
     // workspaces (grow only)
@@ -144,6 +144,7 @@ static int train_init(qpn_handle* h) {
     TrainState* t = new TrainState();
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
+    t->d_gdst = t->d_gdst_list = t->d_gzero = nullptr; t->n_gzero = 0;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
@@ -293,6 +294,22 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_gsrc2, gs2.data(), gs2.size() * sizeof(int), hipMemcpyHostToDevice));
+    {   // inverse of gsrc for the slab-order reduction, CSR: a slab element feeds one parameter, or several (a gate's conv / aux /
+        // past-tap conv biases share one gradient, every layer's skip bias shares one); entries nothing feeds are listed for zeroing
+        std::vector<int> start((size_t)go + 1, 0), list, gz;
+        for (int64_t i = 0; i < g.n_params; ++i) { if (gs[i] >= 0) ++start[(size_t)gs[i] + 1]; else gz.push_back((int)i); }
+        for (int k = 0; k < go; ++k) start[(size_t)k + 1] += start[k];
+        list.resize((size_t)start[go] + 1);
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < g.n_params; ++i) if (gs[i] >= 0) list[(size_t)fill[gs[i]]++] = (int)i;
+        QPN_HIP(hipMalloc(&t->d_gdst, start.size() * sizeof(int)));
+        QPN_HIP(hipMemcpy(t->d_gdst, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+        QPN_HIP(hipMalloc(&t->d_gdst_list, list.size() * sizeof(int)));
+        QPN_HIP(hipMemcpy(t->d_gdst_list, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
+        t->n_gzero = (int)gz.size();
+        QPN_HIP(hipMalloc(&t->d_gzero, (gz.size() + 1) * sizeof(int)));
+        if (!gz.empty()) QPN_HIP(hipMemcpy(t->d_gzero, gz.data(), gz.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     if (t->use_gemm) {
         QPN_HIP(hipMalloc(&t->d_gmap, t->h_gmap.size() * sizeof(int)));
         QPN_HIP(hipMalloc(&t->d_gwp, t->h_gmap.size() * sizeof(float)));
@@ -325,7 +342,7 @@ static int train_init(qpn_handle* h) {
 
 void qpn_train_destroy(TrainState* t) {
     if (!t) return;
-    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct};
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
     if (t->ev_status) (void)hipEventDestroy(t->ev_status);
@@ -533,7 +550,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     if (!d_dlogits || !d_flatgrad) { qpn_set_error("bad train_backward arguments"); return QPN_EINVAL; }
     TrainState* t = h->train;
     TrainBwd& bw = t->bw;
-    bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2;
+    bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, (hipStream_t)stream_);
