@@ -85,7 +85,7 @@ def max_over_ranks(v, world, dev):
 
 def measured_traffic():
     """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (committed under profiles/)."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -429,17 +429,36 @@ def run_default_geometry(local):
     del tr, bt
     m = m.eval()
     dec = {}
+    FR = 500                                   # 2.5 s utterances: 54 999 samples each
+    Lz = len(cfg.dilationsF) + len(cfg.dilationsA)
+    n_edges = 2 * Lz + 3                       # dependent all-gathers per generated sample: gate vector + block output per layer, 3 in the post-net
+    w_bytes = 4.0 * (cfg.n_params - cfg.n_quantize * cfg.n_resch * 2 + 2 * cfg.n_resch)      # weights touched per sample (two rows of the one-hot table)
+    stream_us = w_bytes / 8.6e12 * 1e6         # gathered reads from the Infinity Cache, whole chip (MI355X_MICROARCH.md: 8.6 TB/s)
+    hop_us = 0.8                               # one producer -> one consumer granule hand-off on an idle chip (same guide: handoff-1to1)
     for B in (1, 20):
-        bx, bh, bd, ns = synth.decode_batch(cfg, [(100 + b, 20, 1.0) for b in range(B)])
+        bx, bh, bd, ns = synth.decode_batch(cfg, [(100 + b, FR, 1.0) for b in range(B)])
         xb, hbt = torch.from_numpy(bx).to(dev), torch.from_numpy(bh).to(dev)
-        m.batch_fast_generate(xb, hbt, list(ns), bd, mode="argmax")
+        if B == 1:
+            wx, wh, wd, wn = synth.decode_batch(cfg, [(100, 10, 1.0)])
+            m.batch_fast_generate(torch.from_numpy(wx).to(dev), torch.from_numpy(wh).to(dev), list(wn), wd, mode="argmax")     # warm-up (allocations)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         m.batch_fast_generate(xb, hbt, list(ns), bd, mode="argmax")
         torch.cuda.synchronize(); dtd = time.perf_counter() - t0
-        dec["batch%d" % B] = {"samples_per_s": sum(ns) / dtd, "us_per_sample_per_utterance": m.last_decode_kernel_ms * 1e3 / max(ns),
-                              "workload": "%d x 20-frame utterances (%d samples each)" % (B, ns[0])}
+        us = m.last_decode_kernel_ms * 1e3 / max(ns)
+        floor = n_edges * hop_us + stream_us          # the hops are serial; at B = 1 the stream of one step has nothing else to hide behind
+        dec["batch%d" % B] = {"samples_per_s": sum(ns) / dtd, "us_per_sample_per_utterance": us, "real_time_factor": (sum(ns) / dtd / B) / 22050.0,
+                              "plan": getattr(m, "last_decode_plan", ""),
+                              "workload": "%d x %d-frame utterances (%d samples each)" % (B, FR, ns[0]),
+                              "roofline": {"bound": "latency: %d dependent all-gathers per sample + the weight stream" % n_edges,
+                                           "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance", "frac": floor / us,
+                                           "weight_stream_floor_us": stream_us, "handoff_floor_us": n_edges * hop_us,
+                                           "weights_MB_per_sample": w_bytes / 1e6,
+                                           "weight_stream_achieved_TBps": w_bytes * B / (us * 1e-6) / 1e12,
+                                           "note": "floor = (2L+3) x 0.8 us (idle one-to-one granule hand-off, the cheapest cross-CU edge on this chip) + "
+                                                   "96.6 MB / 8.6 TB/s (Infinity-Cache gather rate); at B = 20 every utterance group re-streams the weights "
+                                                   "(weight_stream_achieved_TBps is the aggregate), so the stream, not the hops, binds"}}
     dec["reference_cpu_samples_per_s"] = 40
-    dec["kernel"] = "k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= 256 whose row slices are whole tiles)"
+    dec["kernel"] = "k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= CUs whose row slices are whole tiles)"
     out["decode"] = dec
     return out
 

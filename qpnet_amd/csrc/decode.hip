@@ -964,9 +964,11 @@ static int launch_one_cu(qpn_handle* h, DecodeParams& p, int n, hipStream_t stre
     return QPN_OK;
 }
 
-// measured per-sample times of the two paper-size kernels (profiles/r02_bench_line.json): only their RATIO is used, to decide
-// whether the rows beyond one pipelined launch's capacity run beside it on one-CU kernels or as further pipelined launches
-static const double T_PIPE_US = 8.3, T_ONE_US = 14.3;
+// measured per-sample times of the two paper-size kernels, used to decide whether the rows beyond one pipelined launch's capacity run
+// beside it on one-CU kernels or as further pipelined launches: 8.3 us pipelined; one-CU rows BESIDE a full pipelined launch 14.8 us
+// for one row, 22.3 us for sixteen (they re-stream their tiles from an L2 the hand-off traffic of 240 busy CUs goes through:
+// profiles/r03_bench_line.json, larger_batches)
+static const double T_PIPE_US = 8.3, T_ONE_US = 14.3, T_ONE_PER_ROW_US = 0.5;
 
 // force_one_cu: the retry of qpn_decode_finish (a multi-workgroup launch gave up) -- one-CU kernels only
 static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
@@ -1029,7 +1031,7 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
             // (b) the longest `cap` rows pipelined, the (shorter) rest on the CUs that launch leaves free, at the same time
             const int free_cus = h->n_cus - 5 * cap, rest = B - cap;
             double t_hybrid = 1e300;
-            if (rest <= free_cus) t_hybrid = std::max(T_PIPE_US * (double)h_n_samples[order[0]], T_ONE_US * (double)h_n_samples[order[cap]]);
+            if (rest <= free_cus) t_hybrid = std::max(T_PIPE_US * (double)h_n_samples[order[0]], (T_ONE_US + T_ONE_PER_ROW_US * rest) * (double)h_n_samples[order[cap]]);
             if (t_hybrid <= t_waves) { n_pipe = cap; n_waves = 1; wave_rows = cap; }
             else { n_pipe = B; n_waves = nw; wave_rows = per; }
         }

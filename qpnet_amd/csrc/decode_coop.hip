@@ -21,8 +21,10 @@
 #include <string.h>
 
 typedef unsigned long long u64;
-#define COOP_NT 1024
-#define COOP_NW 16
+#ifndef COOP_NT
+#define COOP_NT 768      // 12 waves: 1024 threads cap the kernel at 128 registers (29 spilled, 112 bytes of scratch per lane re-read inside the
+#endif                   // per-sample loop); measured at C = 512: 8.98 / 52.9 / 81.5 k samples/s for 1 / 8 / 20 utterances vs 8.84 / 45.4 / 75.2 k (512 threads: 8.69 / 49.9 / 66.7 k)
+#define COOP_NW (COOP_NT / 64)
 #define COOP_SPIN_LIMIT (1u << 22)
 
 __device__ __forceinline__ void gr_store(u64* g, unsigned tag, float v) {

@@ -16,6 +16,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # kernel-name fragment -> (file, max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
     "k_decode_pipe": ("decode_pipe.hip", 0, 2),
+    "k_decode_coop": ("decode_coop.hip", 0, 3),             # 768 threads: three waves per SIMD, nothing in scratch memory
+    "k_layer_fwd_pILi11ELb0E": ("train_fwd.hip", 0, 2),     # persistent layer forward: two workgroups per CU, weights in registers
+    "k_post_fwd_wILi5E": ("train_fwd.hip", 0, 2),           # 80-row post-net tiles: one 512-thread workgroup per CU
+    "k_post_bwd_wILi5E": ("train_bwd.hip", 0, 2),
     "k_layer_fwdILi1E": ("train_fwd.hip", 0, 5),          # five 16-row workgroups per CU must be co-resident
     "k_post_fwdILi1E": ("train_fwd.hip", 0, 5),
     "k_layer_bwdILi1E": ("train_bwd.hip", 0, 5),

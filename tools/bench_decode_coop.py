@@ -16,7 +16,10 @@ def run(cfg, B, F, tag):
     dt = time.perf_counter() - t0
     print("%s B=%d F=%d: %.0f samples/s aggregate, %.1f us/sample/utterance (kernel %.1f ms)" % (tag, B, F, sum(ns) / dt, m.last_decode_kernel_ms * 1e3 / max(ns), m.last_decode_kernel_ms), flush=True)
 which = sys.argv[1] if len(sys.argv) > 1 else "default"
-if which == "default":
+if which == "default500":                   # the workload bench.py reports for the repo-default geometry: 500-frame (2.5 s) utterances
+    for B in (1, 20):
+        run(DEFAULT, B, 500, "default (C=512) G=auto")
+elif which == "default":
     for B in (1, 4, 8, 20):
         run(DEFAULT, B, 20, "default (C=512) G=auto")
 else:

@@ -58,6 +58,20 @@ if f and fs:
             per["train"][name]["mfma_busy_cycles_per_call"] = per_call
             per["train"][name]["avg_us"] = avg_ns[name] / 1e3
             per["train"][name]["mfma_util"] = per_call / (avg_ns[name] * 2.4 * 1024)
+# where the waves' cycles go (SQ wait / active counters), per kernel
+f = find("train_WAIT/**/*counter_collection.csv")
+if f:
+    agg = defaultdict(lambda: defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        agg[(r.get("Kernel_Name") or "").split("(")[0][:80]][r["Counter_Name"]] += float(r["Counter_Value"])
+    with open(os.path.join(dst, "%s_train_wait_pmc.txt" % tag), "w") as o:
+        o.write("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU\n")
+        o.write("  -- python3 bench.py --mode train --steps 2 --warmup 1 --no-cpu   (QPN_TRAIN_SERIAL=1); fractions of SQ_WAVE_CYCLES summed over a kernel's dispatches\n")
+        o.write("%-44s %10s %8s %8s %8s %8s %8s %8s %8s\n" % ("kernel", "wave_cyc", "wait", "waitinst", "active", "wlds", "alds", "avmem", "avalu"))
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"])[:16]:
+            w = v["SQ_WAVE_CYCLES"] or 1
+            o.write("%-44s %10.3g %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f\n" % (k[:44], w, v["SQ_WAIT_ANY"] / w, v["SQ_WAIT_INST_ANY"] / w, v["SQ_ACTIVE_INST_ANY"] / w,
+                                                                                   v["SQ_WAIT_INST_LDS"] / w, v["SQ_ACTIVE_INST_LDS"] / w, v["SQ_ACTIVE_INST_VMEM"] / w, v["SQ_ACTIVE_INST_VALU"] / w))
 json.dump(per, open(os.path.join(dst, "%s_pmc_by_kernel.json" % tag), "w"), indent=1)
 # the figures bench.py reports
 dec = [v for k, v in per.get("decode", {}).items() if "k_decode" in k]
