@@ -833,7 +833,7 @@ static int build_program(qpn_handle* h) {
 
 bool qpn_pipe_supported(const Geom& g);
 int qpn_pipe_rows_resident(int n_cus);
-int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream);
+int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, int groups, hipStream_t stream);
 int qpn_coop_group_size(const Geom& g, int limit);
 int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
 
@@ -861,6 +861,8 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     QPN_HIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     if (h->n_cus < 1) h->n_cus = 1;
     h->pipe_rows = qpn_pipe_rows_resident(h->n_cus);
+    h->pipe_nu = 3;                                      // most utterances a five-role group steps alternately when the batch exceeds the groups
+    if (const char* e = getenv("QPN_PIPE_NU")) { const int v = atoi(e); if (v >= 2 && v <= 3) h->pipe_nu = v; }
     *out = h;
     return QPN_OK;
 }
@@ -1021,19 +1023,23 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     const bool pipe_ok = !coopG && !force_one_cu && (epipe ? atoi(epipe) != 0 : true) && qpn_pipe_supported(g) && !getenv("QPN_DECODE_GENERIC") && h->pipe_rows >= 1;
     int n_pipe = 0, n_waves = 0, wave_rows = 0;
     if (pipe_ok) {
-        const int cap = h->pipe_rows;
+        const int cap = h->pipe_rows;                    // five-role groups one launch holds resident
+        const bool hybrid_knob = getenv("QPN_DECODE_HYBRID") != nullptr;      // dev aid: rows beyond `cap` on one-CU kernels beside the launch (round-3 first form)
         if (B <= cap) { n_pipe = B; n_waves = 1; wave_rows = B; }
+        else if (hybrid_knob && B - cap <= h->n_cus - 5 * cap) { n_pipe = cap; n_waves = 1; wave_rows = cap; }
         else {
-            // (a) every row pipelined, in ceil(B / cap) waves of equal size: time = sum over waves of the wave's longest row
-            const int nw = (B + cap - 1) / cap, per = (B + nw - 1) / nw;
-            double t_waves = 0.0;
-            for (int w = 0; w < nw; ++w) t_waves += T_PIPE_US * (double)h_n_samples[order[std::min(w * per, B - 1)]];
-            // (b) the longest `cap` rows pipelined, the (shorter) rest on the CUs that launch leaves free, at the same time
-            const int free_cus = h->n_cus - 5 * cap, rest = B - cap;
-            double t_hybrid = 1e300;
-            if (rest <= free_cus) t_hybrid = std::max(T_PIPE_US * (double)h_n_samples[order[0]], (T_ONE_US + T_ONE_PER_ROW_US * rest) * (double)h_n_samples[order[cap]]);
-            if (t_hybrid <= t_waves) { n_pipe = cap; n_waves = 1; wave_rows = cap; }
-            else { n_pipe = B; n_waves = nw; wave_rows = per; }
+            // a group takes a second (third) utterance, stepped alternately with the first (a role is busy ~2 us of an utterance's ~8 us
+            // step): up to pipe_nu * cap rows per launch at 10 us (12 us) per step instead of 8.4; beyond that, equal-sized launches
+            // measured step times with 1 / 2 / 3 utterances per group: 8.4 / 10.0 / 15.3 us (profiles/r03_decode_batches.txt); the plan with
+            // the smallest (launches x step time) wins -- three per group only pays where it saves a launch (97..144 rows on 48 groups)
+            static const double step_us[4] = {0.0, 8.4, 10.0, 15.3};
+            double best = 1e300;
+            for (int nu_max = 2; nu_max <= h->pipe_nu; ++nu_max) {
+                const int nw = (B + nu_max * cap - 1) / (nu_max * cap), per = (B + nw - 1) / nw, nu = (per + cap - 1) / cap;
+                const double tt = nw * step_us[nu];
+                if (tt < best) { best = tt; n_waves = nw; wave_rows = per; }
+            }
+            n_pipe = B;
         }
     }
     const int n_one = coopG ? 0 : B - n_pipe;
@@ -1092,7 +1098,7 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
             const int first = w * wave_rows, n = std::min(wave_rows, n_pipe - first);
             if (n <= 0) break;
             DecodeParams pw = p; pw.utts = h->d_utts + first;
-            rc = qpn_launch_decode_pipe(h, pw, n, stream); if (rc) return rc;
+            rc = qpn_launch_decode_pipe(h, pw, n, std::min(n, h->pipe_rows), stream); if (rc) return rc;
         }
         if (n_one > 0) {
             DecodeParams po = p; po.utts = h->d_utts + n_pipe;
@@ -1102,7 +1108,8 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
             QPN_HIP(hipEventRecord(h->dec_join, h->dec_side));
             QPN_HIP(hipStreamWaitEvent(stream, h->dec_join, 0));
         }
-        snprintf(plan, sizeof(plan), "pipe rows=%d waves=%d x %d; one-cu rows=%d%s", n_pipe, n_waves, wave_rows, n_one, beside ? " (beside)" : "");
+        snprintf(plan, sizeof(plan), "pipe rows=%d waves=%d x %d (%d per group); one-cu rows=%d%s", n_pipe, n_waves, wave_rows,
+                 n_pipe > 0 ? (wave_rows + h->pipe_rows - 1) / h->pipe_rows : 1, n_one, beside ? " (beside)" : "");
         h->call.multi_wg = n_pipe > 0 ? 1 : 0; h->call.coopG = 0;
     }
     h->plan = plan;

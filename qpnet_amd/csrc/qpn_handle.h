@@ -28,7 +28,8 @@ struct qpn_handle {
     bool pending;
     // device facts queried at qpn_create (nothing assumes a 256-CU chip that is all ours)
     int n_cus;                       // hipDeviceAttributeMultiprocessorCount
-    int pipe_rows;                   // utterances one pipelined launch can hold resident (5 workgroups each), a multiple of 8
+    int pipe_rows;                   // five-role groups one pipelined launch can hold resident (5 workgroups each), a multiple of 8
+    int pipe_nu;                     // utterances per group when the batch exceeds them (1..3)
     // pinned staging of the utterance descriptors (enqueue does not synchronise) + the side stream of a hybrid launch
     UttDesc* h_utts_pinned; size_t h_utts_cap;
     hipStream_t dec_side; hipEvent_t dec_fork, dec_join;

@@ -373,25 +373,30 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 // ------------------------------------------------------------------------------------------ layer backward, persistent form (n_resch = 64)
 // Same arithmetic as k_layer_bwd, organised like k_layer_fwd_p (train_fwd.hip): 2 workgroups per CU walk contiguous ranges of
 // 16-row tiles with the layer's TRANSPOSED weights resident in registers -- wave w owns column tile w of dg = dXout . Wr and
-// column tiles {w, w + 4, w + 8} of d[x_cur | x_past | aux] = dZ . W1 (4 + 3 x 8 fragment float4s per lane) -- and the next
-// tile's rows (dXout parts, saved gate halves, skip-path gate grads) and scatter targets in flight under the current tile.
-template <int NTK>      // NTK = Ktp / 16 column tiles of the input gradient (11 for n_resch 64, n_aux 39)
-__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles) {     // flags: bit 0 last layer, bit 1 XCD swizzle
-    constexpr int C = 64, C4 = C / 4, NIT = (16 * C4) / 256;       // one float4 item per thread and array
-    constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2;
+// column tiles {w, w + 4, w + 8} of d[x_cur | x_past | aux] = dZ . W1 (4 + 3 x 8 fragment float4s per lane) -- the next tile's
+// rows (dXout parts, saved gate halves, skip-path gate grads) and scatter targets in flight under the current tile, a branch-free
+// tile loop (clamped loads, out-of-range stores redirected to a scratch row: exact s_waitcnt vmcnt counts), LDS-only barriers,
+// all fragment reads ahead of their MFMAs.  Both results leave through LDS as whole rows: dZ (512 B rows), the own-row input
+// gradient (+ residual path), the pitch-tap part as one 256-byte row per tap row -- a plain store for the fixed blocks (unique
+// writer), ONE full-row float-atomic instruction per row for the adaptive blocks (the accumulator layout gave 64-byte strips
+// of four different rows per instruction) -- and the aux columns as row-contiguous atomics.
+template <int NTK, bool LAST>      // NTK = Ktp / 16 column tiles of the input gradient (11 for n_resch 64, n_aux 39)
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles, float* dummy) {     // flags: bit 1 XCD swizzle
+    constexpr int C = 64, C4 = C / 4;
+    constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     constexpr int NJ = (NTK + 3) / 4;                              // column tiles of the second contraction per wave
-    static_assert(NIT == 1, "16 rows x 16 float4 = one item per thread");
     extern __shared__ float sm[];
-    // per buffer: Dx | Sg | Th | Dg, [16][ldx] each; then Dz [16][ldz]
-    float* Dz = sm + 8 * 16 * ldx;                               // staging buffers: sm, sm + 4 * 16 * ldx
+    // two staging buffers {Dx | Sg | Th | Dg}, [16][ldx] each; Dz [16][ldz]; Os [16][ldo] (the second contraction's outputs)
+    float* Dz = sm + 8 * 16 * ldx;
+    float* Os = Dz + 16 * ldz;
     const TrLayer ly = p.layers[l];
-    const int last = flags & 1, Ap = p.Ap, N1 = p.N1;
+    const int Ap = p.Ap, N1 = p.N1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
-    const int g = tr_xcd_tile(blockIdx.x, gridDim.x, flags & 2), G = gridDim.x;
-    const int base = tiles / G, rem = tiles - base * G;
-    const int t_first = g * base + (g < rem ? g : rem), t_count = base + (g < rem ? 1 : 0);
+    int t_first, t_count;
+    tr_tile_range(blockIdx.x, gridDim.x, tiles, flags & 2, t_first, t_count);
     if (t_count <= 0) return;
+    const int t_last = t_first + t_count - 1;
     const size_t rb = (size_t)b * N1;
     const size_t nDX = (size_t)p.B * N1 * C;
     const float* DAin = bw.DXA[0] + (size_t)(l + 1) * nDX + rb * C; const float* DBin = bw.DXB[0] + (size_t)(l + 1) * nDX + rb * C;
@@ -407,41 +412,45 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     const float4* Wrt = p.wp + ly.wrt_f4; const float4* W1t = p.wp + ly.w1t_f4;
     float4 wr[4], w1[NJ][8];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) wr[ks] = last ? make_float4(0.f, 0.f, 0.f, 0.f) : Wrt[((size_t)ks * 4 + wave) * 64 + lane];
+    for (int ks = 0; ks < 4; ++ks) wr[ks] = LAST ? make_float4(0.f, 0.f, 0.f, 0.f) : Wrt[((size_t)ks * 4 + wave) * 64 + lane];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int nt = wave + 4 * j < NTK ? wave + 4 * j : NTK - 1;          // (a wave without a j-th tile keeps a copy it never uses)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) w1[j][ks] = W1t[((size_t)ks * NTK + nt) * 64 + lane];
     }
-    // ---- staging: thread -> (row, 4 columns) of the four [16][C] arrays
-    const int srow = tid / C4, scol = (tid - srow * C4) * 4;
+    // ---- staging in: thread -> (row srow, 16-byte piece sc4) of the four [16][C] arrays
+    const int srow = tid >> 4, sc4 = tid & 15;
     float4 ra, rb2, rsg, rth, rdg;
     auto load_rows = [&](int t) {
         const int n = ly.s_out + t * 16 + srow;
         const int nn = n < N1 ? n : N1 - 1;
-        const size_t o = (size_t)nn * C + scol;
+        const size_t o = (size_t)nn * C + 4 * sc4;
         ra = *(const float4*)(DAin + o); rb2 = *(const float4*)(DBin + o);          // (rows of the last layer: finite garbage, not used)
         rsg = *(const float4*)(SG + o); rth = *(const float4*)(TH + o);
         const int nw = nn >= win0 ? nn - win0 : 0;
-        rdg = *(const float4*)(DGS + (size_t)nw * p.LC + scol);
+        rdg = *(const float4*)(DGS + (size_t)nw * p.LC + 4 * sc4);
     };
     auto store_rows = [&](int t, float* B) {
         const int n = ly.s_out + t * 16 + srow;
         const bool in = n < N1;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 dx = (in && !last) ? make_float4(ra.x + rb2.x, ra.y + rb2.y, ra.z + rb2.z, ra.w + rb2.w) : z;
+        const float4 dx = (in && !LAST) ? make_float4(ra.x + rb2.x, ra.y + rb2.y, ra.z + rb2.z, ra.w + rb2.w) : z;
         const float4 sg = in ? rsg : z, th = in ? rth : z, dg = (in && n >= win0) ? rdg : z;
-        float* d0 = B + (size_t)srow * ldx + scol;
+        float* d0 = B + (size_t)srow * ldx + 4 * sc4;
         *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
         float* d1 = d0 + 16 * ldx; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
         float* d2 = d1 + 16 * ldx; *(float2*)d2 = make_float2(th.x, th.y); *(float2*)(d2 + 2) = make_float2(th.z, th.w);
         float* d3 = d2 + 16 * ldx; *(float2*)d3 = make_float2(dg.x, dg.y); *(float2*)(d3 + 2) = make_float2(dg.z, dg.w);
     };
+    // ---- staging out.  dZ: thread -> 8-byte pieces (rows zrow, zrow + 4, + 8, + 12; column zc2) of the [16][128] tile;
+    //      input gradient: wave w owns rows 4w .. 4w+3, lane = channel: one 256-byte row per instruction
+    const int zrow = tid >> 6, zc2 = (tid & 63) * 2;
+    float* const dmy = dummy + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * 128;       // two 512-byte scratch rows per workgroup
     int tprow[4], tpnext[4];
     auto load_taps = [&](int t, int (&tp)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * (lane >> 4) + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
+        for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * wave + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
     };
     load_rows(t_first);
     load_taps(t_first, tprow);
@@ -451,70 +460,89 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     for (int ti = 0; ti < t_count; ++ti) {
         const int t = t_first + ti, n0 = ly.s_out + t * 16;
         float* Dx = sm + (ti & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
-        if (ti + 1 < t_count) { load_rows(t + 1); load_taps(t + 1, tpnext); }
-        TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz free (readers: previous trip's second contraction)
+        { const int tn = t + 1 < t_last ? t + 1 : t_last; load_rows(tn); load_taps(tn, tpnext); }      // (past the range: a harmless reload)
+        TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz / Os free (readers: previous trip)
         // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
-        f32x4 a0 = (f32x4){0, 0, 0, 0};
-        if (!last) {
+        float xa[4][4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float* ap = Dx + (size_t)arow * ldx + 16 * ks + ak;
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], wr[ks].x, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4], wr[ks].y, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[8], wr[ks].z, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[12], wr[ks].w, a0, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) { const float* ap = Dx + (size_t)arow * ldx + 16 * ks + ak; xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12]; }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+        if (!LAST) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], wr[ks].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][0], wr[ks + 1].x, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], wr[ks].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][1], wr[ks + 1].y, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], wr[ks].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][2], wr[ks + 1].z, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], wr[ks].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][3], wr[ks + 1].w, a1, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = 4 * (lane >> 4) + i, n = n0 + r;
-            const float dg = a0[i] + Dg[(size_t)r * ldx + c];
+            const int r = 4 * (lane >> 4) + i;
+            const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
             const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-            const float dzs = dg * th * sg * (1.0f - sg);
-            const float dzt = dg * sg * (1.0f - th * th);
-            if (n < N1) { DZg[(size_t)n * 2 * C + c] = dzs; DZg[(size_t)n * 2 * C + C + c] = dzt; }
-            Dz[(size_t)r * ldz + c] = dzs; Dz[(size_t)r * ldz + C + c] = dzt;
+            Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
+            Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
         }
         TR_LDS_BARRIER();
         // ---- d[x_cur | x_past | aux] = dZ . W1
+        float za[8][4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { const float* zp = Dz + (size_t)arow * ldz + 16 * ks + ak; za[ks][0] = zp[0]; za[ks][1] = zp[4]; za[ks][2] = zp[8]; za[ks][3] = zp[12]; }
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const float* zp = Dz + (size_t)arow * ldz + 16 * ks + ak;
-            const float z0 = zp[0], z1 = zp[4], z2 = zp[8], z3 = zp[12];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z0, w1[j][ks].x, acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][0], w1[j][ks].x, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z1, w1[j][ks].y, acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][1], w1[j][ks].y, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z2, w1[j][ks].z, acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][2], w1[j][ks].z, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(z3, w1[j][ks].w, acc[j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][3], w1[j][ks].w, acc[j], 0, 0, 0);
+        }
+        {   // dZ rows to global (512 B each), under the contraction: thread -> rows zrow + 4k, 8-byte piece zc2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = zrow + 4 * k;
+                float* d = DZg + (size_t)(n0 + r) * 2 * C + zc2;
+                d = n0 + r < N1 ? d : dmy + zc2;
+                *(float2*)d = *(const float2*)(Dz + (size_t)r * ldz + zc2);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int nt = wave + 4 * j;
             if (nt >= NTK) continue;                               // wave-uniform
-            const int k = 16 * nt + (lane & 15);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * (lane >> 4) + i, n = n0 + r;
-                if (n >= N1) continue;
-                const float v = acc[j][i];
-                if (k < C) DAout[(size_t)n * C + k] = v + Dx[(size_t)r * ldx + k];              // + residual path
-                else if (k < 2 * C) {
-                    if (ly.adaptive) atomicAdd(&DBout[(size_t)tprow[i] * C + (k - C)], v);      // gather backward (collisions)
-                    else DBout[(size_t)tprow[i] * C + (k - C)] = v;                             // unique writer
-                } else if (k < 2 * C + Ap) atomicAdd(&DH[(size_t)n * Ap + (k - 2 * C)], v);     // unique writer per layer, layers in order
+            for (int i = 0; i < 4; ++i) Os[(size_t)(4 * (lane >> 4) + i) * ldo + 16 * nt + (lane & 15)] = acc[j][i];
+        }
+        TR_LDS_BARRIER();
+        // ---- outputs as whole rows: wave w owns rows 4w .. 4w+3, lane = channel
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * wave + i, n = n0 + r;
+            const bool in = n < N1;
+            const float own = Os[(size_t)r * ldo + lane] + Dx[(size_t)r * ldx + lane];                 // + residual path
+            float* da = DAout + (size_t)n * C + lane;
+            *(in ? da : dmy + lane) = own;
+            const float past = Os[(size_t)r * ldo + C + lane];
+            float* db = DBout + (size_t)tprow[i] * C + lane;
+            db = in ? db : dmy + 128 + lane;
+            if (ly.adaptive) atomicAdd(db, past);                                                       // gather backward (collisions)
+            else *db = past;                                                                            // unique writer
+            if (lane < Ap) {                                                                            // (Ap <= 64)
+                float* dh = DH + (size_t)n * Ap + lane;
+                atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);               // unique writer per layer, layers in order
             }
         }
-        if (ti + 1 < t_count) {
-            store_rows(t + 1, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
+        store_rows(t + 1 < t_last ? t + 1 : t_last, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
-        }
+        for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
     }
 }
 
@@ -1236,17 +1264,18 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     const int cut_row = split ? tr_split_cut(p) : 0;
     const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
     if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
-    // (opt-in, QPN_LAYER_BWD_PERSIST=1: first form measured 0.205 vs 0.197 ms per step for the tile-per-workgroup launches)
-    const bool persist = C == 64 && p.Ktp == 176 && !split && getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 1;
-    const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
+    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && !split && !(getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 0);
+    const int wg_per_cu = getenv("QPN_LAYER_BWD_WGS") ? atoi(getenv("QPN_LAYER_BWD_WGS")) : 2;
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
         if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)
             const int tiles = (rows + 15) / 16;
             int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
-            const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C)) * sizeof(float);
-            hipLaunchKernelGGL((k_layer_bwd_p<11>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, (l == L - 1 ? 1 : 0) | (swz ? 2 : 0), tiles);
+            const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(176)) * sizeof(float);
+            (void)hipFuncSetAttribute(l == L - 1 ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
         } else if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
             const size_t lds1 = lds_layer / MT;
             if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);

@@ -222,20 +222,6 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
 #else
 #define FWDP_STAMP(i) do { } while (0)
 #endif
-// tile range of workgroup `orig` (hardware id) of a grid of G over `tiles` tiles: ranges are contiguous in the XCD-aware order
-// g = tr_xcd_tile(orig) and as even as possible; the `rem` workgroups that take one tile more are the ones with the LOWEST
-// hardware ids -- with two workgroups per CU dealt in id order, a CU then gets (base + 1) + base tiles rather than 2 (base + 1)
-__device__ __forceinline__ void tr_tile_range(int orig, int G, int tiles, int swz, int& t_first, int& t_count) {
-    const int base = tiles / G, rem = tiles - base * G;
-    if (!swz || G <= 8) { t_first = orig * base + (orig < rem ? orig : rem); t_count = base + (orig < rem ? 1 : 0); return; }
-    const int q = G / 8, r = G % 8, xcd = orig % 8, j = orig / 8;
-    const int g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;          // = tr_xcd_tile(orig, G, 1)
-    int before = 0;                                                                       // workgroups with an extra tile among g' < g
-    for (int x = 0; x < xcd; ++x) before += rem > x ? (rem - x + 7) / 8 : 0;
-    const int mine = rem > xcd ? (rem - xcd + 7) / 8 : 0;
-    before += j < mine ? j : mine;
-    t_first = g * base + before; t_count = base + (orig < rem ? 1 : 0);
-}
 template <int KS, bool LAST>
 __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy, long long* stamps) {     // flags: bit 1 XCD swizzle
     constexpr int C = 64, Ktp = 16 * KS;

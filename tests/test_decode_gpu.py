@@ -431,9 +431,10 @@ def _paper_batch(B, lo=6, span=9, seed0=300):
 
 @pytest.mark.parametrize("B,mode", [(49, "argmax"), (64, "sampling"), (100, "argmax")])
 def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
-    """decode_batch_size is a free parameter of the reference (--batch_size, src/bin/qpnet_decode.py:52).  More rows than one
-    pipelined launch holds resident (48 on a 256-CU device) run as several launches / beside it on one-CU kernels; whatever
-    the plan, EVERY row equals its single-row oracle stream (sampling: the Philox key is the caller's row number)."""
+    """decode_batch_size is a free parameter of the reference (--batch_size, src/bin/qpnet_decode.py:52).  More rows than the 48
+    five-role groups a 256-CU device holds resident: groups take a second utterance, stepped alternately (and beyond 96 rows,
+    equal-sized launches); whatever the plan, EVERY row equals its single-row oracle stream (sampling: the Philox key is the
+    caller's row number)."""
     import torch
     cfg, specs = _paper_batch(B)
     flat = synth.make_weights(cfg, 13)
@@ -442,14 +443,14 @@ def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
     bx, bh, bd, ns = synth.decode_batch(cfg, specs)
     outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode=mode)
     import re
-    mt = re.match(r"pipe rows=(\d+) waves=(\d+) x (\d+); one-cu rows=(\d+)", m.last_decode_plan)
+    mt = re.match(r"pipe rows=(\d+) waves=(\d+) x (\d+) \((\d) per group\); one-cu rows=(\d+)", m.last_decode_plan)
     assert mt, m.last_decode_plan
-    n_pipe, n_waves, per, n_one = map(int, mt.groups())
-    assert n_pipe + n_one == B and n_pipe >= 48 and per <= 48 and n_waves * per >= n_pipe, m.last_decode_plan
-    if B == 49:
-        assert n_one == 1 and "(beside)" in m.last_decode_plan      # the shortest row rides on a free CU beside the 48-row launch
+    n_pipe, n_waves, per, per_group, n_one = map(int, mt.groups())
+    assert n_pipe == B and n_one == 0 and per_group == 2 and per <= 96 and n_waves * per >= n_pipe, m.last_decode_plan
+    if B in (49, 64):
+        assert n_waves == 1                                         # one launch: 48 groups, B - 48 of them with two utterances
     if B == 100:
-        assert n_one == 0 and n_waves == 3                          # 52 extra rows do not fit the CUs a 48-row launch leaves free
+        assert n_waves == 2 and per == 50
     order = np.argsort(ns, kind="stable")
     assert [len(o) for o in outs] == [ns[b] for b in order]
     maxd = int(np.ceil(np.nanmax(bd)))
@@ -460,9 +461,8 @@ def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
         np.testing.assert_array_equal(outs[k], r["samples"], err_msg="row %d (%s)" % (b, m.last_decode_plan))
 
 
-def test_equal_length_rows_beyond_capacity_run_as_equal_waves(cuda, oracle):
-    """80 rows of one length: 32 more than one launch holds and more than the 16 CUs it leaves free, so the plan is two
-    pipelined launches of 40 (equal waves: each wave's time is set by its longest row)."""
+def test_equal_length_rows_beyond_capacity_share_groups(cuda, oracle):
+    """80 rows of one length: 32 of the 48 resident groups take a second utterance (one launch)."""
     import torch
     from qpnet_amd.config import PAPER
     cfg = PAPER
@@ -471,7 +471,7 @@ def test_equal_length_rows_beyond_capacity_run_as_equal_waves(cuda, oracle):
     specs = [(500 + b % 4, 8, 1.0) for b in range(80)]
     bx, bh, bd, ns = synth.decode_batch(cfg, specs)
     outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
-    assert "pipe rows=80 waves=2 x 40; one-cu rows=0" in m.last_decode_plan, m.last_decode_plan
+    assert "pipe rows=80 waves=1 x 80 (2 per group); one-cu rows=0" in m.last_decode_plan, m.last_decode_plan
     ref = {}
     for k in range(80):
         key = specs[k][0]
