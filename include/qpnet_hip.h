@@ -74,9 +74,9 @@ int qpn_set_weights(qpn_handle* h, const float* d_flat, size_t n, void* stream);
  * QPNet.batch_fast_generate (reference src/nets/qpnet.py:314-559), all batch rows at once: persistent kernels that loop
  * over all samples of their utterances, launched once per call.  The launch plan is sized from the device's CU count
  * (hipDeviceAttributeMultiprocessorCount), nothing assumes a whole 256-CU chip:
- *   paper-size geometry   five resident workgroups per utterance (decode_pipe.hip) for up to (CUs / 40) * 8 rows per launch;
- *                         more rows run as further equal-sized launches, or -- when they are short enough -- on one-CU
- *                         kernels beside the first launch (rows are assigned longest first);
+ *   paper-size geometry   (CUs / 40) * 8 resident groups of five workgroups (decode_pipe.hip), one utterance per group; more
+ *                         rows than groups: a group steps two (three) utterances alternately, the shortest rows share
+ *                         (rows are assigned longest first); beyond three per group, equal-sized launches;
  *   n_resch > 128         G workgroups per utterance (decode_coop.hip), G * rows <= CUs per launch;
  *   other geometries      one workgroup (one CU) per utterance.
  * Every wait between workgroups is bounded; when a multi-workgroup launch gives up (its workgroups were not co-resident:
@@ -112,7 +112,7 @@ int qpn_decode_finish(qpn_handle* h, void* stream);
  * measured with HIP events on the launch stream (bench.py roofline). */
 float qpn_last_decode_kernel_ms(qpn_handle* h);
 
-/* The launch plan of the last decode call as text, e.g. "pipe rows=48 waves=1 x 48; one-cu rows=16 (beside)"
+/* The launch plan of the last decode call as text, e.g. "pipe rows=96 waves=1 x 96 (2 per group); one-cu rows=0"
  * (diagnostics / bench.py; owned by the handle, valid until the next decode call). */
 const char* qpn_last_decode_plan(qpn_handle* h);
 

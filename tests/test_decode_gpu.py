@@ -446,11 +446,11 @@ def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
     mt = re.match(r"pipe rows=(\d+) waves=(\d+) x (\d+) \((\d) per group\); one-cu rows=(\d+)", m.last_decode_plan)
     assert mt, m.last_decode_plan
     n_pipe, n_waves, per, per_group, n_one = map(int, mt.groups())
-    assert n_pipe == B and n_one == 0 and per_group == 2 and per <= 96 and n_waves * per >= n_pipe, m.last_decode_plan
+    assert n_pipe == B and n_one == 0 and n_waves * per >= n_pipe, m.last_decode_plan
     if B in (49, 64):
-        assert n_waves == 1                                         # one launch: 48 groups, B - 48 of them with two utterances
+        assert n_waves == 1 and per_group == 2                      # one launch: 48 groups, B - 48 of them with two utterances
     if B == 100:
-        assert n_waves == 2 and per == 50
+        assert n_waves == 1 and per_group == 3                      # three per group saves the second launch (15.3 us a step against 2 x 10)
     order = np.argsort(ns, kind="stable")
     assert [len(o) for o in outs] == [ns[b] for b in order]
     maxd = int(np.ceil(np.nanmax(bd)))
