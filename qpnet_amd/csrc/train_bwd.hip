@@ -1260,7 +1260,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     // layer l+1 (whose pitch-tap scatter reaches back across the cut) is done
     const bool lbmt1 = !getenv("QPN_LAYER_BWD_MT") || atoi(getenv("QPN_LAYER_BWD_MT")) == 1;
     const bool split = sp && lbmt1 && L >= 2 && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL") &&
-                       (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) && N1 - p.layers[L - 1].s_out >= 4096;
+                       (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) && getenv("QPN_TRAIN_SPLIT_BWD") && N1 - p.layers[L - 1].s_out >= 4096;
     const int cut_row = split ? tr_split_cut(p) : 0;
     const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
     if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }

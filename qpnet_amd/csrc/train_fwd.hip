@@ -223,13 +223,14 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
 #define FWDP_STAMP(i) do { } while (0)
 #endif
 template <int KS, bool LAST>
-__global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy, long long* stamps) {     // flags: bit 1 XCD swizzle
+__global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy, long long* stamps, int tile0) {     // flags: bit 1 XCD swizzle; tile0: first tile of this launch (two-part time split)
     constexpr int C = 64, Ktp = 16 * KS;
     constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;     // tr_lda: conflict-free fragment reads, 8-byte aligned rows
     extern __shared__ float sm[];
     float* Gs = sm + 32 * lda;                                   // As buffers: sm, sm + 16 * lda
     float* SGs = Gs + 16 * ldg; float* THs = SGs + 16 * ldg; float* Xs = THs + 16 * ldg;
-    const TrLayer ly = p.layers[l];
+    TrLayer ly = p.layers[l];
+    ly.s_out += 16 * tile0;                                       // (tiles are counted from the launch's first one)
     const int Ap = p.Ap, N1 = p.N1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
     const int srow = tid >> 4, sc4 = tid & 15;
     const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
     const int orow = tid >> 5, oc2 = (tid & 31) * 2;
-    float* const dmy = dummy + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + oc2;       // two scratch rows per workgroup
+    float* const dmy = dummy + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) + (tile0 ? 512 : 0)) * 2 * C + oc2;       // two scratch rows per workgroup (second half of the table: the split's other launch)
     int tp; float4 rc, rp, rx;
     auto load_tap = [&](int t) { const int n = ly.s_out + t * 16 + srow; tp = taps[n < N1 ? n : N1 - 1]; };
     auto load_rows = [&](int t) {
@@ -848,7 +849,7 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
         const int cut_row = split ? tr_split_cut(p) : 0;
         if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
         // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
-        const bool persist = C == 64 && p.Ktp == 176 && !split && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);
+        const bool persist = C == 64 && p.Ktp == 176 && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);
         const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
         for (int l = 0; l < p.L; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
@@ -860,8 +861,19 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
                 const bool stamp = getenv("QPN_FWDP_STAMPS") != nullptr;
                 if (stamp && !d_stamps) { QPN_HIP(hipMalloc(&d_stamps, 16 * 64 * sizeof(long long))); }
                 if (stamp) QPN_HIP(hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream));
-                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr);
-                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr);
+                if (split) {      // two launches of one workgroup per CU each: the earlier tiles on the main stream, the later ones on the side stream
+                    const int t0 = tr_split_tiles(p, l, cut_row, tiles), ncu = qpn_num_cus();
+                    const int G0 = t0 < ncu ? t0 : ncu, G1 = tiles - t0 < ncu ? tiles - t0 : ncu;
+                    if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
+                    else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
+                    QPN_HIP(hipEventRecord(sp->ev[l], stream));
+                    if (l > 0) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l - 1], 0));
+                    if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G1, p.B), dim3(256), ldsp, sp->side, p, l, flags0, tiles - t0, p.scratch_rows, nullptr, t0);
+                    else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G1, p.B), dim3(256), ldsp, sp->side, p, l, flags0, tiles - t0, p.scratch_rows, nullptr, t0);
+                    continue;
+                }
+                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr, 0);
+                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr, 0);
                 if (stamp && l == 5) {      // dev aid: print the stamps of one adaptive layer's launch (cycles relative to the first stamp of each sampled workgroup)
                     static int printed = 0;
                     long long hs[16 * 64];
