@@ -15,7 +15,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # kernel-name fragment -> (file, max scratch bytes per lane, min waves per SIMD)
 BUDGET = {
-    "k_decode_pipe": ("decode_pipe.hip", 0, 2),
+    "k_decode_pipe12DecodeParams": ("decode_pipe.hip", 0, 2),    # one utterance per five-role group: the latency-optimal kernel, nothing in scratch
+    "k_decode_pipe_nILi2E": ("decode_pipe.hip", 32, 2),           # two per group: three weight pairs of the post-2 role spill (whole-kernel allocation:
+                                                                  # the K role needs all 256 registers); non-inlined roles cost 2.6 KB of scratch instead
     "k_decode_coop": ("decode_coop.hip", 0, 3),             # 768 threads: three waves per SIMD, nothing in scratch memory
     "k_layer_fwd_pILi11ELb0E": ("train_fwd.hip", 0, 2),     # persistent layer forward: two workgroups per CU, weights in registers
     "k_post_fwd_wILi5E": ("train_fwd.hip", 0, 2),           # 80-row post-net tiles: one 512-thread workgroup per CU
