@@ -979,10 +979,13 @@ __global__ void k_reduce_grad(const float* __restrict__ slab, const int* __restr
 // The same reduction walked in SLAB order: a wave reads 64 consecutive floats of each partial slab (the flat order is a
 // permutation of it -- transposed blocks, interleaved taps -- so the gather above touches scattered 4-byte words of 64 slabs),
 // and the sum goes to the parameter(s) it feeds; entries nothing feeds are zeroed, the trailer appended.
+// [s0, s1): the slab elements this launch reduces (the early range runs on the side stream under the layer backward); `tail`: this launch
+// also zeroes the unfed entries and appends the trailer
 __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __restrict__ gdst, const int* __restrict__ gdst_list, const int* __restrict__ gzero, int n_gzero,
-                                int nch, int gstage, int64_t n, float* __restrict__ g, float scale, int append_scale) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < gstage) {
+                                int nch, int gstage, int64_t n, float* __restrict__ g, float scale, int append_scale, int s0, int s1, int skip0, int skip1, int tail) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + s0;
+    if (i < s1) {
+        if (i >= skip0 && i < skip1) return;                 // (already reduced by the early launch)
         const int k0 = gdst[i], k1 = gdst[i + 1];
         if (k0 == k1) return;                                // padding of the slab layout
         float a = 0.f;
@@ -991,7 +994,8 @@ __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __res
         for (int k = k0; k < k1; ++k) g[gdst_list[k]] = a;
         return;
     }
-    const int64_t j = i - gstage;
+    if (!tail) return;
+    const int64_t j = i - s1;
     if (j < n_gzero) g[gzero[j]] = 0.f;
     else if (append_scale && j < n_gzero + 4) g[n + (j - n_gzero)] = j == n_gzero ? scale : 0.f;
 }
@@ -1121,11 +1125,17 @@ void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t st
 
 // slabs -> flat gradient (writes every entry), then the histogram-style gradients on top (causal table when no
 // contraction owns it, upsampling kernel)
-int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+// the skip / post-net part of the slab reduction, launched on the side stream right behind those weight gradients
+static void launch_reduce_early(const TrainBwd& bw, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((bw.g_early1 - bw.g_early0 + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
+                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, 0);
+}
+
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done) {
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
     if (bw.gdst && !getenv("QPN_REDUCE_FLAT_ORDER"))
         hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + bw.n_gzero + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
+                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? bw.g_early0 : 0, early_done ? bw.g_early1 : 0, 1);
     else
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
     {
@@ -1245,6 +1255,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     };
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
     const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
+    // the memory-bound reduction of the skip / post-net slabs (half of k_reduce_grad's 130 MB) runs on the side stream under the
+    // matrix-bound layer backward instead of at the end of the step
+    const bool early_reduce = overlap && bw.gdst && bw.g_early1 > bw.g_early0 && !getenv("QPN_REDUCE_FLAT_ORDER") && !(getenv("QPN_REDUCE_EARLY") && atoi(getenv("QPN_REDUCE_EARLY")) == 0);
     // the side stream carries, under the layer backward: the skip / post-net weight gradients (ready after k_post_bwd) and, once the
     // upper half of the stack has been differentiated, that half's dW1 / dWr (QPN_WGRAD_SPLIT = first layer of that half; L = none)
     int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
@@ -1254,6 +1267,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
+        if (early_reduce) launch_reduce_early(bw, side);
     }
     // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
     // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
@@ -1319,7 +1333,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD, stream);
-    return qpn_launch_grad_tail(p, bw, stream);
+    return qpn_launch_grad_tail(p, bw, stream, early_reduce);
 }
 
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {

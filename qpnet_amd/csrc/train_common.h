@@ -77,6 +77,7 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     // slab offsets (floats) of every weight-grad block
     int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
     int g_p1, g_bp1, g_p2, g_bp2;
+    int g_early0, g_early1;           // slab range [g_early0, g_early1): skip 1x1 / skip bias / post-net blocks, complete before the layer backward ends
     int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
     float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
     int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)

@@ -234,12 +234,17 @@ static int train_init(qpn_handle* h) {
     std::vector<int>& gs = t->h_gsrc; std::vector<int>& gs2 = t->h_gsrc2;
     gs.assign(g.n_params, -1); gs2.assign(g.n_params, -1);
     for (int l = 0; l < L; ++l) {
-        const LayerGeom y = g.layers[l];
         bw.g_w1[l] = gtake(2 * C * Ktp);   // dW1[n][k] (n = z row, k = A-tile column), row-major [2C][Ktp]
         bw.g_b1[l] = gtake(2 * C);
         bw.g_wr[l] = gtake(C * C);         // dWr[o][c]
         bw.g_br[l] = gtake(C);
-        bw.g_ws[l] = gtake(S * C);         // dWs_l[s][c]
+    }
+    bw.g_early0 = go;
+    for (int l = 0; l < L; ++l) bw.g_ws[l] = gtake(S * C);         // dWs_l[s][c]
+    for (int l = 0; l < L; ++l) {
+        const LayerGeom y = g.layers[l];
+        // (slab order: first the blocks that need the layer backward -- dW1, dWr of every layer -- then, contiguous, the ones the side
+        //  stream finishes early: skip 1x1 of every layer, skip bias, post-net; that range is reduced early as well, under the layer backward)
         for (int n = 0; n < 2 * C; ++n) {
             const int half = n / C, r = n % C;
             for (int k = 0; k < 2 * C + A; ++k) {
@@ -259,6 +264,7 @@ static int train_init(qpn_handle* h) {
     bw.g_bs = gtake(S);
     for (int l = 0; l < L; ++l) for (int s = 0; s < S; ++s) gs[g.layers[l].skipb + s] = bw.g_bs + s;
     bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
+    bw.g_early1 = go;
     for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
     for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
     // causal conv table: dW[c][q][tap] = sum_t dX0[t][c] * onehot(x[t-1+tap])[q] is one more time contraction (k_wgrad3 mode 4)
