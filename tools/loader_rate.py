@@ -36,6 +36,9 @@ def main():
     scaler = lambda h: (h - mean) / scale      # noqa: E731
     dev = torch.device("cuda:0") if torch.cuda.is_available() else None
 
+    from qpnet_amd.runners import PinnedStager
+    stage = PinnedStager(dev) if dev is not None else None
+
     def rate(shard, to_dev):
         np.random.seed(1)
         gen = loaders.train_generator(utts, cfg.receptiveCausal_field, cfg.receptiveF_field, cfg.receptiveA_field, 22050,
@@ -46,7 +49,9 @@ def main():
         for _ in range(args.chunks):
             bx, bh, bt, bd, bb = next(gen)
             maxd = int(np.ceil(float(bd.max())))          # what runners._batches does per chunk
-            if to_dev:
+            if to_dev == "pinned":
+                out = stage({"x": bx, "h": bh, "t": bt, "d": bd})
+            elif to_dev:
                 out = [t.to(dev, non_blocking=True) for t in (bx, bh, bt, bd)]
         if to_dev:
             torch.cuda.synchronize()
@@ -56,8 +61,10 @@ def main():
     for shard in (None, (0, 2), (0, 4), (0, 8)):
         print("  shard %-8s %8.1f chunks/s delivered to this rank (host only)" % (shard, rate(shard, False)))
     if dev is not None:
-        print("  shard None     %8.1f chunks/s incl. the host-to-device copies" % rate(None, True))
-        print("  shard (0, 8)   %8.1f chunks/s incl. the host-to-device copies" % rate((0, 8), True))
+        print("  shard None     %8.1f chunks/s incl. host-to-device copies from pageable memory (tensor.to)" % rate(None, True))
+        print("  shard (0, 8)   %8.1f chunks/s incl. host-to-device copies from pageable memory" % rate((0, 8), True))
+        print("  shard None     %8.1f chunks/s incl. host-to-device copies through the pinned staging ring (runners.PinnedStager)" % rate(None, "pinned"))
+        print("  shard (0, 8)   %8.1f chunks/s incl. host-to-device copies through the pinned staging ring" % rate((0, 8), "pinned"))
 
 
 if __name__ == "__main__":
