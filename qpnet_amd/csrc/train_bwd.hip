@@ -566,6 +566,7 @@ struct Wg2 {
     int row0A[TR_MAXL], row0B[TR_MAXL], R[TR_MAXL];                         // window per layer
     int goff[TR_MAXL], gbias[TR_MAXL], tap_off[TR_MAXL], dil[TR_MAXL];
     int ldc, ncol_groups;                                                   // post: N split into column groups (blockIdx.z)
+    long long* stamps;                                                      // dev aid (QPN_ENABLE_STAMPS builds, QPN_WGRAD_STAMPS=<bmode>)
 };
 
 struct Wg2L {            // per-workgroup scalars hoisted out of the kernel-argument arrays
@@ -754,6 +755,13 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
 // the matrix-core loop, no branches around the staging loads (out-of-range rows are clamped and zeroed, the three
 // sources of the [x_cur | x_past | aux] operand become one per-thread base/stride), bias column sums taken from the
 // staging registers instead of 32 LDS reads per stage.  k_wgrad2 stays as the generic fallback.
+// dev aid: s_memtime of thread 0 at the phase boundaries of four sampled workgroups (build -DQPN_ENABLE_STAMPS, run QPN_WGRAD_STAMPS=<bmode>)
+#ifdef QPN_ENABLE_STAMPS
+#define WG_STAMP(i) do { if (w.stamps && threadIdx.x == 0 && blockIdx.y == (gridDim.y > 3 ? 3 : 0) && blockIdx.z == 0 && (blockIdx.x & 15) == 5 && (i) < 128) \
+    w.stamps[(blockIdx.x >> 4) * 128 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
 template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
     extern __shared__ float sm[];
@@ -802,13 +810,35 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
     float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 ra[NA], ra2[NA], rb[NB], rb2[NB];
     int tpv[NB];
+    int rbi[NB];                     // BMODE 4: sample class of the staged row (the one-hot is made when the stage goes to LDS)
+    unsigned okA = 0, okB = 0;       // bit k: staged row k is a real row.  The loaded registers are NOT touched before the stage goes to
+                                     // LDS: a select on a just-loaded value puts an s_waitcnt vmcnt in front of the matrix-core loop
+                                     // (measured with in-kernel stamps: 6-8 k cycles per stage in the skip 1x1 launch)
+
+    // Staging addresses.  A stage that lies inside one batch item and ends before rend -- all but the last one or two of a chunk -- takes
+    // the FAST form: one uniform base per operand and stage plus per-thread offsets fixed for the whole kernel.  The generic form below
+    // (row clamp, per-row batch split, 64-bit multiplies: ~650 instructions = 5.7 k cycles per stage in the dW1 launch, as long as its
+    // 176 MFMAs) only runs for the others.
+    const unsigned a_voff = (unsigned)a_row0 * (unsigned)w.lda + (unsigned)a_col, a_kstep = (unsigned)ARS * (unsigned)w.lda;
+    const unsigned b_voff = (unsigned)b_row0 * (unsigned)w.ldb + (unsigned)n, b_kstep = (unsigned)BRS * (unsigned)w.ldb;
 
     // rows of a stage: r in [0,32); rows at or past rend are clamped to the last valid row and zeroed
     auto rowsplit = [&](int rr, int& b, int& i) { if (multi) { b = (int)((unsigned)rr / uR); i = rr - b * (int)uR; } else { b = 0; i = rr; } };
+    auto stage_fast = [&](int rs, int& b0, int& i0) {       // uniform
+        rowsplit(rs, b0, i0);
+        return rs + RS <= rend && i0 + RS <= (int)uR;
+    };
     // (every thread loads its row's tap entry, needed or not: a per-thread condition around the load becomes a branch with an
     //  s_waitcnt behind each load, which also drains the operand loads issued just before -- the next stage's prefetch no longer
     //  ran under the MFMAs)
     auto taps = [&](int rs) {
+        int b0, i0;
+        if (stage_fast(rs, b0, i0)) {
+            const int* tst = tap + ((size_t)b0 * w.rowsB + row0B + i0);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) { const int r = b_row0 + k * BRS; tpv[k] = tst[r < RS ? r : b_row0]; }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int r = b_row0 + k * BRS;
@@ -818,34 +848,62 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
             tpv[k] = tap[(size_t)b * w.rowsB + nloc];
         }
     };
+    // Both forms only compute ADDRESSES (and the row masks) under the uniform branch; the loads themselves are issued once, behind it.
+    // [Loads in both arms made the merged values phi nodes: the copies at the join need the data, i.e. an s_waitcnt vmcnt(0) in front of
+    //  the matrix-core loop -- the whole memory latency exposed in every stage.]
     auto fetch = [&](int rs) {
+        const float* pa[NA]; const float* pb[NB]; const int* pi[NB];
+        int b0, i0;
+        if (stage_fast(rs, b0, i0)) {
+            const float* Ast = A + ((size_t)b0 * w.rowsA + row0A + i0) * w.lda;
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const int r = a_row0 + k * ARS;
-            int rr = rs + r; const bool ok = rr < rend; rr = ok ? rr : rend - 1;
-            int b, i; rowsplit(rr, b, i);
-            const size_t o = ((size_t)b * w.rowsA + row0A + i) * w.lda + a_col;
-            const float4 v = *(const float4*)(A + o);
-            if (TWO_A) ra2[k] = *(const float4*)(A2 + o);       // summed when the stage goes to LDS: no wait between the passes' loads
-            ra[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (b_act) {
+            for (int k = 0; k < NA; ++k) pa[k] = Ast + (k * a_kstep + a_voff);
+            okA = ~0u;
+            const size_t brow = (size_t)b0 * w.rowsB + row0B + i0;
+            const float* bsrc = BMODE == 3 ? bbase + (size_t)b0 * w.rowsB * bstride : B1 + brow * w.ldb;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int r = b_row0 + k * BRS;
+                if (BMODE == 4) pi[k] = w.xc + brow + (r < RS ? r : b_row0);
+                else if (BMODE == 3) {
+                    const unsigned row = use_tap ? (unsigned)tpv[k] : (unsigned)(row0B + i0 + (r < RS ? r : b_row0));
+                    pb[k] = bsrc + __umul24(row, (unsigned)bstride);
+                } else pb[k] = bsrc + ((r < RS ? k * b_kstep : 0u) + b_voff);
+            }
+            okB = b_pad ? 0u : ~0u;
+        } else {
+            okA = 0; okB = 0;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                const int r = a_row0 + k * ARS;
+                int rr = rs + r; const bool ok = rr < rend; rr = ok ? rr : rend - 1;
+                int b, i; rowsplit(rr, b, i);
+                pa[k] = A + (((size_t)b * w.rowsA + row0A + i) * w.lda + a_col);
+                okA |= ok ? 1u << k : 0u;
+            }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int r = b_row0 + k * BRS;
                 int rr = rs + r; const bool ok = r < RS && rr < rend && !b_pad; rr = rr < rend ? rr : rend - 1;
                 int b, i; rowsplit(rr, b, i);
                 const size_t row = (size_t)b * w.rowsB + ((BMODE == 3 && use_tap) ? tpv[k] : row0B + i);
-                float4 v;
-                if (BMODE == 4) {
-                    const int dlt = w.xc[row] - n;
-                    v = make_float4(dlt == 0 ? 1.f : 0.f, dlt == 1 ? 1.f : 0.f, dlt == 2 ? 1.f : 0.f, dlt == 3 ? 1.f : 0.f);
-                } else {
-                    const float* ptr = bbase + row * bstride;
-                    v = *(const float4*)ptr;
-                    if (BMODE == 2) rb2[k] = *(const float4*)(ptr + b2off);
+                if (BMODE == 4) pi[k] = w.xc + row; else pb[k] = bbase + row * bstride;
+                okB |= ok ? 1u << k : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            ra[k] = *(const float4*)pa[k];
+            if (TWO_A) ra2[k] = *(const float4*)(pa[k] + (A2 - A));
+        }
+        if (b_act) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (BMODE == 4) rbi[k] = *pi[k];
+                else {
+                    rb[k] = *(const float4*)pb[k];
+                    if (BMODE == 2) rb2[k] = *(const float4*)(pb[k] + b2off);
                 }
-                rb[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -855,12 +913,15 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
         if (BMODE == 3 && rbeg + RS < rend) taps(rbeg + RS);
     }
     const int g = lane >> 4, cl = lane & 15;
+    WG_STAMP(0);
     for (int rs = rbeg; rs < rend; rs += RS) {
+        WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
         // registers -> LDS
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             float4 v = ra[k];
-            if (TWO_A && rs + a_row0 + k * ARS < rend) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
+            if (TWO_A) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
+            { const bool ok = (okA >> k) & 1u; v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; }     // (component-wise: a select between float4 objects makes the staging arrays addressable -> scratch)
             cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;
             *(float4*)(As + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
         }
@@ -869,19 +930,25 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
             for (int k = 0; k < NB; ++k) {
                 const int r = b_row0 + k * BRS;
                 if (r < RS) {
-                    float4 v = rb[k];
+                    float4 v;
+                    if (BMODE == 4) { const int dlt = rbi[k] - n; v = make_float4(dlt == 0 ? 1.f : 0.f, dlt == 1 ? 1.f : 0.f, dlt == 2 ? 1.f : 0.f, dlt == 3 ? 1.f : 0.f); }
+                    else v = rb[k];
                     if (BMODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     else if (BMODE == 2) { v.x *= rb2[k].x; v.y *= rb2[k].y; v.z *= rb2[k].z; v.w *= rb2[k].w; }
+                    { const bool ok = (okB >> k) & 1u; v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; }
                     *(float4*)(Bs + (size_t)r * ldB + b_col) = v;
                 }
             }
         }
+        WG_STAMP(2 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
+        WG_STAMP(3 + 6 * ((rs - rbeg) / RS));
         // next stage's rows fly while the matrix cores work on this one
         if (rs + RS < rend) {
             fetch(rs + RS);
             if (BMODE == 3 && rs + 2 * RS < rend) taps(rs + 2 * RS);       // gather rows of the stage after next
         }
+        WG_STAMP(4 + 6 * ((rs - rbeg) / RS));
 #pragma unroll
         for (int ks = 0; ks < RS / 4; ++ks) {
             float bfr[NT];
@@ -894,8 +961,11 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
                 for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[nt], acc[mi][nt], 0, 0, 0);
             }
         }
+        WG_STAMP(5 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
+        WG_STAMP(6 + 6 * ((rs - rbeg) / RS));
     }
+    WG_STAMP(120);
     float* out = w.slab + (size_t)ch * w.gstage;
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
@@ -909,6 +979,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
             }
         }
     }
+    WG_STAMP(121);
     if (gbias >= 0) {          // bias grads: column sums of A, reduced over the ARS row groups of the staging layout
         *(float4*)(sm + (size_t)a_row0 * Mp + a_col) = cs4;
         __syncthreads();
@@ -916,10 +987,13 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
     }
 }
 
+#ifndef QPN_WGRAD_MINW
+#define QPN_WGRAD_MINW 2
+#endif
 template <int BMODE, int MPW, int NT, bool TWO_A>
 static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t stream) {
     // the 256 x 64 one-array launches (post-net, skip 1x1) sit two registers above the three-workgroups-per-CU line: ask for it
-    constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? 3 : 1;
+    constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? QPN_WGRAD_MINW : 1;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
 }
@@ -934,7 +1008,32 @@ static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     else launch_wgrad3_k<BMODE, MPW, NT, false>(w, nch, lds, stream);
     return true;
 }
-static bool wgrad3_any(const Wg2& w, int nch, hipStream_t stream) {
+static bool wgrad3_any_(const Wg2& w, int nch, hipStream_t stream);
+static bool wgrad3_any(const Wg2& w0, int nch, hipStream_t stream) {
+#ifdef QPN_ENABLE_STAMPS
+    const char* e = getenv("QPN_WGRAD_STAMPS");
+    if (e && atoi(e) == w0.bmode && w0.M == (getenv("QPN_WGRAD_STAMPS_M") ? atoi(getenv("QPN_WGRAD_STAMPS_M")) : w0.M)) {
+        static long long* d = nullptr; static int calls = 0;
+        if (!d) (void)hipMalloc(&d, 4 * 128 * sizeof(long long));
+        (void)hipMemsetAsync(d, 0, 4 * 128 * sizeof(long long), stream);
+        Wg2 w = w0; w.stamps = d;
+        const bool ok = wgrad3_any_(w, nch, stream);
+        if (++calls == 8) {
+            long long h[4 * 128];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+            for (int g = 0; g < 4; ++g) {
+                fprintf(stderr, "wgrad stamps bmode %d M %d wg %d: start 0", w0.bmode, w0.M, 16 * g + 5);
+                for (int i = 1; i < 128; ++i) if (h[g * 128 + i]) fprintf(stderr, " [%d]%lld", i, h[g * 128 + i] - h[g * 128]);
+                fprintf(stderr, "\n");
+            }
+        }
+        return ok;
+    }
+#endif
+    return wgrad3_any_(w0, nch, stream);
+}
+static bool wgrad3_any_(const Wg2& w, int nch, hipStream_t stream) {
     if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream);                                        // causal table: C = 64, 128-class groups
     if (getenv("QPN_WGRAD_GENERIC")) return false;
     switch (w.bmode) {
