@@ -762,14 +762,18 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
 #else
 #define WG_STAMP(i) do { } while (0)
 #endif
-template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1>
+// DB: 16-row stages in TWO LDS buffers (same footprint as one 32-row stage) and ONE LDS-only barrier per stage: stage s+1 goes from the
+// staging registers into the other buffer and stage s+2's rows are requested between the k-steps of stage s, so the staging instructions
+// issue in the shadow of the stage's own MFMAs instead of between two barriers with the matrix cores idle.
+template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1, bool DB = false>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
     extern __shared__ float sm[];
-    constexpr int RS = 32, Mp = 64 * MPW, Np = 16 * NT;
+    constexpr int RS = DB ? 16 : 32, Mp = 64 * MPW, Np = 16 * NT;
     constexpr int ldA = ((Mp + 15) / 32) * 32 + 16, ldB = ((Np + 15) / 32) * 32 + 16;       // tr_ldt
     constexpr int A4 = Mp / 4, ARS = 256 / A4, NA = RS / ARS;                               // A: every thread active, NA full passes
     constexpr int B4 = Np / 4, BRS = 256 / B4, NB = (RS + BRS - 1) / BRS;                   // B: threads < BRS*B4 active
-    static_assert(256 % A4 == 0 && RS % ARS == 0, "A staging must tile 32 rows exactly");
+    static_assert(256 % A4 == 0 && RS % ARS == 0, "A staging must tile the stage's rows exactly");
+    constexpr int BUF = RS * (ldA + ldB);                                                   // floats of one stage buffer
     const int y = blockIdx.y, ch = blockIdx.x, zg = blockIdx.z;
     float* As = sm; float* Bs = sm + RS * ldA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -914,16 +918,16 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
     }
     const int g = lane >> 4, cl = lane & 15;
     WG_STAMP(0);
-    for (int rs = rbeg; rs < rend; rs += RS) {
-        WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
-        // registers -> LDS
+    // staging registers -> LDS buffer `buf`
+    auto to_lds = [&](int buf) {
+        float* Ab = As + buf * BUF; float* Bb = Bs + buf * BUF;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             float4 v = ra[k];
             if (TWO_A) { v.x += ra2[k].x; v.y += ra2[k].y; v.z += ra2[k].z; v.w += ra2[k].w; }
             { const bool ok = (okA >> k) & 1u; v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; }     // (component-wise: a select between float4 objects makes the staging arrays addressable -> scratch)
             cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;
-            *(float4*)(As + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
+            *(float4*)(Ab + (size_t)(a_row0 + k * ARS) * ldA + a_col) = v;
         }
         if (b_act) {
 #pragma unroll
@@ -936,10 +940,58 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
                     if (BMODE == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     else if (BMODE == 2) { v.x *= rb2[k].x; v.y *= rb2[k].y; v.z *= rb2[k].z; v.w *= rb2[k].w; }
                     { const bool ok = (okB >> k) & 1u; v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f; }
-                    *(float4*)(Bs + (size_t)r * ldB + b_col) = v;
+                    *(float4*)(Bb + (size_t)r * ldB + b_col) = v;
                 }
             }
         }
+    };
+    auto ksteps = [&](int buf, int k0, int k1) {
+        const float* Ab = As + buf * BUF; const float* Bb = Bs + buf * BUF;
+#pragma unroll
+        for (int ks = k0; ks < k1; ++ks) {
+            float bfr[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[nt] = Bb[(4 * ks + g) * ldB + 16 * nt + cl];
+#pragma unroll
+            for (int mi = 0; mi < MPW; ++mi) {
+                const float a = Ab[(4 * ks + g) * ldA + 16 * (wave + 4 * mi) + cl];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[nt], acc[mi][nt], 0, 0, 0);
+            }
+        }
+    };
+    if (DB) {
+        if (rbeg < rend) {
+            to_lds(0);
+            if (rbeg + RS < rend) {
+                fetch(rbeg + RS);
+                if (BMODE == 3 && rbeg + 2 * RS < rend) taps(rbeg + 2 * RS);
+            }
+            TR_LDS_BARRIER();
+        }
+        int buf = 0;
+        for (int rs = rbeg; rs < rend; rs += RS, buf ^= 1) {
+            WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
+            ksteps(buf, 0, 1);
+            WG_STAMP(2 + 6 * ((rs - rbeg) / RS));
+            if (rs + RS < rend) {
+                to_lds(buf ^ 1);                                                // (requested a whole stage ago)
+                WG_STAMP(3 + 6 * ((rs - rbeg) / RS));
+                if (rs + 2 * RS < rend) {
+                    fetch(rs + 2 * RS);
+                    if (BMODE == 3 && rs + 3 * RS < rend) taps(rs + 3 * RS);
+                }
+            }
+            WG_STAMP(4 + 6 * ((rs - rbeg) / RS));
+            ksteps(buf, 1, RS / 4);
+            WG_STAMP(5 + 6 * ((rs - rbeg) / RS));
+            TR_LDS_BARRIER();
+            WG_STAMP(6 + 6 * ((rs - rbeg) / RS));
+        }
+    } else
+    for (int rs = rbeg; rs < rend; rs += RS) {
+        WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
+        to_lds(0);
         WG_STAMP(2 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
         WG_STAMP(3 + 6 * ((rs - rbeg) / RS));
@@ -949,18 +1001,7 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
             if (BMODE == 3 && rs + 2 * RS < rend) taps(rs + 2 * RS);       // gather rows of the stage after next
         }
         WG_STAMP(4 + 6 * ((rs - rbeg) / RS));
-#pragma unroll
-        for (int ks = 0; ks < RS / 4; ++ks) {
-            float bfr[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[nt] = Bs[(4 * ks + g) * ldB + 16 * nt + cl];
-#pragma unroll
-            for (int mi = 0; mi < MPW; ++mi) {
-                const float a = As[(4 * ks + g) * ldA + 16 * (wave + 4 * mi) + cl];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[nt], acc[mi][nt], 0, 0, 0);
-            }
-        }
+        ksteps(0, 0, RS / 4);
         WG_STAMP(5 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
         WG_STAMP(6 + 6 * ((rs - rbeg) / RS));
@@ -994,8 +1035,14 @@ template <int BMODE, int MPW, int NT, bool TWO_A>
 static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t stream) {
     // the 256 x 64 one-array launches (post-net, skip 1x1) sit two registers above the three-workgroups-per-CU line: ask for it
     constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? QPN_WGRAD_MINW : 1;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    static const int db = getenv("QPN_WGRAD_DB") ? atoi(getenv("QPN_WGRAD_DB")) : 0;         // bit mask by BMODE (dev knob)
+    constexpr bool DB_OK = MPW * NT >= 16;         // (a 64 x 64 block has 4 MFMAs per k-step: nothing to hide the staging under)
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, DB_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (DB_OK && (db >> BMODE & 1)) hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, DB_OK>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    else hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
 }
 template <int BMODE, int MPW, int NT>
 static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
@@ -1225,16 +1272,26 @@ void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t st
 // slabs -> flat gradient (writes every entry), then the histogram-style gradients on top (causal table when no
 // contraction owns it, upsampling kernel)
 // the skip / post-net part of the slab reduction, launched on the side stream right behind those weight gradients
-static void launch_reduce_early(const TrainBwd& bw, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((bw.g_early1 - bw.g_early0 + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, 0);
+// tail: this launch also zeroes the entries no slab feeds and appends the trailer (then the final reduction must not: the upsampling
+// kernel's gradient is added onto those zeros in between, see qpn_launch_bwd)
+static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail) {
+    const int64_t n = (int64_t)(bw.g_early1 - bw.g_early0) + (tail ? bw.n_gzero + 4 : 0);
+    hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
+                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, tail);
+}
+static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t st) {
+    const int64_t q0 = (int64_t)p.F * p.U - p.N1;
+    const int nfr = (int)(((int64_t)p.F * p.U - 1) / p.U - q0 / p.U + 1);       // frames that the N1 rows touch
+    hipLaunchKernelGGL(k_up_bwd, dim3(nfr, p.B), dim3(128), 0, st, p, bw);
 }
 
-int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done) {
+// early_done: the [g_early0, g_early1) slab range has been reduced already; up_done: so have the zeroing / trailer and, on top of the zeros, the
+// upsampling kernel's gradient
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done) {
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
     if (bw.gdst && !getenv("QPN_REDUCE_FLAT_ORDER"))
-        hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + bw.n_gzero + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? bw.g_early0 : 0, early_done ? bw.g_early1 : 0, 1);
+        hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + (up_done ? 0 : bw.n_gzero + 4) + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
+                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? bw.g_early0 : 0, early_done ? bw.g_early1 : 0, up_done ? 0 : 1);
     else
     hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
     {
@@ -1244,11 +1301,7 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0) {
-            const int64_t q0 = (int64_t)p.F * p.U - N1;
-            const int nfr = (int)(((int64_t)p.F * p.U - 1) / p.U - q0 / p.U + 1);       // frames that the N1 rows touch
-            hipLaunchKernelGGL(k_up_bwd, dim3(nfr, B), dim3(128), 0, stream, p, bw);
-        }
+        if (p.U > 0 && !up_done) launch_up_bwd(p, bw, stream);
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());
@@ -1266,6 +1319,14 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
+    hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
+    const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
+    if (overlap) {          // the zeroing touches nothing the post-net backward does: under it, on the side stream (joined before the first layer)
+        QPN_HIP(hipEventRecord(ev_fork, stream));
+        QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        qpn_launch_zero_dx(p, bw, side);
+        QPN_HIP(hipEventRecord(bw.ev_mid, side));
+    } else
     qpn_launch_zero_dx(p, bw, stream);
     const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
     if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
@@ -1309,9 +1370,19 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
                 qpn_launch_post_wgrad_gemm(p, bw, st);
             } else {
             w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
+            if (Q == S && !(getenv("QPN_POST_WGRAD_PAIR") && atoi(getenv("QPN_POST_WGRAD_PAIR")) == 0)) {
+                // both contractions have the same shape: ONE launch with the second as "layer 1" (strides = the distance between the arrays,
+                // modulo 2^64), 2 x 256 workgroups = two per CU, so one's staging runs under the other's MFMAs (alone, each launch put one
+                // workgroup on a CU: 35 % of every stage with the matrix cores idle, in-kernel stamps)
+                w.nlayers = 2;
+                w.A_lstride = (size_t)(bw.DY0 - bw.dlogits); w.B_lstride = (size_t)(p.S0 - p.Y0);
+                w.row0A[1] = w.row0B[1] = 0; w.R[1] = BL; w.tap_off[1] = -1; w.goff[1] = bw.g_p1; w.gbias[1] = bw.g_bp1;
+                ok = ok && wgrad2_any(w, nch, st);
+            } else {
             ok = ok && wgrad2_any(w, nch, st);
             w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
             ok = ok && wgrad2_any(w, nch, st);
+            }
             }
         }
     };
@@ -1352,13 +1423,14 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
         }
     };
-    hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
-    const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
     // the memory-bound reduction of the skip / post-net slabs (half of k_reduce_grad's 130 MB) runs on the side stream under the
     // matrix-bound layer backward instead of at the end of the step
     const bool early_reduce = overlap && bw.gdst && bw.g_early1 > bw.g_early0 && !getenv("QPN_REDUCE_FLAT_ORDER") && !(getenv("QPN_REDUCE_EARLY") && atoi(getenv("QPN_REDUCE_EARLY")) == 0);
     // the side stream carries, under the layer backward: the skip / post-net weight gradients (ready after k_post_bwd) and, once the
     // upper half of the stack has been differentiated, that half's dW1 / dWr (QPN_WGRAD_SPLIT = first layer of that half; L = none)
+    // with the early reduction doing the zeroing / trailer too, the upsampling kernel's gradient (atomics onto those zeros, needs dH of every
+    // layer) runs on the side stream next to dW1 instead of behind the final reduction
+    const bool up_side = early_reduce && p.U > 0 && !(getenv("QPN_UP_SIDE") && atoi(getenv("QPN_UP_SIDE")) == 0);
     int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
     if (const char* e = getenv("QPN_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= L) mid = v; }
     if (!overlap) mid = L;
@@ -1366,7 +1438,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
-        if (early_reduce) launch_reduce_early(bw, side);
+        if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0);
+        QPN_HIP(hipStreamWaitEvent(stream, bw.ev_mid, 0));          // (the zeroing, recorded above)
     }
     // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
     // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
@@ -1412,10 +1485,11 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     // the residual-1x1 weight gradient is a memory-bound 64 x 64 contraction: on the side stream next to the matrix-heavy dW1 launch
     // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
     const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
-    if (wr_side) {
+    if (wr_side || up_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        launch_w1_wr(0, mid, side, 2);
+        if (up_side) launch_up_bwd(p, bw, side);
+        if (wr_side) launch_w1_wr(0, mid, side, 2);
     }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
@@ -1432,7 +1506,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD, stream);
-    return qpn_launch_grad_tail(p, bw, stream, early_reduce);
+    return qpn_launch_grad_tail(p, bw, stream, early_reduce, up_side);
 }
 
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {

@@ -475,7 +475,7 @@ int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t st
 }
 
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
-int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done);
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done);
 
 // post-net weight gradients dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0) (+ bias column sums) into the `nch` partial slabs;
 // also used by the tile path of the narrow geometries (train_bwd.hip), where these two are the only 256-row outputs
@@ -572,5 +572,5 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
     }
     qpn_launch_post_wgrad_gemm(p, bw, stream);
     qpn_prof_mark(PG_WGRAD, stream);
-    return qpn_launch_grad_tail(p, bw, stream, false);
+    return qpn_launch_grad_tail(p, bw, stream, false, false);
 }
