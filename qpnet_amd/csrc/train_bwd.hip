@@ -162,8 +162,12 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 // workgroups), the transposed post-net weights stream from L2 once per 80 rows instead of once per 16, one [16 MT][256] LDS
 // tile reused in place by the stages, every output array written as whole rows.  The ReLU masks are the signs of the rectified
 // activations the forward stored (p.Y0, p.S0), requested ahead of the contraction they follow.
+__device__ __forceinline__ void zero_dx_slice(const TrainParams& p, const TrainBwd& bw, int j, int b, size_t part, size_t nparts, int t, int nthr);
+// zero_dx: this launch also does k_zero_dx's zeroing (fire-and-forget stores ahead of the first contraction; nothing here touches those
+// arrays, the layer backward that does starts after this kernel) -- one launch and two stream events fewer per step
 template <int MT>
-__global__ __launch_bounds__(512) void k_post_bwd_w(TrainParams p, TrainBwd bw) {
+__global__ __launch_bounds__(512) void k_post_bwd_w(TrainParams p, TrainBwd bw, int zero_dx) {
+    if (zero_dx) for (int j = 0; j < p.L; ++j) zero_dx_slice(p, bw, j, blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, 512);
     constexpr int TM = 16 * MT, S = 256, Q = 256;
     constexpr int lds = ((S + 29) / 32) * 32 + 2;
     extern __shared__ float sm[];
@@ -1243,8 +1247,9 @@ __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float
 //   DXB[j] (pitch-tap scatter part): a fixed layer is the unique writer of rows [s_in(j), N1 - dilation), so only the last
 //           `dilation` rows (and, for j = 0, nothing in front) need zeros; an adaptive layer adds with atomics -> all rows.
 // X[L]'s gradient is never read (the last block's residual output is unused, qpnet.py:306-309).
-__global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
-    const int j = blockIdx.y, b = blockIdx.z, C = p.C;
+// part / nparts: the slice of (layer j, batch item b)'s zeroing this caller does, with nthr threads of which this is thread t
+__device__ __forceinline__ void zero_dx_slice(const TrainParams& p, const TrainBwd& bw, int j, int b, size_t part, size_t nparts, int t, int nthr) {
+    const int C = p.C;
     const TrLayer ly = p.layers[j];
     const size_t nDX = (size_t)p.B * p.N1 * C;
     float* A = bw.DXA[0] + (size_t)j * nDX + (size_t)b * p.N1 * C;
@@ -1255,11 +1260,14 @@ __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     // layer 0's blocks also clear the aux-feature gradient [N1][Ap] of this batch item (every layer adds to it)
     const size_t nh = j == 0 ? (size_t)p.N1 * p.Ap / 4 : 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb + nh; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = part * nthr + t; i < na + nb + nh; i += nparts * nthr) {
         if (i < na) ((float4*)(A + (size_t)a0 * C))[i] = z;
         else if (i < na + nb) ((float4*)(Bq + (size_t)(b0 > 0 ? b0 : 0) * C))[i - na] = z;
         else ((float4*)(bw.DHUP + (size_t)b * p.N1 * p.Ap))[i - na - nb] = z;
     }
+}
+__global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
+    zero_dx_slice(p, bw, blockIdx.y, blockIdx.z, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x);
 }
 
 void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
@@ -1321,19 +1329,14 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
     const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
-    if (overlap) {          // the zeroing touches nothing the post-net backward does: under it, on the side stream (joined before the first layer)
-        QPN_HIP(hipEventRecord(ev_fork, stream));
-        QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-        qpn_launch_zero_dx(p, bw, side);
-        QPN_HIP(hipEventRecord(bw.ev_mid, side));
-    } else
-    qpn_launch_zero_dx(p, bw, stream);
     const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
+    const bool zero_in_post = post_wide && !qpn_prof_active() && !(getenv("QPN_ZERO_IN_POST") && atoi(getenv("QPN_ZERO_IN_POST")) == 0);
+    if (!zero_in_post) qpn_launch_zero_dx(p, bw, stream);
     if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
         constexpr int MTW = 5;
         const size_t ldsw = (size_t)16 * MTW * tr_lda(256) * sizeof(float);
         QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
-        hipLaunchKernelGGL((k_post_bwd_w<MTW>), dim3((BL + 16 * MTW - 1) / (16 * MTW), B), dim3(512), ldsw, stream, p, bw);
+        hipLaunchKernelGGL((k_post_bwd_w<MTW>), dim3((BL + 16 * MTW - 1) / (16 * MTW), B), dim3(512), ldsw, stream, p, bw, zero_in_post ? 1 : 0);
     } else if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
         const size_t lds1 = lds_post / MT;
         if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
@@ -1439,7 +1442,6 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
         if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0);
-        QPN_HIP(hipStreamWaitEvent(stream, bw.ev_mid, 0));          // (the zeroing, recorded above)
     }
     // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
     // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
@@ -1484,25 +1486,31 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     // the residual-1x1 weight gradient is a memory-bound 64 x 64 contraction: on the side stream next to the matrix-heavy dW1 launch
     // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
-    const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
-    if (wr_side || up_side) {
-        QPN_HIP(hipEventRecord(bw.ev_mid, stream));
-        QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        if (up_side) launch_up_bwd(p, bw, side);
-        if (wr_side) launch_w1_wr(0, mid, side, 2);
-    }
-    if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
-    qpn_prof_mark(PG_LAYER_BWD, stream);
-    launch_w1_wr(0, mid, stream, wr_side ? 1 : 3);
-    Wg2 w = wbase;
-    if (!overlap) launch_skip_post(stream);
-    if (bw.g_cw >= 0) {   // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
+    auto launch_causal = [&](hipStream_t st) {
+        if (bw.g_cw < 0) return;
+        // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
+        Wg2 w = wbase;
         w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
         w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
         w.N = Q; w.Nvalid = Q; w.rowsB = N1 + 1; w.ldb = 0; w.ldc = Q;
         for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
-        ok = ok && wgrad2_any(w, nch, stream);
+        ok = ok && wgrad2_any(w, nch, st);
+    };
+    // the causal table's contraction (256 workgroups, latency-bound) next to dW1 as well: the side chain up_bwd + dWr + causal is as long as dW1
+    const bool causal_side = overlap && getenv("QPN_CAUSAL_SIDE") && atoi(getenv("QPN_CAUSAL_SIDE")) == 1;
+    const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
+    if (wr_side || up_side || causal_side) {
+        QPN_HIP(hipEventRecord(bw.ev_mid, stream));
+        QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
+        if (up_side) launch_up_bwd(p, bw, side);
+        if (wr_side) launch_w1_wr(0, mid, side, 2);
+        if (causal_side) launch_causal(side);
     }
+    if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
+    qpn_prof_mark(PG_LAYER_BWD, stream);
+    launch_w1_wr(0, mid, stream, wr_side ? 1 : 3);
+    if (!overlap) launch_skip_post(stream);
+    if (!causal_side) launch_causal(stream);
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD, stream);

@@ -332,9 +332,12 @@ static int train_init(qpn_handle* h) {
         QPN_HIP(hipMemcpy(t->d_ctmap, ctm.data(), ctm.size() * sizeof(int), hipMemcpyHostToDevice));
     }
     QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
-    QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
-    QPN_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-    QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, hipEventDisableTiming));
+    // the fork / join events only order kernels of THIS device's streams: no system-scope fence (cache write-back for the host) at each record
+    // (QPN_EVENT_FENCE=1 restores it)
+    const unsigned evf = hipEventDisableTiming | ((getenv("QPN_EVENT_FENCE") && atoi(getenv("QPN_EVENT_FENCE")) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, evf));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_join, evf));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, evf));
     if (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) {     // opt-in experiment: no extra hardware queue otherwise
         QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
         for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
