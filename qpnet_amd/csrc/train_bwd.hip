@@ -759,18 +759,61 @@ static bool wgrad2_mode(const Wg2& w, int nch, hipStream_t stream) {
 // the matrix-core loop, no branches around the staging loads (out-of-range rows are clamped and zeroed, the three
 // sources of the [x_cur | x_past | aux] operand become one per-thread base/stride), bias column sums taken from the
 // staging registers instead of 32 LDS reads per stage.  k_wgrad2 stays as the generic fallback.
+// upsampling kernel grad: dw[j] = sum_{a,f} dH[a, U f + j] h[a,f];  db = sum dH   (qpnet.py:134-158)
+// One workgroup per (frame, batch item): thread j < U owns sample U f + j of the frame, reads its dH row (Ap contiguous floats: the
+// workgroup's reads are one contiguous U*Ap*4-byte block) and dots it with the frame's feature column held in LDS; one global atomic per
+// (j, frame) instead of an LDS atomic per element (the element-wise version was 20 us for 3.8 MB: contended LDS atomics on 110 bins).
+struct UpArgs { const float* h; const float* DHUP; float* gflat; int64_t up_w, up_b; float gscale; int U, Ap, A, F, N1, nfr, B; };
+static UpArgs up_args(const TrainParams& p, const TrainBwd& bw) {
+    UpArgs u; u.h = p.h; u.DHUP = bw.DHUP; u.gflat = bw.gflat; u.gscale = bw.gscale; u.U = p.U; u.Ap = p.Ap; u.A = p.A; u.F = p.F; u.N1 = p.N1;
+    u.up_w = p.up_w; u.up_b = p.up_b; u.B = p.B;
+    const int64_t q0 = (int64_t)p.F * p.U - p.N1;
+    u.nfr = p.U > 0 ? (int)(((int64_t)p.F * p.U - 1) / p.U - q0 / p.U + 1) : 0;       // frames that the N1 rows touch
+    return u;
+}
+// fx: frame (counted from the first one the rows touch), b: batch item; nthr threads (a multiple of 64, <= 256), all of which call this
+__device__ __forceinline__ void up_bwd_body(const UpArgs& p, int fx, int b, int tid, int nthr) {
+    __shared__ float hcol[64];
+    __shared__ float red[4];
+    const int U = p.U, Ap = p.Ap, A = p.A;
+    const int64_t q0 = (int64_t)p.F * U - p.N1;           // h_up sample index of row 0
+    const int f = (int)(q0 / U) + fx;                     // frames touched: f0 .. f0 + nfr - 1
+    float dsum = 0.f;
+    for (int a0 = 0; a0 < A; a0 += 64) {                  // (one pass for the usual 39 features)
+        __syncthreads();
+        if (tid < 64) hcol[tid] = (a0 + tid < A && f < p.F) ? p.h[((size_t)b * A + a0 + tid) * p.F + f] : 0.f;
+        __syncthreads();
+        for (int j = tid; j < U; j += nthr) {
+            const int64_t n = (int64_t)f * U + j - q0;    // local row
+            if (n < 0 || n >= p.N1 || f >= p.F) continue;
+            const float* row = p.DHUP + ((size_t)b * p.N1 + n) * Ap + a0;
+            float acc = 0.f;
+            const int na = A - a0 < 64 ? A - a0 : 64;
+            int a = 0;
+            for (; a + 4 <= na; a += 4) { const float4 v = *(const float4*)(row + a); acc += v.x * hcol[a] + v.y * hcol[a + 1] + v.z * hcol[a + 2] + v.w * hcol[a + 3]; dsum += (v.x + v.y) + (v.z + v.w); }
+            for (; a < na; ++a) { const float v = row[a]; acc += v * hcol[a]; dsum += v; }
+            atomicAdd(&p.gflat[p.up_w + j], acc * p.gscale);
+        }
+    }
+    for (int s = 32; s >= 1; s >>= 1) dsum += __shfl_xor(dsum, s);
+    if ((tid & 63) == 0) red[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) { float a = 0.f; for (int k = 0; k < nthr / 64; ++k) a += red[k]; atomicAdd(&p.gflat[p.up_b], a * p.gscale); }
+}
+
 // dev aid: s_memtime of thread 0 at the phase boundaries of four sampled workgroups (build -DQPN_ENABLE_STAMPS, run QPN_WGRAD_STAMPS=<bmode>)
 #ifdef QPN_ENABLE_STAMPS
-#define WG_STAMP(i) do { if (w.stamps && threadIdx.x == 0 && blockIdx.y == (gridDim.y > 3 ? 3 : 0) && blockIdx.z == 0 && (blockIdx.x & 15) == 5 && (i) < 128) \
-    w.stamps[(blockIdx.x >> 4) * 128 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define WG_STAMP(i) do { if (w.stamps && threadIdx.x == 0 && y == (w.nlayers > 3 ? 3 : 0) && zg == 0 && (ch & 15) == 5 && (i) < 128) \
+    w.stamps[(ch >> 4) * 128 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WG_STAMP(i) do { } while (0)
 #endif
 // DB: 16-row stages in TWO LDS buffers (same footprint as one 32-row stage) and ONE LDS-only barrier per stage: stage s+1 goes from the
 // staging registers into the other buffer and stage s+2's rows are requested between the k-steps of stage s, so the staging instructions
 // issue in the shadow of the stage's own MFMAs instead of between two barriers with the matrix cores idle.
-template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1, bool DB = false>
-__global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
+// (ch, y, zg) = (time chunk, layer, column group) of this workgroup: blockIdx of the one-contraction launches, decoded from a flat index in k_wgrad_tail
+template <int BMODE, int MPW, int NT, bool TWO_A, bool DB>
+__device__ __forceinline__ void wgrad3_body(const Wg2& w, const int nch, const int ch, const int y, const int zg) {
     extern __shared__ float sm[];
     constexpr int RS = DB ? 16 : 32, Mp = 64 * MPW, Np = 16 * NT;
     constexpr int ldA = ((Mp + 15) / 32) * 32 + 16, ldB = ((Np + 15) / 32) * 32 + 16;       // tr_ldt
@@ -778,7 +821,6 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
     constexpr int B4 = Np / 4, BRS = 256 / B4, NB = (RS + BRS - 1) / BRS;                   // B: threads < BRS*B4 active
     static_assert(256 % A4 == 0 && RS % ARS == 0, "A staging must tile the stage's rows exactly");
     constexpr int BUF = RS * (ldA + ldB);                                                   // floats of one stage buffer
-    const int y = blockIdx.y, ch = blockIdx.x, zg = blockIdx.z;
     float* As = sm; float* Bs = sm + RS * ldA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Rl = w.R[y];
@@ -1031,6 +1073,30 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
         if (tid < Mp) { float s = 0.f; for (int r = 0; r < ARS; ++r) s += sm[r * Mp + tid]; out[gbias + tid] = s; }
     }
 }
+template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1, bool DB = false>
+__global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
+    wgrad3_body<BMODE, MPW, NT, TWO_A, DB>(w, nch, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The three contractions that wait for the whole layer backward -- dW1 (matrix-core heavy), the residual 1x1 (memory-bound) and the causal
+// table (one workgroup per CU on its own) -- as ONE launch: flat block index -> (contraction, chunk, layer, column group), the long dW1
+// workgroups first.  As separate launches on two streams they cost two stream events on the step's critical path (7-10 us each, more than
+// some of the kernels) and left the causal launch alone on the chip.
+struct WgTail { Wg2 w1, wr, wc; UpArgs up; int n1, nr, nc; };       // up.nfr * up.B more workgroups do the upsampling kernel's gradient (0: not here)
+__global__ __launch_bounds__(256, 2) void k_wgrad_tail(WgTail t, int nch) {
+    int b = blockIdx.x;
+    if (b < t.n1) { wgrad3_body<3, 2, 11, false, false>(t.w1, nch, b % nch, b / nch, 0); return; }
+    b -= t.n1;
+    if (b < t.nr) { wgrad3_body<2, 1, 4, true, false>(t.wr, nch, b % nch, b / nch, 0); return; }
+    b -= t.nr;
+    if (b < t.nc) {
+        const int yz = b / nch;
+        wgrad3_body<4, 1, 8, true, false>(t.wc, nch, b % nch, yz % t.wc.nlayers, yz / t.wc.nlayers);
+        return;
+    }
+    b -= t.nc;
+    up_bwd_body(t.up, b % t.up.nfr, b / t.up.nfr, threadIdx.x, 256);
+}
 
 #ifndef QPN_WGRAD_MINW
 #define QPN_WGRAD_MINW 2
@@ -1049,12 +1115,19 @@ static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t strea
     else hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
 }
 template <int BMODE, int MPW, int NT>
-static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
+static bool wgrad3_fits(const Wg2& w) {
     const int Ng = w.N / w.ncol_groups;
+    if (w.bmode != BMODE) return false;
     if (w.M != 64 * MPW || Ng != 16 * NT || w.N % w.ncol_groups || (w.Nvalid != w.N && (w.ncol_groups != 1 || w.Nvalid % 4))) return false;
     if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4) || !w.tap)) return false;
     if (BMODE == 3) for (int l = 0; l < w.nlayers; ++l) if (w.tap_off[l] < 0) return false;      // the kernel loads taps unconditionally
-    const size_t lds = (size_t)32 * (tr_ldt(64 * MPW) + tr_ldt(16 * NT)) * sizeof(float);
+    return true;
+}
+template <int MPW, int NT> static constexpr size_t wgrad3_lds() { return (size_t)32 * (tr_ldt(64 * MPW) + tr_ldt(16 * NT)) * sizeof(float); }
+template <int BMODE, int MPW, int NT>
+static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
+    if (!wgrad3_fits<BMODE, MPW, NT>(w)) return false;
+    const size_t lds = wgrad3_lds<MPW, NT>();
     if (w.A2) launch_wgrad3_k<BMODE, MPW, NT, true>(w, nch, lds, stream);
     else launch_wgrad3_k<BMODE, MPW, NT, false>(w, nch, lds, stream);
     return true;
@@ -1192,39 +1265,7 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
     }
 }
 
-// upsampling kernel grad: dw[j] = sum_{a,f} dH[a, U f + j] h[a,f];  db = sum dH   (qpnet.py:134-158)
-// One workgroup per (frame, batch item): thread j < U owns sample U f + j of the frame, reads its dH row (Ap contiguous floats: the
-// workgroup's reads are one contiguous U*Ap*4-byte block) and dots it with the frame's feature column held in LDS; one global atomic per
-// (j, frame) instead of an LDS atomic per element (the element-wise version was 20 us for 3.8 MB: contended LDS atomics on 110 bins).
-__global__ __launch_bounds__(128) void k_up_bwd(TrainParams p, TrainBwd bw) {
-    __shared__ float hcol[64];
-    __shared__ float red[2];
-    const int U = p.U, Ap = p.Ap, A = p.A, tid = threadIdx.x;
-    const int b = blockIdx.y;
-    const int64_t q0 = (int64_t)p.F * U - p.N1;           // h_up sample index of row 0
-    const int f = (int)(q0 / U) + blockIdx.x;             // frames touched: f0 .. f0 + gridDim.x - 1
-    float dsum = 0.f;
-    for (int a0 = 0; a0 < A; a0 += 64) {                  // (one pass for the usual 39 features)
-        __syncthreads();
-        if (tid < 64) hcol[tid] = (a0 + tid < A && f < p.F) ? p.h[((size_t)b * A + a0 + tid) * p.F + f] : 0.f;
-        __syncthreads();
-        for (int j = tid; j < U; j += 128) {
-            const int64_t n = (int64_t)f * U + j - q0;    // local row
-            if (n < 0 || n >= p.N1 || f >= p.F) continue;
-            const float* row = bw.DHUP + ((size_t)b * p.N1 + n) * Ap + a0;
-            float acc = 0.f;
-            const int na = A - a0 < 64 ? A - a0 : 64;
-            int a = 0;
-            for (; a + 4 <= na; a += 4) { const float4 v = *(const float4*)(row + a); acc += v.x * hcol[a] + v.y * hcol[a + 1] + v.z * hcol[a + 2] + v.w * hcol[a + 3]; dsum += (v.x + v.y) + (v.z + v.w); }
-            for (; a < na; ++a) { const float v = row[a]; acc += v * hcol[a]; dsum += v; }
-            atomicAdd(&bw.gflat[p.up_w + j], acc * bw.gscale);
-        }
-    }
-    for (int s = 32; s >= 1; s >>= 1) dsum += __shfl_xor(dsum, s);
-    if ((tid & 63) == 0) red[tid >> 6] = dsum;
-    __syncthreads();
-    if (tid == 0) atomicAdd(&bw.gflat[p.up_b], (red[0] + red[1]) * bw.gscale);
-}
+__global__ __launch_bounds__(128) void k_up_bwd(UpArgs u) { up_bwd_body(u, blockIdx.x, blockIdx.y, threadIdx.x, 128); }
 
 // torch.optim.Adam (single tensor semantics, fp32)
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -1288,9 +1329,8 @@ static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail) {
                        bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, tail);
 }
 static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t st) {
-    const int64_t q0 = (int64_t)p.F * p.U - p.N1;
-    const int nfr = (int)(((int64_t)p.F * p.U - 1) / p.U - q0 / p.U + 1);       // frames that the N1 rows touch
-    hipLaunchKernelGGL(k_up_bwd, dim3(nfr, p.B), dim3(128), 0, st, p, bw);
+    const UpArgs u = up_args(p, bw);
+    hipLaunchKernelGGL(k_up_bwd, dim3(u.nfr, p.B), dim3(128), 0, st, u);
 }
 
 // early_done: the [g_early0, g_early1) slab range has been reduced already; up_done: so have the zeroing / trailer and, on top of the zeros, the
@@ -1401,10 +1441,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         return w;
     };
     // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
-    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st, int which = 3) {      // which: bit 0 dW1, bit 1 dWr
-        if (lo >= hi) return;
+    auto build_w1 = [&]() {     // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
         Wg2 w = wbase;
-        if (which & 1) {   // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
             w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
             w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
             w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
@@ -1413,18 +1451,23 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
                 w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
                 w.tap_off[l] = ly.tap_off; w.dil[l] = ly.dilation;
             }
-            ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
-        }
-        if (which & 2) {   // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
+        return w;
+    };
+    auto build_wr = [&]() {     // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
+        Wg2 w = wbase;
             w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
             w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
-            w.ncol_groups = wgrad_col_groups(w.M, w.N);
+            w.nlayers = L; w.ncol_groups = wgrad_col_groups(w.M, w.N);
             for (int l = 0; l < L; ++l) {
                 w.row0A[l] = w.row0B[l] = p.layers[l].s_out;
                 w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1; w.dil[l] = 0;
             }
-            ok = ok && wgrad2_any(subset(w, lo, hi), nch, st);
-        }
+        return w;
+    };
+    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st, int which = 3) {      // which: bit 0 dW1, bit 1 dWr
+        if (lo >= hi) return;
+        if (which & 1) ok = ok && wgrad2_any(subset(build_w1(), lo, hi), nch, st);
+        if (which & 2) ok = ok && wgrad2_any(subset(build_wr(), lo, hi), nch, st);
     };
     // the memory-bound reduction of the skip / post-net slabs (half of k_reduce_grad's 130 MB) runs on the side stream under the
     // matrix-bound layer backward instead of at the end of the step
@@ -1486,16 +1529,40 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     // the residual-1x1 weight gradient is a memory-bound 64 x 64 contraction: on the side stream next to the matrix-heavy dW1 launch
     // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
-    auto launch_causal = [&](hipStream_t st) {
-        if (bw.g_cw < 0) return;
-        // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
+    auto build_causal = [&]() {      // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
         Wg2 w = wbase;
         w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
         w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
         w.N = Q; w.Nvalid = Q; w.rowsB = N1 + 1; w.ldb = 0; w.ldc = Q;
         for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
-        ok = ok && wgrad2_any(w, nch, st);
+        return w;
     };
+    auto launch_causal = [&](hipStream_t st) { if (bw.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, st); };
+    // ---- everything that waits for the whole layer backward as ONE launch (k_wgrad_tail): no fork / join around it
+    bool tail_fused = false, up_in_tail = false;
+    // [measured: 1146 steps/s against 1205 with the launches on two streams -- one register budget (247 VGPRs, two workgroups per CU) for all
+    //  roles, and the dW1 workgroups fill every slot first, so the others no longer run beside them.  Opt-in: QPN_WGRAD_TAIL=1]
+    if (!qpn_prof_active() && mid == L && bw.g_cw >= 0 && getenv("QPN_WGRAD_TAIL") && atoi(getenv("QPN_WGRAD_TAIL")) == 1) {
+        WgTail t;
+        t.w1 = build_w1(); t.wr = build_wr(); t.wc = build_causal();
+        if (wgrad3_fits<3, 2, 11>(t.w1) && wgrad3_fits<2, 1, 4>(t.wr) && t.wr.A2 && wgrad3_fits<4, 1, 8>(t.wc) && t.wc.A2 && !getenv("QPN_WGRAD_GENERIC")) {
+            tail_fused = true;
+            up_in_tail = up_side;                                             // (the early reduction has zeroed the slots it adds to)
+            if (overlap) { QPN_HIP(hipEventRecord(ev_join, side)); QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0)); }     // the side stream's work ended under the layer backward
+            else launch_skip_post(stream);
+            t.n1 = nch * t.w1.nlayers; t.nr = nch * t.wr.nlayers; t.nc = nch * t.wc.nlayers * t.wc.ncol_groups;
+            t.up = up_args(p, bw); if (!up_in_tail) t.up.nfr = 0;
+            size_t lds = wgrad3_lds<2, 11>(); if (wgrad3_lds<1, 4>() > lds) lds = wgrad3_lds<1, 4>(); if (wgrad3_lds<1, 8>() > lds) lds = wgrad3_lds<1, 8>();
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            qpn_prof_mark(PG_LAYER_BWD, stream);
+            hipLaunchKernelGGL(k_wgrad_tail, dim3((unsigned)(t.n1 + t.nr + t.nc + t.up.nfr * t.up.B)), dim3(256), lds, stream, t, nch);
+        }
+    }
+    if (tail_fused) {
+        if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
+        qpn_prof_mark(PG_WGRAD, stream);
+        return qpn_launch_grad_tail(p, bw, stream, early_reduce, up_in_tail);
+    }
     // the causal table's contraction (256 workgroups, latency-bound) next to dW1 as well: the side chain up_bwd + dWr + causal is as long as dW1
     const bool causal_side = overlap && getenv("QPN_CAUSAL_SIDE") && atoi(getenv("QPN_CAUSAL_SIDE")) == 1;
     const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
