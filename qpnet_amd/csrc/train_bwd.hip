@@ -1211,8 +1211,17 @@ __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __res
         if (i >= skip0 && i < skip1) return;                 // (already reduced by the early launch)
         const int k0 = gdst[i], k1 = gdst[i + 1];
         if (k0 == k1) return;                                // padding of the slab layout
+        // eight slabs' words requested together (the one-at-a-time sum kept ~4 loads in flight per lane: 29 us for 61 MB)
         float a = 0.f;
-        for (int c = 0; c < nch; ++c) a += slab[(size_t)c * gstage + i];
+        const float* sp = slab + i;
+        int c = 0;
+        for (; c + 8 <= nch; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sp[(size_t)(c + k) * gstage];
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; c < nch; ++c) a += sp[(size_t)c * gstage];
         a *= scale;
         for (int k = k0; k < k1; ++k) g[gdst_list[k]] = a;
         return;
