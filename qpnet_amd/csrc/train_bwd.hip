@@ -1085,26 +1085,6 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
     wgrad3_body<BMODE, MPW, NT, TWO_A, DB>(w, nch, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// The three contractions that wait for the whole layer backward -- dW1 (matrix-core heavy), the residual 1x1 (memory-bound) and the causal
-// table (one workgroup per CU on its own) -- as ONE launch: flat block index -> (contraction, chunk, layer, column group), the long dW1
-// workgroups first.  As separate launches on two streams they cost two stream events on the step's critical path (7-10 us each, more than
-// some of the kernels) and left the causal launch alone on the chip.
-struct WgTail { Wg2 w1, wr, wc; UpArgs up; int n1, nr, nc; };       // up.nfr * up.B more workgroups do the upsampling kernel's gradient (0: not here)
-__global__ __launch_bounds__(256, 2) void k_wgrad_tail(WgTail t, int nch) {
-    int b = blockIdx.x;
-    if (b < t.n1) { wgrad3_body<3, 2, 11, false, false>(t.w1, nch, b % nch, b / nch, 0); return; }
-    b -= t.n1;
-    if (b < t.nr) { wgrad3_body<2, 1, 4, true, false>(t.wr, nch, b % nch, b / nch, 0); return; }
-    b -= t.nr;
-    if (b < t.nc) {
-        const int yz = b / nch;
-        wgrad3_body<4, 1, 8, true, false>(t.wc, nch, b % nch, yz % t.wc.nlayers, yz / t.wc.nlayers);
-        return;
-    }
-    b -= t.nc;
-    up_bwd_body(t.up, b % t.up.nfr, b / t.up.nfr, threadIdx.x, 256);
-}
-
 #ifndef QPN_WGRAD_MINW
 #define QPN_WGRAD_MINW 2
 #endif
@@ -1554,31 +1534,10 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         return w;
     };
     auto launch_causal = [&](hipStream_t st) { if (bw.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, st); };
-    // ---- everything that waits for the whole layer backward as ONE launch (k_wgrad_tail): no fork / join around it
-    bool tail_fused = false, up_in_tail = false;
-    // [measured: 1146 steps/s against 1205 with the launches on two streams -- one register budget (247 VGPRs, two workgroups per CU) for all
-    //  roles, and the dW1 workgroups fill every slot first, so the others no longer run beside them.  Opt-in: QPN_WGRAD_TAIL=1]
-    if (!qpn_prof_active() && mid == L && bw.g_cw >= 0 && getenv("QPN_WGRAD_TAIL") && atoi(getenv("QPN_WGRAD_TAIL")) == 1) {
-        WgTail t;
-        t.w1 = build_w1(); t.wr = build_wr(); t.wc = build_causal();
-        if (wgrad3_fits<3, 2, 11>(t.w1) && wgrad3_fits<2, 1, 4>(t.wr) && t.wr.A2 && wgrad3_fits<4, 1, 8>(t.wc) && t.wc.A2 && !getenv("QPN_WGRAD_GENERIC")) {
-            tail_fused = true;
-            up_in_tail = up_side;                                             // (the early reduction has zeroed the slots it adds to)
-            if (overlap) { QPN_HIP(hipEventRecord(ev_join, side)); QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0)); }     // the side stream's work ended under the layer backward
-            else launch_skip_post(stream);
-            t.n1 = nch * t.w1.nlayers; t.nr = nch * t.wr.nlayers; t.nc = nch * t.wc.nlayers * t.wc.ncol_groups;
-            t.up = up_args(p, bw); if (!up_in_tail) t.up.nfr = 0;
-            size_t lds = wgrad3_lds<2, 11>(); if (wgrad3_lds<1, 4>() > lds) lds = wgrad3_lds<1, 4>(); if (wgrad3_lds<1, 8>() > lds) lds = wgrad3_lds<1, 8>();
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            qpn_prof_mark(PG_LAYER_BWD, stream);
-            hipLaunchKernelGGL(k_wgrad_tail, dim3((unsigned)(t.n1 + t.nr + t.nc + t.up.nfr * t.up.B)), dim3(256), lds, stream, t, nch);
-        }
-    }
-    if (tail_fused) {
-        if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
-        qpn_prof_mark(PG_WGRAD, stream);
-        return qpn_launch_grad_tail(p, bw, stream, early_reduce, up_in_tail);
-    }
+    // [One launch for everything that waits for the whole layer backward (dW1 + dWr + causal table + upsampling kernel as roles of one kernel)
+    //  was tried: 1146 steps/s against 1205.  dW1 is a 247-register kernel (159 VGPRs + 88 accumulators): two of its workgroups fill a CU's
+    //  register file, nothing runs beside them -- which is also why kernels launched next to it on the side stream start when it ends.  The
+    //  causal table as an LDS histogram (27 us, as long as the one-hot MFMA contraction it would replace) did not pay either.]
     // the causal table's contraction (256 workgroups, latency-bound) next to dW1 as well: the side chain up_bwd + dWr + causal is as long as dW1
     const bool causal_side = overlap && getenv("QPN_CAUSAL_SIDE") && atoi(getenv("QPN_CAUSAL_SIDE")) == 1;
     const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
