@@ -180,6 +180,28 @@ def test_train_oracle_pinned_to_reference_autograd(golden_dir):
     np.testing.assert_allclose(flat[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
 
 
+def test_train_torch_oracle_pinned_to_reference_autograd(golden_dir):
+    """oracle/train_torch.py (the torch-CPU restatement bench.py times as `cpu_baseline`) against the same reference fixture: loss of every
+    step, the full gradient of step 0, final weights after the Adam steps."""
+    from oracle import train_torch as TT
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES[0]
+    g = np.load(golden_dir + "/train.npz")
+    tr = TT.Trainer(cfg, synth.make_weights(cfg, wseed))
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+        if step == 0:
+            loss, grad = tr.loss_and_grad(x, h, t, d, b)
+            ref = g[name + "_grad0"]
+            assert np.abs(grad - ref).max() <= 2e-5 * np.abs(ref).max()
+            tr.opt.step()
+        else:
+            loss = tr.step(x, h, t, d, b)
+        losses.append(loss)
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(tr.flat.detach().numpy()[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
 def test_train_oracle_paper_loss_and_grad_sample(golden_dir):
     """paper-size: first-step loss and the strided gradient sample of the reference fixture"""
     from oracle import train_oracle as TO
