@@ -246,11 +246,21 @@ def cpu_baseline_train(cfg, flat, batch):
     x, h, t, d, b = batch
     tr = TT.Trainer(cfg, flat)
     tr.step(x, h, t, d, b)                           # warm-up (thread pools, allocator)
+    # the step's matrices are small (20 k x 64..256): more threads than ~16 make it slower on a many-core host.  One step at each
+    # count, then the best one for the sample -- `cores` is the count actually used
+    saved, sweep = torch.get_num_threads(), {}
+    for nt in sorted({c for c in (8, 16, 32, saved) if c <= saved}):
+        torch.set_num_threads(nt)
+        t0 = time.time(); tr.step(x, h, t, d, b); sweep[nt] = time.time() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     n, t0 = 0, time.time()
-    while n < 1 or (time.time() - t0 < 15.0 and n < 50):
+    while n < 1 or (time.time() - t0 < 10.0 and n < 50):
         tr.step(x, h, t, d, b); n += 1
     dt = (time.time() - t0) / n
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+    torch.set_num_threads(saved)
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": best, "kind": "port",
+            "threads_tried_s_per_step": {str(k): round(v, 3) for k, v in sweep.items()},
             "sample": "%d full-size steps (forward+CE+backward+Adam, chunk of %d samples) of the torch-CPU float32 port, after one warm-up step" % (n, x.shape[1]),
             "note": "the reference's own torch-CPU step: 1.20 s/step on 8 threads in the survey container (BASELINE.md section 2)"}
 
