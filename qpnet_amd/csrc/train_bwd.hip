@@ -1366,7 +1366,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
     const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
     const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
-    const bool zero_in_post = post_wide && !qpn_prof_active() && !(getenv("QPN_ZERO_IN_POST") && atoi(getenv("QPN_ZERO_IN_POST")) == 0);
+    const bool zero_in_post = post_wide && !(getenv("QPN_ZERO_IN_POST") && atoi(getenv("QPN_ZERO_IN_POST")) == 0);
     if (!zero_in_post) qpn_launch_zero_dx(p, bw, stream);
     if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
         constexpr int MTW = 5;
