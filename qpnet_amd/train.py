@@ -66,12 +66,15 @@ def ensure_flat(model, dev):
 
 
 def _split_like(model, gflat):
-    out, o = [], 0
-    for p in model_params(model):
-        n = p.numel()
-        out.append(gflat[o:o + n].view(p.shape))
-        o += n
-    return out
+    """views of the flat gradient, one per parameter: ONE split call + a reshape for the tensors that are not 1-D (slicing and viewing
+    each of the 90 by hand was 0.27 ms of the backward's host time)."""
+    params = model_params(model)
+    c = model.__dict__.get("_qpn_split")
+    if c is None or c[0] is not params:
+        c = (params, [p.numel() for p in params], [tuple(p.shape) if p.dim() != 1 else None for p in params])
+        model.__dict__["_qpn_split"] = c
+    pieces = gflat.split_with_sizes(c[1])
+    return [g if shp is None else g.view(shp) for g, shp in zip(pieces, c[2])]
 
 
 def _flat_grad_of(params):
