@@ -514,7 +514,7 @@ def main():
             # decode_batch_size is the caller's choice (--batch_size, src/bin/qpnet_decode.py:52): the chip full (48 five-role groups x 5 CUs)
             # and beyond (a group steps two utterances alternately; plan reported)
             out["decode"]["larger_batches"] = {}
-            for Bx in (48, 49, 96):
+            for Bx in (48, 49, 64, 96):
                 a6 = copy.copy(a3); a6.batch = Bx; a6.steps, a6.warmup = 1, 0
                 d6 = run_decode(a6, rank, local, world)
                 out["decode"]["larger_batches"]["batch%d" % Bx] = {"value": d6["value"], "unit": d6["unit"], "ms_per_step": d6["ms_per_step"],

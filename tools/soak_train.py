@@ -13,10 +13,11 @@ bts = [[torch.from_numpy(np.ascontiguousarray(a)).to(cuda) for a in hb[:4]] for 
 maxds = [int(np.ceil(hb[3]).max()) for hb in hbs]
 losses = []
 t0 = time.time()
-for i in range(3000):
+NSTEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for i in range(NSTEPS):
     k = i % 4
-    l = tr.step(*bts[k], hbs[k][4], want_loss=(i % 250 == 0), maxd=maxds[k])
+    l = tr.step(*bts[k], hbs[k][4], want_loss=(i % (NSTEPS // 12) == 0), maxd=maxds[k])
     if l is not None: losses.append(l); print(i, round(l, 4), flush=True)
 torch.cuda.synchronize()
-print("3000 steps in %.1f s; losses %s" % (time.time() - t0, [round(x, 3) for x in losses]))
+print("%d steps in %.1f s; losses %s" % (NSTEPS, time.time() - t0, [round(x, 3) for x in losses]))
 assert all(np.isfinite(losses)) and losses[-1] < losses[0]
