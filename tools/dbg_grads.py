@@ -1,5 +1,7 @@
+# dev: per-parameter gradient error of the drop-in module's autograd backward against the numpy oracle (paper size) -- which weight
+# gradient a kernel change broke:  python tools/dbg_grads.py
 import numpy as np, torch, sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from qpnet_amd import synth
 from qpnet_amd.config import PAPER
 import util
