@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {         
 #endif
 template <int BMODE, int MPW, int NT, bool TWO_A>
 static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t stream) {
-    // the 256 x 64 one-array launches (post-net, skip 1x1) sit two registers above the three-workgroups-per-CU line: ask for it
+    // the 256 x 64 one-array launches (post-net pair, skip 1x1) are 512 workgroups = two per CU: the allocation may use half a SIMD's registers
+    // (round 2 asked for a third of it -- three workgroups per CU; with the staging addresses hoisted that cap spills 80-150 B per lane)
     constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? QPN_WGRAD_MINW : 1;
     static const int db = getenv("QPN_WGRAD_DB") ? atoi(getenv("QPN_WGRAD_DB")) : 0;         // bit mask by BMODE (dev knob)
     constexpr bool DB_OK = MPW * NT >= 16;         // (a 64 x 64 block has 4 MFMAs per k-step: nothing to hide the staging under)
