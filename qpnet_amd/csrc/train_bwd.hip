@@ -1093,7 +1093,7 @@ static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t strea
     // the 256 x 64 one-array launches (post-net pair, skip 1x1) are 512 workgroups = two per CU: the allocation may use half a SIMD's registers
     // (round 2 asked for a third of it -- three workgroups per CU; with the staging addresses hoisted that cap spills 80-150 B per lane)
     constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? QPN_WGRAD_MINW : 1;
-    static const int db = getenv("QPN_WGRAD_DB") ? atoi(getenv("QPN_WGRAD_DB")) : 0;         // bit mask by BMODE (dev knob)
+    const int db = getenv("QPN_WGRAD_DB") ? atoi(getenv("QPN_WGRAD_DB")) : 0;                // bit mask by BMODE (dev knob; read per call: the tests flip it)
     constexpr bool DB_OK = MPW * NT >= 16;         // (a 64 x 64 block has 4 MFMAs per k-step: nothing to hide the staging under)
     if (lds > 64 * 1024) {
         (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

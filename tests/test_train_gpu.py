@@ -150,6 +150,36 @@ def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
     assert np.abs(grads[0] - grads[1]).max() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("knobs", [{"QPN_TRAIN_SERIAL": "1"}, {"QPN_UP_SIDE": "0"}, {"QPN_REDUCE_EARLY": "0"}, {"QPN_POST_WGRAD_PAIR": "0"},
+                                   {"QPN_ZERO_IN_POST": "0"}, {"QPN_WR_SIDE": "0"}, {"QPN_CAUSAL_SIDE": "1"}, {"QPN_WGRAD_DB": "14"}, {"QPN_EVENT_FENCE": "1"}],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_backward_launch_arrangements_agree(knobs, cuda, monkeypatch):
+    """Where the backward's launches run (side stream or not, early reduction, paired post-net contraction, zeroing inside k_post_bwd_w, the
+    double-buffered weight-gradient variant ...) is a set of environment knobs: every arrangement yields the default one's gradient up to the
+    order of float atomics."""
+    import torch
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 23)
+    x, h, t, d, b = synth.train_inputs(cfg, 3000, 67, 30000)
+    BL = int(b[0])
+
+    def grad():
+        m = util.build_model(cfg, flat, cuda).train()          # a fresh native handle: QPN_EVENT_FENCE is read when its events are created
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        logits = m(xt, ht, dt, bt)
+        loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+        loss.backward()
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy(), float(loss)
+
+    g0, l0 = grad()
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g1, l1 = grad()
+    assert abs(l0 - l1) < 1e-6
+    assert np.abs(g0 - g1).max() <= 1e-5 * np.abs(g0).max()
+
+
 def test_full_size_step_vs_oracle(cuda):
     """BASELINE config[2] size (paper-size model, batch_length 20000 -> one chunk of ~20.7 k samples): loss within the
     north_star tolerance (1e-4) and every gradient tensor against the numpy oracle's hand-derived backward."""
