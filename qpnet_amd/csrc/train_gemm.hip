@@ -276,7 +276,12 @@ struct TArgs {
     int row0A[TR_MAXL], row0B[TR_MAXL], R[TR_MAXL], goff[TR_MAXL], gbias[TR_MAXL], tap_off[TR_MAXL], dil[TR_MAXL];
 };
 
-template <int BMODE>
+// Staging as in k_wgrad3 (train_bwd.hip; in-kernel stamps there): a 16-row stage that lies inside one batch item and before the chunk's end
+// takes ONE uniform base per operand plus per-thread offsets; only ADDRESSES are computed under the uniform branch, the loads are issued once
+// behind it and the loaded registers are not touched (row masks, the two-array sum, ReLU) before the stage goes to LDS -- the first form selected
+// `row valid ? v : 0` right behind each load, i.e. five s_waitcnt vmcnt(0) and ~650 instructions of 64-bit row arithmetic in front of every
+// stage's 32 MFMAs.  TWO_A is a template flag for the same reason (a run-time `if (A2)` around a load makes the loaded value a phi).
+template <int BMODE, bool TWO_A>
 __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_tn(TArgs g) {
     extern __shared__ float sm[];
     float* As = sm;                              // [2][GKT * 128]
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_tn(TArgs g) {
     const float* B1 = g.b1 + (size_t)y * g.b_ls;
     const int* tap = (BMODE == BM_GATHER && g.tap && g.tap_off[y] >= 0) ? g.tap + g.tap_off[y] : nullptr;
     // B column source of this thread (fixed for the whole contraction)
-    int bkind = 0; const float* bbase = B1 + bn; int bstride = g.ldb; bool b_ok = bn < g.N;
+    int bkind = 0; bool b_ok = bn < g.N; const float* bbase = B1 + (b_ok ? bn : 0); int bstride = g.ldb;       // (a column past N: loaded from column 0, zeroed at the LDS write)
     if (BMODE == BM_GATHER) {
         if (bn < g.C) { bkind = 0; bbase = B1 + bn; bstride = g.C; }
         else if (bn < 2 * g.C) { bkind = 1; bbase = B1 + (bn - g.C); bstride = g.C; }
@@ -304,35 +309,72 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_tn(TArgs g) {
     }
     const int row0A = g.row0A[y], row0B = g.row0B[y], dil = g.dil[y];
     constexpr int PT = GKT / 8;
-    float4 ra[PT], rb[PT];
-    auto load = [&](long k0) {
+    float4 ra[PT], ra2[PT], rb[PT];
+    int tpv[PT];                                 // gather rows of the NEXT stage's x_past columns (loaded one stage ahead)
+    unsigned okm = 0;                            // bit p: staged row p is a real row
+    const bool use_tap = BMODE == BM_GATHER && bkind == 1 && tap;
+    const int Rli = Rl > 0 ? Rl : 1;
+    auto stage_pos = [&](long k0, int& bi0, int& i0) {          // uniform
+        if (g.nb > 1) { bi0 = (int)(k0 / Rli); i0 = (int)(k0 - (long)bi0 * Rli); } else { bi0 = 0; i0 = (int)k0; }
+        return k0 + GKT <= kend && i0 + GKT <= Rli;
+    };
+    auto taps = [&](long k0) {                   // every thread loads (a per-thread condition around the load would put a wait behind it)
+        if (BMODE != BM_GATHER || !tap) return;
+        int bi0, i0; const bool fast = stage_pos(k0, bi0, i0);
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            long kk = k0 + sk + 8 * p;
-            const bool ok = kk < kend;
-            kk = ok ? kk : kend - 1;
-            const int bi = g.nb > 1 ? (int)(kk / Rl) : 0; const int i = (int)(kk - (long)bi * Rl);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
-            if (a_ok) {
-                const size_t o = ((size_t)bi * g.rowsA + row0A + i) * g.lda + am;
-                v = *(const float4*)(A + o);
-                if (A2) { const float4 v2 = *(const float4*)(A2 + o); v.x += v2.x; v.y += v2.y; v.z += v2.z; v.w += v2.w; }
+            long kk = k0 + sk + 8 * p; kk = kk < kend ? kk : kend - 1;
+            int bi = bi0, i = i0 + sk + 8 * p;
+            if (!fast) { bi = g.nb > 1 ? (int)(kk / Rli) : 0; i = (int)(kk - (long)bi * Rli); }
+            tpv[p] = tap[(size_t)bi * g.rowsB + row0B + i];
+        }
+    };
+    auto load = [&](long k0) {
+        const float* pa[PT]; const float* pb[PT];
+        int bi0, i0;
+        if (stage_pos(k0, bi0, i0)) {
+            const float* Ast = A + ((size_t)bi0 * g.rowsA + row0A + i0) * g.lda + (a_ok ? am : 0);
+            const float* Bst = bbase + (size_t)bi0 * g.rowsB * bstride;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                pa[p] = Ast + (size_t)(sk + 8 * p) * g.lda;
+                const int row = use_tap ? tpv[p] : (BMODE == BM_GATHER && bkind == 1) ? row0B + i0 + sk + 8 * p - dil : row0B + i0 + sk + 8 * p;
+                pb[p] = Bst + (size_t)row * bstride;
             }
-            if (b_ok) {
-                int row = row0B + i;
-                if (BMODE == BM_GATHER && bkind == 1) row = tap ? tap[(size_t)bi * g.rowsB + row] : row - dil;
-                w = *(const float4*)(bbase + ((size_t)bi * g.rowsB + row) * bstride);
-                if (BMODE == BM_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+            okm = ~0u;
+        } else {
+            okm = 0;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                long kk = k0 + sk + 8 * p;
+                const bool ok = kk < kend;
+                kk = ok ? kk : kend - 1;
+                const int bi = g.nb > 1 ? (int)(kk / Rli) : 0; const int i = (int)(kk - (long)bi * Rli);
+                pa[p] = A + ((size_t)bi * g.rowsA + row0A + i) * g.lda + (a_ok ? am : 0);
+                const int row = use_tap ? tpv[p] : (BMODE == BM_GATHER && bkind == 1) ? row0B + i - dil : row0B + i;
+                pb[p] = bbase + ((size_t)bi * g.rowsB + row) * bstride;
+                okm |= ok ? 1u << p : 0u;
             }
-            ra[p] = (ok && a_ok) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[p] = (ok && b_ok) ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            ra[p] = *(const float4*)pa[p];
+            if (TWO_A) ra2[p] = *(const float4*)(pa[p] + (A2 - A));
+            rb[p] = *(const float4*)pb[p];
         }
     };
     auto put = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
-            *(float4*)(As + buf * (GKT * GM) + (sk + 8 * p) * GM + c4) = ra[p];
-            *(float4*)(Bs + buf * (GKT * GN) + (sk + 8 * p) * GN + c4) = rb[p];
+            const bool ok = (okm >> p) & 1u;
+            float4 v = ra[p], w = rb[p];
+            if (TWO_A) { v.x += ra2[p].x; v.y += ra2[p].y; v.z += ra2[p].z; v.w += ra2[p].w; }
+            if (BMODE == BM_RELU) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+            const bool oa = ok && a_ok, ob = ok && b_ok;
+            v.x = oa ? v.x : 0.f; v.y = oa ? v.y : 0.f; v.z = oa ? v.z : 0.f; v.w = oa ? v.w : 0.f;      // (component-wise: see k_wgrad3)
+            w.x = ob ? w.x : 0.f; w.y = ob ? w.y : 0.f; w.z = ob ? w.z : 0.f; w.w = ob ? w.w : 0.f;
+            *(float4*)(As + buf * (GKT * GM) + (sk + 8 * p) * GM + c4) = v;
+            *(float4*)(Bs + buf * (GKT * GN) + (sk + 8 * p) * GN + c4) = w;
         }
     };
     f32x16 acc[4];
@@ -342,12 +384,12 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_tn(TArgs g) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int gbias = blockIdx.x == 0 ? g.gbias[y] : -1;
     float csum = 0.f;
-    if (kbeg < kend) { load(kbeg); put(0); }
+    if (kbeg < kend) { taps(kbeg); load(kbeg); if (kbeg + GKT < kend) taps(kbeg + GKT); put(0); }
     __syncthreads();
     int buf = 0;
     for (long k0 = kbeg; k0 < kend; k0 += GKT, buf ^= 1) {
         const bool more = k0 + GKT < kend;
-        if (more) load(k0 + GKT);
+        if (more) { load(k0 + GKT); if (k0 + 2 * GKT < kend) taps(k0 + 2 * GKT); }
         const float* Aq = As + buf * (GKT * GM) + (lane >> 5) * GM + 32 * wave + (lane & 31);
         const float* Bq = Bs + buf * (GKT * GN) + (lane >> 5) * GN + (lane & 31);
         float an = Aq[0], bn0 = Bq[0], bn1 = Bq[32], bn2 = Bq[64], bn3 = Bq[96];       // one k-step of lookahead in registers
@@ -404,9 +446,11 @@ static void launch_nn(const GArgs& g, int ntiles_n, hipStream_t stream) {
 }
 template <int BMODE>
 static void launch_tn(const TArgs& g, int nlayers, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_tn<BMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TN); attr = true; }
-    hipLaunchKernelGGL((k_gemm_tn<BMODE>), dim3((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, nlayers * g.nsplit), dim3(256), LDS_TN, stream, g);
+    (void)hipFuncSetAttribute((const void*)k_gemm_tn<BMODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TN);      // (per device: set on every launch)
+    (void)hipFuncSetAttribute((const void*)k_gemm_tn<BMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TN);
+    const dim3 grid((g.N + GN - 1) / GN, (g.M + GM - 1) / GM, nlayers * g.nsplit);
+    if (g.a2) hipLaunchKernelGGL((k_gemm_tn<BMODE, true>), grid, dim3(256), LDS_TN, stream, g);
+    else hipLaunchKernelGGL((k_gemm_tn<BMODE, false>), grid, dim3(256), LDS_TN, stream, g);
 }
 
 static GArgs gbase(const TrainParams& p) {
