@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
         const int n = g.row_base + m;
         rtap[p] = any_tap ? (g.tap ? g.tap[(size_t)b * g.tap_bs + n] : n - g.dil) : 0;
     }
-    float4 ra[PA];
+    float4 ra[PA], ra2[PA];       // (ra2: the second array of AL_SUM2)
+    bool ra_valid = true;         // the staged columns are real ones.  Sum / ReLU / zeroing happen when the chunk goes to LDS: applied to the
+                                  // just-loaded registers they put an s_waitcnt vmcnt in front of the chunk's MFMAs (AL_SUM2, AL_RELU did)
     // per-thread row pointers of the (up to) three side-by-side A arrays, computed once: the chunk loop only adds the chunk's
     // column offset (the row * ld products and the tap / own-row choice used to sit in front of every chunk's loads)
     const float* pa0[PA]; const float* pa1[PA]; const float* pa2[PA];
@@ -100,15 +102,15 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
     // (macros with literal row indices, not a lambda or a loop: hipcc keeps arrays it cannot fully scalarise in scratch memory)
 #define G_LOADA_ROW(P) { \
             const float* ptr_ = (s_ == 0 ? pa0[P] : s_ == 1 ? pa1[P] : pa2[P]) + off_; \
-            float4 v = *(const float4*)ptr_; \
-            if (AL == AL_SUM2) { const float4 w = *(const float4*)(ptr_ + d2); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; } \
-            if (AL == AL_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
-            ra[P] = valid_ ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+            const float4 v_ = *(const float4*)ptr_; \
+            if (AL == AL_SUM2) ra2[P] = *(const float4*)(ptr_ + d2); \
+            ra[P] = (AL == AL_PLAIN && !valid_) ? make_float4(0.f, 0.f, 0.f, 0.f) : v_; }      /* (plain loads: hipcc schedules this select behind the MFMAs by itself) */
 #define G_LOADA(kc) { \
         const int k0_ = (kc) * GK; \
         const int s_ = k0_ < g.a_kend[0] ? 0 : k0_ < g.a_kend[1] ? 1 : 2; \
         const int kl_ = k0_ - (s_ ? g.a_kend[s_ - 1] : 0); \
         const bool valid_ = kl_ + ak4 < g.a_kvalid[s_]; \
+        ra_valid = valid_; \
         ptrdiff_t off_ = valid_ ? kl_ : -ak4;              /* columns past the valid ones: a safe address (column 0), value zeroed */ \
         if (g.a_rep_len) {                                 /* a[0] repeats every a_rep_len columns (the L gate arrays of the skip sum) */ \
             const int kk_ = kl_ + ak4, l_ = kk_ / g.a_rep_len; \
@@ -129,7 +131,11 @@ __global__ __launch_bounds__(256) GEMM_WAVES void k_gemm_nn(GArgs g) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             float* d = ad + RA * p * G_LDA;
-            d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+            float4 v = ra[p];
+            if (AL == AL_SUM2) { v.x += ra2[p].x; v.y += ra2[p].y; v.z += ra2[p].z; v.w += ra2[p].w; }
+            if (AL == AL_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            const bool keep = AL == AL_PLAIN || ra_valid;
+            d[0] = keep ? v.x : 0.f; d[1] = keep ? v.y : 0.f; d[2] = keep ? v.z : 0.f; d[3] = keep ? v.w : 0.f;
         }
         *(float4*)(bd) = rb0; *(float4*)(bd + 8 * G_LDB) = rb1;
         if (PB > 2) { *(float4*)(bd + 16 * G_LDB) = rb2; *(float4*)(bd + 24 * G_LDB) = rb3; }
