@@ -16,7 +16,7 @@ import torch
 from . import _lib
 
 
-# Walking a module tree for its parameters costs ~0.15 ms of Python per call (90 tensors, 60 sub-modules), and the reference-style
+# Walking a module tree for its parameters costs ~0.15 ms of Python per call (120 tensors, 60 sub-modules), and the reference-style
 # loop needs the list three times per step.  The list is cached per model and dropped whenever ANY parameter is registered on any module
 # (torch's global registration hook: `m.x = nn.Parameter(...)`, `register_parameter`); storages replaced by .to()/.cuda() keep the
 # Parameter objects and are caught by ensure_flat's pointer check.
@@ -67,7 +67,7 @@ def ensure_flat(model, dev):
 
 def _split_like(model, gflat):
     """views of the flat gradient, one per parameter: ONE split call + a reshape for the tensors that are not 1-D (slicing and viewing
-    each of the 90 by hand was 0.27 ms of the backward's host time)."""
+    each of the 120 by hand was 0.27 ms of the backward's host time)."""
     params = model_params(model)
     c = model.__dict__.get("_qpn_split")
     if c is None or c[0] is not params:
@@ -217,7 +217,7 @@ def adam_state_from_torch(model, sd, flat):
 class FlatAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (lr, betas, eps, weight_decay; no amsgrad) as ONE kernel over the model's flat parameter
     buffer -- a one-line swap for `torch.optim.Adam(model.parameters(), lr=...)` in the reference loop
-    (src/bin/qpnet_train.py:426-429,531), whose ~50-tensor foreach update costs 0.9 ms per step on this GPU.
+    (src/bin/qpnet_train.py:426-429,531), whose 120-tensor foreach update costs 0.9 ms per step on this GPU.
     Gradients are read from `p.grad`: when they are consecutive views of one flat buffer (what the autograd backward hands
     out) no gather happens.  state_dict()/load_state_dict() use torch.optim.Adam's own layout, so checkpoints written by
     the reference trainer resume here and vice versa."""
