@@ -1146,7 +1146,7 @@ static bool wgrad3_any(const Wg2& w0, int nch, hipStream_t stream) {
     return wgrad3_any_(w0, nch, stream);
 }
 static bool wgrad3_any_(const Wg2& w, int nch, hipStream_t stream) {
-    if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream);                                        // causal table: C = 64, 128-class groups
+    if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream) || launch_wgrad3<4, 1, 4>(w, nch, stream);      // causal table: C = 64, 128- or 64-class groups
     if (getenv("QPN_WGRAD_GENERIC")) return false;
     switch (w.bmode) {
     case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 / 32, n_aux 33..48
@@ -1528,7 +1528,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
     auto build_causal = [&]() {      // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
         Wg2 w = wbase;
-        w.nlayers = 2; w.ncol_groups = Q / 128; w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
+        w.nlayers = 2; w.ncol_groups = Q / ((Q % 64 == 0 && !getenv("QPN_CAUSAL_NG128")) ? 64 : 128);     /* 64-class groups: 512 workgroups, two per CU (29 -> 25 us) */ w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
         w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
         w.N = Q; w.Nvalid = Q; w.rowsB = N1 + 1; w.ldb = 0; w.ldc = Q;
         for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
