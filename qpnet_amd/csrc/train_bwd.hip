@@ -384,8 +384,14 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 // gradient (+ residual path), the pitch-tap part as one 256-byte row per tap row -- a plain store for the fixed blocks (unique
 // writer), ONE full-row float-atomic instruction per row for the adaptive blocks (the accumulator layout gave 64-byte strips
 // of four different rows per instruction) -- and the aux columns as row-contiguous atomics.
+// dev aid (build with -DQPN_ENABLE_STAMPS, run with QPN_BWDP_STAMPS=1): s_memtime of wave 0 at the phase boundaries of a few workgroups
+#ifdef QPN_ENABLE_STAMPS
+#define BWDP_STAMP(i) do { if (stamps && lane == 0 && wave == 0 && (blockIdx.x & 63) == 5 && (i) < 64) stamps[(blockIdx.x >> 6) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BWDP_STAMP(i) do { } while (0)
+#endif
 template <int NTK, bool LAST>      // NTK = Ktp / 16 column tiles of the input gradient (11 for n_resch 64, n_aux 39)
-__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles, float* dummy) {     // flags: bit 1 XCD swizzle
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles, float* dummy, long long* stamps) {     // flags: bit 1 XCD swizzle
     constexpr int C = 64, C4 = C / 4;
     constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     constexpr int NJ = (NTK + 3) / 4;                              // column tiles of the second contraction per wave
@@ -429,11 +435,13 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     auto load_rows = [&](int t) {
         const int n = ly.s_out + t * 16 + srow;
         const int nn = n < N1 ? n : N1 - 1;
-        const size_t o = (size_t)nn * C + 4 * sc4;
+        // 32-bit element offsets (one batch item's rows x channels fit easily; the batch part is in the bases): one full-rate multiply and
+        // the SAME offset register behind four uniform bases, instead of a 64-bit multiply-add and a 64-bit add per load
+        const unsigned o = __umul24((unsigned)nn, (unsigned)C) + 4u * sc4;
         ra = *(const float4*)(DAin + o); rb2 = *(const float4*)(DBin + o);          // (rows of the last layer: finite garbage, not used)
         rsg = *(const float4*)(SG + o); rth = *(const float4*)(TH + o);
         const int nw = nn >= win0 ? nn - win0 : 0;
-        rdg = *(const float4*)(DGS + (size_t)nw * p.LC + 4 * sc4);
+        rdg = *(const float4*)(DGS + (__umul24((unsigned)nw, (unsigned)p.LC) + 4u * sc4));
     };
     auto store_rows = [&](int t, float* B) {
         const int n = ly.s_out + t * 16 + srow;
@@ -456,16 +464,20 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * wave + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
     };
+    BWDP_STAMP(0);
     load_rows(t_first);
     load_taps(t_first, tprow);
     store_rows(t_first, sm);
+    BWDP_STAMP(1);
     const int arow = lane & 15, ak = lane >> 4;
     const int c = 16 * wave + (lane & 15);
     for (int ti = 0; ti < t_count; ++ti) {
         const int t = t_first + ti, n0 = ly.s_out + t * 16;
         float* Dx = sm + (ti & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
         { const int tn = t + 1 < t_last ? t + 1 : t_last; load_rows(tn); load_taps(tn, tpnext); }      // (past the range: a harmless reload)
+        BWDP_STAMP(2 + 8 * ti);
         TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz / Os free (readers: previous trip)
+        BWDP_STAMP(3 + 8 * ti);
         // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
         float xa[4][4];
 #pragma unroll
@@ -489,7 +501,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
             Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
             Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
         }
+        BWDP_STAMP(4 + 8 * ti);
         TR_LDS_BARRIER();
+        BWDP_STAMP(5 + 8 * ti);
         // ---- d[x_cur | x_past | aux] = dZ . W1
         float za[8][4];
 #pragma unroll
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = zrow + 4 * k;
-                float* d = DZg + (size_t)(n0 + r) * 2 * C + zc2;
+                float* d = DZg + (__umul24((unsigned)(n0 + r), 2u * C) + zc2);
                 d = n0 + r < N1 ? d : dmy + zc2;
                 *(float2*)d = *(const float2*)(Dz + (size_t)r * ldz + zc2);
             }
@@ -525,26 +539,30 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
             for (int i = 0; i < 4; ++i) Os[(size_t)(4 * (lane >> 4) + i) * ldo + 16 * nt + (lane & 15)] = acc[j][i];
         }
+        BWDP_STAMP(6 + 8 * ti);
         TR_LDS_BARRIER();
+        BWDP_STAMP(7 + 8 * ti);
         // ---- outputs as whole rows: wave w owns rows 4w .. 4w+3, lane = channel
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * wave + i, n = n0 + r;
             const bool in = n < N1;
             const float own = Os[(size_t)r * ldo + lane] + Dx[(size_t)r * ldx + lane];                 // + residual path
-            float* da = DAout + (size_t)n * C + lane;
+            float* da = DAout + (__umul24((unsigned)n, (unsigned)C) + lane);
             *(in ? da : dmy + lane) = own;
             const float past = Os[(size_t)r * ldo + C + lane];
-            float* db = DBout + (size_t)tprow[i] * C + lane;
+            float* db = DBout + (__umul24((unsigned)tprow[i], (unsigned)C) + lane);
             db = in ? db : dmy + 128 + lane;
             if (ly.adaptive) atomicAdd(db, past);                                                       // gather backward (collisions)
             else *db = past;                                                                            // unique writer
             if (lane < Ap) {                                                                            // (Ap <= 64)
-                float* dh = DH + (size_t)n * Ap + lane;
+                float* dh = DH + (__umul24((unsigned)n, (unsigned)Ap) + lane);
                 atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);               // unique writer per layer, layers in order
             }
         }
+        BWDP_STAMP(8 + 8 * ti);
         store_rows(t + 1 < t_last ? t + 1 : t_last, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
+        BWDP_STAMP(9 + 8 * ti);
 #pragma unroll
         for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
     }
@@ -1502,8 +1520,26 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
             const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(176)) * sizeof(float);
             (void)hipFuncSetAttribute(l == L - 1 ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
-            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            long long* d_st = nullptr;
+#ifdef QPN_ENABLE_STAMPS
+            static long long* d_stamps = nullptr;
+            if (getenv("QPN_BWDP_STAMPS")) { if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * 64 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream); d_st = d_stamps; }
+#endif
+            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows, d_st);
+            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows, d_st);
+#ifdef QPN_ENABLE_STAMPS
+            if (d_st && l == atoi(getenv("QPN_BWDP_STAMPS"))) {      // print one layer's launch (cycles relative to the first stamp of each sampled workgroup)
+                static int printed = 0;
+                long long hs[16 * 64];
+                (void)hipStreamSynchronize(stream);
+                (void)hipMemcpy(hs, d_st, sizeof(hs), hipMemcpyDeviceToHost);
+                if (printed++ == 8) for (int w = 0; w < 8; ++w) {
+                    fprintf(stderr, "bwdp stamps layer %d wg %d:", l, 64 * w + 5);
+                    for (int i = 0; i < 34; ++i) fprintf(stderr, " %lld", hs[w * 64 + i] ? hs[w * 64 + i] - hs[w * 64] : -1LL);
+                    fprintf(stderr, "\n");
+                }
+            }
+#endif
         } else if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
             const size_t lds1 = lds_layer / MT;
             if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);

@@ -266,9 +266,10 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
     auto load_tap = [&](int t) { const int n = ly.s_out + t * 16 + srow; tp = taps[n < N1 ? n : N1 - 1]; };
     auto load_rows = [&](int t) {
         const int n = ly.s_out + t * 16 + srow, nn = n < N1 ? n : N1 - 1;
-        rc = *(const float4*)(Xin + (size_t)nn * C + 4 * sc4);
-        rp = *(const float4*)(Xin + (size_t)tp * C + 4 * sc4);
-        rx = *(const float4*)(hup + (size_t)nn * Ap + (aux_real ? 4 * sc4 : 0));
+        // (32-bit element offsets behind uniform bases: see k_layer_bwd_p)
+        rc = *(const float4*)(Xin + (__umul24((unsigned)nn, (unsigned)C) + 4u * sc4));
+        rp = *(const float4*)(Xin + (__umul24((unsigned)tp, (unsigned)C) + 4u * sc4));
+        rx = *(const float4*)(hup + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
     };
     auto store_rows = [&](int t, float* As) {
         const bool in = ly.s_out + t * 16 + srow < N1;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
     };
     auto store_out = [&](const float* T, float* dst, int n0, bool live) {      // a [16][64] LDS tile -> rows n0.. of a [N1][64] array, whole rows
         const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
-        float* d0 = dst + ((size_t)n0 + orow) * C + oc2;
+        float* d0 = dst + (__umul24((unsigned)(n0 + orow), (unsigned)C) + oc2);
         float* d1 = d0 + 8 * C;
         d0 = (live && n0 + orow < N1) ? d0 : dmy;
         d1 = (live && n0 + orow + 8 < N1) ? d1 : dmy + C;
