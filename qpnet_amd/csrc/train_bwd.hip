@@ -1510,7 +1510,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     const int cut_row = split ? tr_split_cut(p) : 0;
     const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
     if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
-    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && !split && !(getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 0);
+    const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
+    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && off32 && !split && !(getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 0);
     const int wg_per_cu = getenv("QPN_LAYER_BWD_WGS") ? atoi(getenv("QPN_LAYER_BWD_WGS")) : 2;
     for (int l = L - 1; l >= 0; --l) {
         const TrLayer& ly = p.layers[l];

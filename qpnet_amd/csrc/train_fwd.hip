@@ -850,7 +850,7 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
         const int cut_row = split ? tr_split_cut(p) : 0;
         if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
         // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
-        const bool persist = C == 64 && p.Ktp == 176 && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);
+        const bool persist = C == 64 && p.Ktp == 176 && p.N1 < (1 << 24) && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);      // (N1 < 2^24: 32-bit element offsets of one batch item)
         const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
         for (int l = 0; l < p.L; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
