@@ -1124,6 +1124,7 @@ template <int BMODE, int MPW, int NT>
 static bool wgrad3_fits(const Wg2& w) {
     const int Ng = w.N / w.ncol_groups;
     if (w.bmode != BMODE) return false;
+    if (w.rowsB >= (1 << 24) || (int64_t)w.rowsB * (w.C > w.ldb ? w.C : w.ldb) >= (1ll << 32)) return false;      // 24 x 24-bit row x stride products of the fast staging path
     if (w.M != 64 * MPW || Ng != 16 * NT || w.N % w.ncol_groups || (w.Nvalid != w.N && (w.ncol_groups != 1 || w.Nvalid % 4))) return false;
     if (BMODE == 3 && (w.ldb != w.C || w.ncol_groups != 1 || (w.C % 4) || (w.Ap % 4) || !w.tap)) return false;
     if (BMODE == 3) for (int l = 0; l < w.nlayers; ++l) if (w.tap_off[l] < 0) return false;      // the kernel loads taps unconditionally
