@@ -113,8 +113,9 @@ def test_torch_adam_on_views_matches(cuda, golden_dir):
 
 
 def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
-    """Two chunks per step (rows of both batch items flattened into the weight-gradient contraction): the
-    compile-time-tiled k_wgrad3 and the generic k_wgrad2 (QPN_WGRAD_GENERIC=1) both match the numpy oracle."""
+    """Two chunks per step (rows of both batch items flattened into the weight-gradient contraction: stages that straddle the two items take
+    the kernels' generic staging path): the compile-time-tiled k_wgrad3, the generic k_wgrad2 (QPN_WGRAD_GENERIC=1) and the GEMM path's
+    k_gemm_tn (QPN_TRAIN_GEMM=1) all match the numpy oracle."""
     import torch
     from oracle import train_oracle as TO
     from qpnet_amd.config import PAPER
@@ -130,9 +131,11 @@ def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
     _, dl = TO.ce_loss(lg, t[:, -BL:])
     og = TO.backward(cfg, flat, caches, dl)
     grads = []
-    for generic in (False, True):
-        if generic:
+    for variant in ("tile", "generic", "gemm"):        # gemm: the LDS-tiled GEMM path (k_gemm_nn / k_gemm_tn) forced on this geometry
+        if variant == "generic":
             monkeypatch.setenv("QPN_WGRAD_GENERIC", "1")
+        if variant == "gemm":
+            monkeypatch.delenv("QPN_WGRAD_GENERIC"); monkeypatch.setenv("QPN_TRAIN_GEMM", "1")
         m = util.build_model(cfg, flat, cuda).train()
         xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
         logits = m(xt, ht, dt, bt)
@@ -146,7 +149,7 @@ def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
             n = int(np.prod(shp))
             a, r = grad[o:o + n], og[o:o + n]
             assert np.abs(a - r).max() <= 2e-5 * scale + 1e-4 * np.abs(r).max(), "grad mismatch in " + k
-    # the two kernels share everything else; float atomics (upsampling / scatter grads) make runs differ in the last bits
+    # the two tile kernels share everything else; float atomics (upsampling / scatter grads) make runs differ in the last bits
     assert np.abs(grads[0] - grads[1]).max() <= 1e-5 * scale
 
 
