@@ -197,6 +197,10 @@ int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d
 #define QPN_PG_ADAM 8
 #define QPN_PG_ALLREDUCE 9     /* marked by the caller after its gradient all-reduce (qpn_train_profile_mark) */
 #define QPN_PG_COUNT 10
+/* Diagnostics of the one-launch residual stack (csrc/train_stack.hip; no reference counterpart): the first n <= 1024 control words of
+ * the work queues as the last step left them -- [1] abort raised; forward [4..6] / backward [8..10]: escalations (a workgroup published
+ * everything it held before waiting without a bound), polls spent waiting, waves that did not find their producers' flags at first look.  Synchronises the stream. */
+int qpn_train_stack_stats(qpn_handle* h, unsigned* h_out, int n, void* stream);
 int qpn_train_profile_begin(qpn_handle* h, void* stream);
 int qpn_train_profile_mark(qpn_handle* h, int group, void* stream);   /* attribute the work enqueued since the previous mark to `group` */
 int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);

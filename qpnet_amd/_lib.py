@@ -47,6 +47,7 @@ SYMBOLS = [
     ("qpn_ce_loss", _i, [_vp, _vp, _vp, _i64, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("qpn_adam_step", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
+    ("qpn_train_stack_stats", _i, [_vp, C.POINTER(C.c_uint), _i, _vp]),
     ("qpn_train_profile_begin", _i, [_vp, _vp]),
     ("qpn_train_profile_mark", _i, [_vp, _i, _vp]),
     ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),

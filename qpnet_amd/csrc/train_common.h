@@ -52,6 +52,11 @@ struct TrainParams {
     const int64_t* ce_tgt; int64_t ce_stride; float* ce_dlogits; double* ce_loss;
     int* status;
     float* scratch_rows;      // [B * 1024 workgroups][2][128] floats nobody reads: target of the persistent kernels' out-of-range row stores
+    unsigned* qctl;           // control words of the stack work queues (train_stack.hip), control words and sub-queue heads zeroed by k_train_prep; or nullptr
+    int4* qtab;               // [qtotal + 1][2] tile table of the forward queue, written by k_train_prep (tr_queue_entry_fwd); or nullptr
+    int qtotal;               // positions of a queue: sum over layers of B * qT[l]
+    int qP[TR_MAXL + 1];      // first position of layer l (forward order)
+    int qT[TR_MAXL];          // 16-row tiles per batch item in layer l
     // post-net packed blocks
     int ws_f4, p1_f4, p2_f4;          // fwd: [LC x S], [S x S], [S x Q]
     int wst_f4, p1t_f4, p2t_f4;       // bwd: [S x LC], [S x S], [Q x S]
@@ -83,6 +88,45 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
 };
+
+#define TR_QHEAD_STRIDE 1056   // words between sub-queue heads (4224 bytes: different memory channels)
+#define TR_QHDR_WORDS 17920    // control block: [1] abort, counters [4..6] forward, [8..10] backward, [1024 + (8 dir + q) * TR_QHEAD_STRIDE]: sub-queue heads
+// Work queue of the one-launch residual stack (train_stack.hip): positions = (layer, batch item, 16-row tile) in layer-major order
+struct StackQ {
+    unsigned* flags;          // [sq_fidx(position)] == epoch once the position's output rows are visible device-wide
+    unsigned* head;           // 8 sub-queue heads, TR_QHEAD_STRIDE words apart (zeroed before the launch): next ticket of each
+    unsigned* stats;          // dev counters: [0] escalations (a bounded wait ran out), [1] polls of waits, [2] waves that did not find the flags at first look
+    unsigned* abort;          // raised when a wait timed out: every workgroup stops waiting and drains
+    const int4* tab;          // tile table [total + 1][2] (entry total: the invalid tile)
+    unsigned epoch;           // never 0; a new one per forward
+    int total, nq;            // positions; sub-queues in use
+};
+
+// One entry of the forward tile table (device side of k_train_prep; read by k_stack_fwd):
+//   a = {first row n0, layer | batch item << 8 | last layer << 24 | valid << 25, first producer position, producer positions}
+//   b = {row offset of the layer's input in X (= of its sigma / tanh rows), tap table offset, row offset of the aux features, 0}
+// producers of tile (l, t): the tiles of layer l - 1 that hold the rows n0 - reach .. n0 + 15 (own rows and every row a tap can touch;
+// reach = dilation (fixed) or dilation * maxd (adaptive), reference src/nets/qpnet.py:271-306)
+__device__ __forceinline__ void tr_queue_entry_fwd(const TrainParams& p, int pos, int4& a, int4& b) {
+    const bool valid = pos < p.qtotal;
+    const int ps = valid ? pos : 0;
+    int l = 0;
+    for (int k = 1; k < p.L; ++k) l += ps >= p.qP[k] ? 1 : 0;
+    const int r = ps - p.qP[l], T = p.qT[l];
+    const int bi = r / T, t = r - bi * T;
+    const TrLayer ly = p.layers[l];
+    const int n0 = ly.s_out + 16 * t;
+    int first = 0, n = 0;
+    if (valid && l > 0) {
+        const int reach = ly.s_out - ly.s_in, s_prev = p.layers[l - 1].s_out;
+        int lo = n0 - reach; if (lo < s_prev) lo = s_prev;
+        int hi = n0 + 15; if (hi > p.N1 - 1) hi = p.N1 - 1;
+        const int t_lo = (lo - s_prev) >> 4, t_hi = (hi - s_prev) >> 4;
+        first = p.qP[l - 1] + bi * p.qT[l - 1] + t_lo; n = t_hi - t_lo + 1;
+    }
+    a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0), first, n);
+    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, 0);
+}
 
 // Host-side only: the second stream and events of the two-part time split of the layer kernels (owned by TrainState).
 // The stack is causal, so the EARLIER part of layer l needs nothing from the later part; launching the two parts of every

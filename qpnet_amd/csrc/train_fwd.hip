@@ -31,6 +31,12 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
     const int C4 = C / 4, A4 = Ap / 4;
     const int nX = N1 * C4, nH = N1 * A4;
     const int total = nX + nH + N1 * p.L;
+    if (p.qctl && blockIdx.x == 0 && b == 0 && threadIdx.x < 32) p.qctl[threadIdx.x < 16 ? threadIdx.x : 1024 + (threadIdx.x - 16) * TR_QHEAD_STRIDE] = 0u;      // abort word / counters / sub-queue heads of this step's stack queues (train_stack.hip)
+    if (p.qtab && b == 0)          // tile table of the one-launch residual stack (train_stack.hip)
+        for (int pos = blockIdx.x * 256 + threadIdx.x; pos <= p.qtotal; pos += gridDim.x * 256) {
+            int4 ea, eb; tr_queue_entry_fwd(p, pos, ea, eb);
+            p.qtab[2 * pos] = ea; p.qtab[2 * pos + 1] = eb;
+        }
     for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += gridDim.x * 256) {
         if (it < nX) {
             const int n = it / C4, c = (it - n * C4) * 4;
@@ -820,7 +826,10 @@ void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(k_train_prep, dim3(blocks, p.B), dim3(256), 0, stream, p);
 }
 
-int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t stream) {
+bool qpn_stack_fwd_fits(const TrainParams& p);
+int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stream);
+
+int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S;
     qpn_launch_prep(p, stream);
     qpn_prof_mark(PG_PREP, stream);
@@ -852,7 +861,10 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t strea
         // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
         const bool persist = C == 64 && p.Ktp == 176 && p.N1 < (1 << 24) && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);      // (N1 < 2^24: 32-bit element offsets of one batch item)
         const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
-        for (int l = 0; l < p.L; ++l) {
+        // the whole stack as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE=0 keeps a launch per layer
+        const bool stack_q = persist && !split && sq && sq->flags && p.qctl && qpn_stack_fwd_fits(p) && !getenv("QPN_FWDP_STAMPS");
+        if (stack_q) { const int rcq = qpn_launch_stack_fwd(p, *sq, stream); if (rcq) return rcq; }
+        for (int l = 0; l < p.L && !stack_q; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
             if (persist) {
                 const int tiles = (rows + 15) / 16;

@@ -7,7 +7,8 @@
 #include <algorithm>
 #include <string.h>
 
-int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, hipStream_t stream);
+int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq, hipStream_t stream);
+void qpn_stack_fill(TrainParams& p);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
@@ -37,6 +38,8 @@ struct TrainState {
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
     TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
+    unsigned* d_sq; size_t sq_pos_cap, sq_per_dir;                           // stack work queues (train_stack.hip): [16 control words | forward flags | backward flags]
+    StackQ sqf, sqb;
 };
 
 int qpn_num_cus() {
@@ -148,6 +151,7 @@ static int train_init(qpn_handle* h) {
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
+    t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -351,7 +355,7 @@ static int train_init(qpn_handle* h) {
 
 void qpn_train_destroy(TrainState* t) {
     if (!t) return;
-    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct};
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct, t->d_sq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
     if (t->ev_status) (void)hipEventDestroy(t->ev_status);
@@ -432,6 +436,27 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     p.scratch_rows = carve(nScr);
     if (t->use_gemm) t->gm.G = carve(nG);
     p.TAP = t->d_tap; p.status = t->d_status;
+    {   // stack work queues (train_stack.hip): a flag word per (layer, batch item, 16-row tile) and direction, compared with a per-forward epoch
+        // (zeroed only when (re)allocated), and the tile tables k_train_prep writes.  The regions keep their places for the life of an
+        // allocation (sized for 1.5x the positions that forced it): a table word of an earlier step must never be read as a flag
+        qpn_stack_fill(p);
+        if ((size_t)p.qtotal > t->sq_pos_cap) {
+            if (t->d_sq) (void)hipFree(t->d_sq);
+            t->d_sq = nullptr; t->sq_pos_cap = 0;
+            const size_t cap = (size_t)p.qtotal + (size_t)p.qtotal / 2 + 64;
+            const size_t per_dir = (cap / 32 + 2) * 1056;              // (sq_fidx: 32 flags per 128-byte line, lines 4224 bytes apart)
+            const size_t nsq = TR_QHDR_WORDS + 2 * per_dir + 2 * (cap + 1) * 8;      // + two int4 per position and direction
+            QPN_HIP(hipMalloc(&t->d_sq, nsq * sizeof(unsigned)));
+            QPN_HIP(hipMemsetAsync(t->d_sq, 0, nsq * sizeof(unsigned), stream));
+            t->sq_pos_cap = cap; t->sq_per_dir = per_dir;
+        }
+        p.qctl = t->d_sq;
+        p.qtab = (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
+        const unsigned epoch = (unsigned)((t->generation + 1) % 0xFFFFFFFFll) + 1u;      // (generation is bumped below; never 0)
+        StackQ& f = t->sqf; StackQ& bq = t->sqb;
+        f.flags = t->d_sq + TR_QHDR_WORDS; f.head = t->d_sq + 1024; f.abort = t->d_sq + 1; f.stats = t->d_sq + 4; f.epoch = epoch; f.total = p.qtotal; f.tab = p.qtab;
+        bq.flags = f.flags + t->sq_per_dir; bq.head = f.head + 8 * TR_QHEAD_STRIDE; bq.abort = f.abort; bq.stats = t->d_sq + 8; bq.epoch = epoch; bq.total = p.qtotal; bq.tab = p.qtab + 2 * (t->sq_pos_cap + 1);
+    }
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
     {
@@ -449,7 +474,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !getenv("QPN_CE_SEPARATE");
     p.ce_tgt = fuse_ce ? d_targets : nullptr; p.ce_stride = tgt_stride; p.ce_dlogits = d_dlogits; p.ce_loss = t->d_loss;
     if (fuse_ce && !want_logits) p.logits = nullptr;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, stream);
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, &t->sqf, stream);
     p.ce_tgt = nullptr; p.logits = d_logits;
     if (rc) return rc;
     t->fwd_valid = true;
@@ -500,6 +525,7 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
 
 static int status_to_rc(int st) {
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
+    if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup (QPN_STACK_QUEUE=0 selects a launch per layer)"); return QPN_ENODEV; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;
 }
@@ -544,6 +570,15 @@ extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* 
         for (int i = 0; i < 64; ++i) sum += parts[i];
         *h_loss = sum;
     }
+    return QPN_OK;
+}
+
+// dev / diagnostics: the control words of the stack work queues as the last step left them (synchronises the stream)
+extern "C" int qpn_train_stack_stats(qpn_handle* h, unsigned* h_out, int n, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train || !h->train->d_sq || !h_out || n < 1) { qpn_set_error("no stack-queue launch yet"); return QPN_ESTATE; }
+    QPN_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    QPN_HIP(hipMemcpy(h_out, h->train->d_sq, sizeof(unsigned) * (size_t)(n < 1024 ? n : 1024), hipMemcpyDeviceToHost));      // (words 600.. : stamps of a -DQPN_STACK_STAMPS build)
     return QPN_OK;
 }
 

@@ -1,0 +1,358 @@
+// train_stack.hip -- the residual stack of a training step (n_resch = 64) as ONE persistent launch per direction.
+//
+// k_layer_fwd_p / k_layer_bwd_p (train_fwd.hip, train_bwd.hip) run a layer per launch: 16 launches of ~11 us of matrix work each,
+// every one paying a kernel boundary, a fill and a drain.  Here the (layer, batch item, 16-row tile) triples of the
+// whole stack are the POSITIONS of one work queue, in layer-major order; 2 workgroups per CU pull positions with a returning
+// atomic add and run the same tile body as the per-layer kernels.  What lets the layers overlap is that the stack is causal and
+// its dependencies are local in time: tile (l, t) needs the rows of layer l-1 that its own rows and their pitch-dependent taps
+// touch (reference src/nets/qpnet.py:271-306: xC / xP of layer l are slices / gathers of layer l-1's output) -- at most
+// reach_l / 16 + 2 producer tiles, all of them ~T - reach_l / 16 positions back in the queue, i.e. ~2.4 rounds of the 512
+// resident workgroups.  So:
+//   * one flag word per position: the producer stores the tile's rows WRITE-THROUGH (sc1), every storing wave drains them
+//     (in-order vmcnt: the wave's later flag loads return behind them), the workgroup's barrier, then ONE lane stores
+//     flag[pos] = epoch (sc1).  Consumers read the flags of their producer range with ONE sc1 load per wave and the rows with
+//     sc1 buffer loads (CDNA4 guide, Guideline 16 R1: no release / acquire fence, correct for any placement of the workgroups).
+//   * the rows of a workgroup's NEXT position are requested half a tile ahead, behind a NON-blocking look at its flags.  When a
+//     flag is missing the workgroup finishes and PUBLISHES everything it holds and only then blocks on the flags: every blocking
+//     wait is for positions lower than any unfinished position the waiter holds, so the lowest unfinished position of the queue
+//     can always run -- no deadlock whatever the dispatch order or the number of resident workgroups (positions are handed out
+//     by the atomic, never assumed).
+//   * epoch = the forward's generation number: nothing is zeroed per launch except the queue head (by k_train_prep).
+//   * every wait is bounded: a timeout raises the abort word, all workgroups drain, the status word reports it (bit 4).
+// Arithmetic and its order are those of k_layer_fwd_p / k_layer_bwd_p: the results are bit-identical to the per-layer launches.
+#include "train_common.h"
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define SQ_SC1 16                                   // aux bits of the raw buffer builtins: sc1 (agent-scope / write-through)
+#define SQ_OOB 0x80000000u                          // a buffer offset beyond every descriptor's range: the access is dropped
+#define SQ_SPIN_LIMIT (1u << 22)
+#define SQ_FLINE 1056u                              // words between the 128-byte lines of the flag array
+#define SQ_NQ 8                                     // sub-queues (head words 128 bytes apart)
+
+__device__ __forceinline__ unsigned sq_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sq_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int sq_rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float sq_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float sq_tanh(float z) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f; }
+
+// dev aid (build with -DQPN_STACK_STAMPS): s_memtime (low word) of wave 0 of workgroup 5 at the phase boundaries of its first 25 tiles,
+// into control words [600 + 8 * tile + phase]
+#ifdef QPN_STACK_STAMPS
+#define SQ_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 5 && tid == 0 && it < 25) q.stats[596 + 8 * it + (i)] = (unsigned)t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SQ_STAMP(i) do { } while (0)
+#endif
+
+// Flag words: 32 consecutive positions share a 128-byte line (a consumer's producer range is 2-3 lines), consecutive LINES lie 4224 bytes
+// apart: the ~1000 flags the frontier of the queue polls and publishes at any moment would otherwise sit in ONE 4 KB stretch of memory,
+// i.e. behind one memory channel (measured: waits of 20-180 us on flags published long before).
+__host__ __device__ __forceinline__ static unsigned sq_fidx(unsigned pos) { return (pos >> 5) * SQ_FLINE + (pos & 31u); }
+
+struct SqTile { int n0, meta, dfirst, dn, xrow, tapb, hrow, pos; };       // wave-uniform (SGPRs); meta: layer | batch item << 8 | last << 24 | valid << 25
+__device__ __forceinline__ bool sq_valid(const SqTile& d) { return (d.meta >> 25) & 1; }
+__device__ __forceinline__ bool sq_last(const SqTile& d) { return (d.meta >> 24) & 1; }
+__device__ __forceinline__ int sq_layer(const SqTile& d) { return d.meta & 255; }
+
+// the table entry of a position (positions past the end: the invalid tile, which addresses like position 0 and stores nothing), in two steps so that
+// the load is in flight for most of a tile: sq_fetch issues it (every lane the same address), sq_take makes the words wave-uniform
+struct SqRaw { int4 a, b; int pos; };
+__device__ __forceinline__ SqRaw sq_fetch(const StackQ& q, int pos) {
+    const int i = (pos >= 0 && pos < q.total) ? pos : q.total;
+    SqRaw r; r.a = q.tab[2 * i]; r.b = q.tab[2 * i + 1]; r.pos = i;
+    return r;
+}
+__device__ __forceinline__ SqTile sq_take(const SqRaw& r) {
+    SqTile d;
+    d.n0 = sq_rfl(r.a.x); d.meta = sq_rfl(r.a.y); d.dfirst = sq_rfl(r.a.z); d.dn = sq_rfl(r.a.w);
+    d.xrow = sq_rfl(r.b.x); d.tapb = sq_rfl(r.b.y); d.hrow = sq_rfl(r.b.z); d.pos = r.pos;
+    return d;
+}
+
+// wait for flags [first, first + n): every lane polls one flag.  `bound` > 0: give up after that many polls per 64-flag group (returns 2:
+// the caller escalates -- publishes what it holds and comes back with bound = 0); bound = 0: until SQ_SPIN_LIMIT, then the abort word is
+// raised (returns 0, as it does when another workgroup raised it).  1 = every flag carries the epoch.
+__device__ __forceinline__ int sq_wait(const StackQ& q, int first, int n, int lane, int* status, unsigned bound) {
+    unsigned total_spins = 0;
+    int rc = 1;
+    for (int base = 0; base < n && rc == 1; base += 64) {
+        const int i = base + lane < n ? base + lane : n - 1;
+        const unsigned* fp = q.flags + sq_fidx((unsigned)(first + i));
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned v = sq_ld(fp);
+            if (__all(v == q.epoch)) break;
+            ++total_spins;
+            if ((spins & 63u) == 63u && sq_ld(q.abort)) { rc = 0; break; }      // (one word for the whole chip: looked at rarely)
+            ++spins;
+            if (bound && spins >= bound) { rc = 2; break; }
+            if (spins > SQ_SPIN_LIMIT) { if (lane == 0) { sq_st(q.abort, 1u); atomicOr(status, 4); } rc = 0; break; }
+            if (spins > 2) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (total_spins && lane == 0) atomicAdd(q.stats + 1, total_spins);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// dynamic LDS: As[2][16][lda] | Gs | SGs | THs | Xs ([16][ldg] each) | control words
+template <int KS>
+__global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
+    constexpr int C = 64, Ktp = 16 * KS;
+    constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;
+    extern __shared__ float sm[];
+    float* Gs = sm + 32 * lda;
+    float* SGs = Gs + 16 * ldg; float* THs = SGs + 16 * ldg; float* Xs = THs + 16 * ldg;
+    int* ctl = (int*)(Xs + 16 * ldg);          // [0..3] position ring, [4..7] per wave: the next tile's rows were NOT requested, [8] arrivals at the publish point
+    const int Ap = p.Ap, N1 = p.N1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = sq_rfl(tid >> 6);
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
+    const int orow = tid >> 5, oc2 = (tid & 31) * 2;
+    const int c = 16 * wave + (lane & 15);
+    const int arow = lane & 15, ak = lane >> 4;
+    float* const dmy = p.scratch_rows + (size_t)blockIdx.x * 2 * C + oc2;
+    const unsigned xbytes = (unsigned)N1 * C * 4u;                // one batch item of one layer's activations
+    const size_t xlayer = (size_t)p.B * N1 * C;                   // floats between consecutive layers' activations
+
+    // ---- resident weight fragments of the layer in hand
+    float4 w1[KS][2], wr[4];
+    float bs = 0.f, bt = 0.f, bb = 0.f;
+    auto load_weights = [&](int l) {
+        const TrLayer ly = p.layers[l];
+        const float4* W1 = p.wp + ly.w1_f4; const float4* Wr = p.wp + ly.wr_f4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { w1[ks][0] = W1[((size_t)ks * 8 + wave) * 64 + lane]; w1[ks][1] = W1[((size_t)ks * 8 + 4 + wave) * 64 + lane]; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wr[ks] = Wr[((size_t)ks * 4 + wave) * 64 + lane];
+        bs = p.bp[ly.bias1 + c]; bt = p.bp[ly.bias1 + C + c]; bb = p.bp[ly.biasr + c];
+    };
+    auto xrsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
+    int tp = 0; float4 rc, rp, rx;
+    auto load_tap = [&](const SqTile& d, int& out) {
+        const int n = d.n0 + srow;
+        out = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1];
+    };
+    auto load_rows = [&](const SqTile& d, bool go) {           // go (wave-uniform) false: the two activation loads are dropped by the range check
+        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
+        const auto rs = xrsrc(p.X + (size_t)d.xrow * C);
+        const unsigned oc = go ? (__umul24((unsigned)nn, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
+        const unsigned op = go ? (__umul24((unsigned)tp, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oc, 0, SQ_SC1);
+        const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)op, 0, SQ_SC1);
+        rc = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        rp = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
+        rx = *(const float4*)(p.HUP + (size_t)d.hrow * Ap + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
+        __builtin_amdgcn_sched_barrier(0);                       // (all three requests before anything waits for one of them)
+    };
+    auto store_rows = [&](const SqTile& d, float* As) {
+        const bool in = d.n0 + srow < N1;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vc = in ? rc : z, vp = in ? rp : z, vx = (in && aux_real) ? rx : z;
+        float* dd = As + (size_t)srow * lda + 4 * sc4;
+        *(float2*)dd = make_float2(vc.x, vc.y); *(float2*)(dd + 2) = make_float2(vc.z, vc.w);
+        *(float2*)(dd + C) = make_float2(vp.x, vp.y); *(float2*)(dd + C + 2) = make_float2(vp.z, vp.w);
+        if (aux_thread) { *(float2*)(dd + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(dd + 2 * C + 2) = make_float2(vx.z, vx.w); }
+    };
+    auto store_out = [&](const float* T, float* dst, int n0) {      // a [16][64] LDS tile -> rows n0.. of a [N1][64] array (plain stores: read by later kernels only)
+        const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
+        float* d0 = dst + (__umul24((unsigned)(n0 + orow), (unsigned)C) + oc2);
+        float* d1 = d0 + 8 * C;
+        d0 = n0 + orow < N1 ? d0 : dmy;
+        d1 = n0 + orow + 8 < N1 ? d1 : dmy + C;
+        *(float2*)d0 = v0; *(float2*)d1 = v1;
+    };
+    auto store_x = [&](const SqTile& d, bool go) {                // the block output of tile d (in Xs) -> X[l + 1], write-through, 16 bytes per thread
+        const float2 v0 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4), v1 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4 + 2);
+        const int n = d.n0 + srow;
+        const unsigned o = (go && n < N1) ? (__umul24((unsigned)n, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
+        const u32x4 v = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v1.x), __float_as_uint(v1.y)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, xrsrc(p.X + (size_t)d.xrow * C + xlayer), (int)o, 0, SQ_SC1);
+    };
+    auto publishes = [&](const SqTile& d) { return sq_valid(d) && !sq_last(d); };     // (nothing reads the last block's residual output: no rows, no flag)
+
+    int zero_v; asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    // ---- prologue: three positions, the first tile staged
+    // positions come from SQ_NQ sub-queues (position = ticket * SQ_NQ + sub-queue, each handed out in increasing order; one head word
+    // saturates at ~88 returning atomics per microsecond chip-wide: CDNA4 guide, price list 'dequeue'); a workgroup's home is blockIdx % SQ_NQ
+    const int NQ = q.nq, sub = (blockIdx.x / 8) % NQ;      // (blockIdx % 8 tells the XCD under round-robin dispatch: a sub-queue served by ONE XCD drifts away from the others)
+    unsigned* const head = q.head + sub * TR_QHEAD_STRIDE + zero_v;
+    // (three separate tickets, each requested when the previous one has returned: every workgroup does the same, so the first tickets of
+    //  all of them come before the second ones -- ONE add of 3 gave a workgroup three neighbouring tiles, and the workgroups that started
+    //  with tiles of layer 1 waited for layer 0 tiles their neighbours had third in line)
+    if (tid == 0) {
+        ctl[8] = 0;
+        const unsigned k0 = atomicAdd(head, 1u); ctl[0] = (int)(k0 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k1 = atomicAdd(head, 1u); ctl[1] = (int)(k1 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k2 = atomicAdd(head, 1u); ctl[2] = (int)(k2 * NQ + sub);
+    }
+    __syncthreads();
+    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1]))), nn = sq_take(sq_fetch(q, sq_rfl(ctl[2])));
+    if (!sq_valid(cur)) return;
+    SqTile prev = cur; prev.meta = 0;
+    int lw = sq_layer(cur);
+    load_weights(lw);
+    load_tap(cur, tp);
+    sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
+    load_rows(cur, true);
+    store_rows(cur, sm);
+    load_tap(next, tp);
+    // Per tile, three barriers:
+    //   B1  the tile's staged rows are complete
+    //       gate contraction; then (the previous tile's write-through rows left a whole contraction ago) this wave's counted wait, an
+    //       arrival on the LDS counter, and the wave that arrives LAST publishes the previous tile -- no barrier of its own
+    //       gate epilogue
+    //   B2  the gate tile is complete
+    //       the flags of the NEXT tile's producers are requested here -- as late as the tile allows: a producer is ~2.45 rounds of the
+    //       resident workgroups ahead of its consumer, of which one round is its own tile and ~0.5 its rows' way to memory -- and looked
+    //       at ONCE behind the residual contraction; a wave that finds them all requests the next tile's rows
+    //   B3  the block output is complete in LDS and leaves (write-through); every wave knows whether all four found their flags.
+    //       If not: the stores drain, a barrier, the tile is PUBLISHED, and only then do the waves without rows wait (so every wait is for
+    //       positions lower than any unpublished position the workgroup holds).  Then the next tile's rows are requested
+    bool cur_published = false;         // (the tile just finished was published by the slow path: this trip's publish point skips it)
+    for (int it = 0;; ++it) {
+        float* As = sm + (it & 1) * 16 * lda;
+        const bool last = sq_last(cur);
+        SQ_STAMP(0);
+        // the position three tiles ahead.  (The address goes through an opaque zero: with a provably uniform address LLVM's atomic optimizer
+        // turns the add into a wave reduction whose v_readfirstlane needs the returned value AT ONCE -- s_waitcnt vmcnt(0) at the top of every tile.)
+        unsigned rtk = 0;                                         // (the raw ticket: any arithmetic on it here would wait for the atomic at once)
+        if (tid == 0) rtk = atomicAdd(head, 1u);
+        if (sq_layer(cur) != lw) { lw = sq_layer(cur); load_weights(lw); }
+        int tpn; load_tap(nn, tpn);
+        TR_LDS_BARRIER();                                          // B1
+        const bool pub_prev = publishes(prev) && !cur_published;
+        SQ_STAMP(1);
+        float xa[KS][4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* ap = As + (size_t)arow * lda + 16 * ks + ak;
+            xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][0].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][1].x, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][0].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][1].y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][0].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][1].z, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][0].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][1].w, a1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SQ_STAMP(2);
+        // publish point: younger than the previous tile's row stores are only this trip's tap load and, in wave 0, the ticket
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        SQ_STAMP(3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (4 * (lane >> 4) + i) * ldg + c;
+            const float sg = sq_sigmoid(a0[i] + bs), th = sq_tanh(a1[i] + bt);
+            Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
+        }
+        SQ_STAMP(4);
+        if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
+        TR_LDS_BARRIER();                                          // B2
+        SQ_STAMP(5);
+        const SqRaw raw3 = sq_fetch(q, sq_rfl(ctl[(it + 3) & 3]));       // the table entry of the tile three ahead: taken at the end of the trip
+        const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;      // (no producers: a word of its own)
+        unsigned fv0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fv1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+        asm volatile("" ::: "memory");
+        float* SG = p.SG + (size_t)cur.xrow * C;
+        float* TH = p.TH + (size_t)cur.xrow * C;
+        if (!last) {                                               // the last block's residual output is never used (qpnet.py:306-309)
+            float ga[4][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float* gp = Gs + (size_t)arow * ldg + 16 * ks + ak;
+                ga[ks][0] = gp[0]; ga[ks][1] = gp[4]; ga[ks][2] = gp[8]; ga[ks][3] = gp[12];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 ar0 = (f32x4){0, 0, 0, 0}, ar1 = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][0], wr[ks].x, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][0], wr[ks + 1].x, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][1], wr[ks].y, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][1], wr[ks + 1].y, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][2], wr[ks].z, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][2], wr[ks + 1].z, ar1, 0, 0, 0);
+                ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
+            }
+            store_out(SGs, SG, cur.n0);
+            store_out(THs, TH, cur.n0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * (lane >> 4) + i;
+                Xs[r * ldg + c] = ((ar0[i] + ar1[i]) + bb) + As[(size_t)r * lda + c];
+            }
+        } else {
+            store_out(SGs, SG, cur.n0);
+            store_out(THs, TH, cur.n0);
+        }
+        SQ_STAMP(6);
+        asm volatile("" : "+v"(fv0), "+v"(fv1));                   // (the flag words are looked at HERE: left alone hipcc compares them, i.e. waits for them, right behind the loads)
+        const bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+        if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
+        TR_LDS_BARRIER();                                          // B3
+        store_x(cur, publishes(cur));
+        const int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
+        cur_published = false;
+        if (any_slow) {
+            // a producer of the next tile has not published yet: hand over everything this workgroup holds, THEN wait (a workgroup that
+            // waits while it holds finished, unpublished tiles makes its own consumers wait: measured, a convoy that tripled the launch)
+            if (tid == 0) atomicAdd(q.stats, 1u);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR_LDS_BARRIER();
+            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch);
+            cur_published = true;
+            if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
+        }
+        // the next tile's rows: ONE request site (a second one inside the branch above makes the row registers phi nodes, and hipcc
+        // resolves them with copies -- i.e. waits for the rows, and for the write-through stores in front of them, right here)
+        load_rows(next, true);
+        store_rows(next, sm + ((it + 1) & 1) * 16 * lda);
+        SQ_STAMP(7);
+        tp = tpn;
+        prev = cur; cur = next; next = nn; nn = sq_take(raw3);
+        if (!sq_valid(cur)) break;
+    }
+    // the last tile's output has left; publish it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_LDS_BARRIER();
+    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool qpn_stack_fwd_fits(const TrainParams& p) {
+    if (getenv("QPN_STACK_QUEUE") && atoi(getenv("QPN_STACK_QUEUE")) == 0) return false;
+    return p.C == 64 && p.Ktp == 176 && p.L >= 1 && p.L <= TR_MAXL && p.B < 65536 && (int64_t)p.N1 * p.C * 4 <= (1ll << 30) &&
+           (int64_t)(p.L + 1) * p.B * p.N1 < (1ll << 31);
+}
+
+// positions of the queue: layer-major, batch item, tile (rows ascending); the table itself is written on the device by k_train_prep
+void qpn_stack_fill(TrainParams& p) {
+    int pos = 0;
+    for (int l = 0; l < p.L; ++l) {
+        p.qT[l] = (p.N1 - p.layers[l].s_out + 15) / 16;
+        p.qP[l] = pos; pos += p.B * p.qT[l];
+    }
+    for (int l = p.L; l <= TR_MAXL; ++l) p.qP[l] = pos;
+    p.qtotal = pos;
+}
+
+int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stream) {
+    constexpr int lda = ((176 + 29) / 32) * 32 + 2, ldg = ((64 + 29) / 32) * 32 + 2;
+    const size_t lds = (size_t)(32 * lda + 4 * 16 * ldg) * sizeof(float) + 64;
+    int G = qpn_num_cus() * 2;
+    if (const char* e = getenv("QPN_STACK_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) G = v; }
+    if (G > q.total) G = q.total;
+    if (G > 1024) G = 1024;                                      // (scratch rows: one pair per workgroup)
+    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);      // every sub-queue needs a puller (a workgroup's home: (blockIdx / 8) % nq)
+    hipLaunchKernelGGL((k_stack_fwd<11>), dim3(G), dim3(256), lds, stream, p, qq);
+    return QPN_OK;
+}
