@@ -282,29 +282,40 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
                 ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][2], wr[ks].z, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][2], wr[ks + 1].z, ar1, 0, 0, 0);
                 ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
             }
-            store_out(SGs, SG, cur.n0);
-            store_out(THs, TH, cur.n0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * (lane >> 4) + i;
                 Xs[r * ldg + c] = ((ar0[i] + ar1[i]) + bb) + As[(size_t)r * lda + c];
             }
-        } else {
-            store_out(SGs, SG, cur.n0);
-            store_out(THs, TH, cur.n0);
         }
         SQ_STAMP(6);
         asm volatile("" : "+v"(fv0), "+v"(fv1));                   // (the flag words are looked at HERE: left alone hipcc compares them, i.e. waits for them, right behind the loads)
-        const bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+        bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+        // sigma / tanh leave BEHIND the look at the flags: vmcnt counts in order, so stores issued in front of it are waited for with it
+        asm volatile("" ::: "memory");
+        store_out(SGs, SG, cur.n0);
+        store_out(THs, TH, cur.n0);
         if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
         TR_LDS_BARRIER();                                          // B3
-        store_x(cur, publishes(cur));
-        const int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
+        int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
         cur_published = false;
+        if (any_slow) {
+            // Some wave did not find every flag.  Most such misses are near misses (the producer publishes within a microsecond or two): the
+            // waves that missed look ONCE more before the workgroup pays for the hand-over below (a drain, two barriers, a wait).
+            if (tid == 0) atomicAdd(q.stats + 2, 1u);
+            if (!ready) {
+                const unsigned g0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), g1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+                ready = fn <= 128 && __all(g0 == q.epoch && g1 == q.epoch);
+            }
+            if (lane == 0) ctl[12 + wave] = ready ? 0 : 1;        // (words of their own: a wave may still be reading the first look's)
+            TR_LDS_BARRIER();
+            any_slow = sq_rfl(ctl[12] | ctl[13] | ctl[14] | ctl[15]);
+        }
         if (any_slow) {
             // a producer of the next tile has not published yet: hand over everything this workgroup holds, THEN wait (a workgroup that
             // waits while it holds finished, unpublished tiles makes its own consumers wait: measured, a convoy that tripled the launch)
             if (tid == 0) atomicAdd(q.stats, 1u);
+            store_x(cur, publishes(cur));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TR_LDS_BARRIER();
             if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch);
@@ -314,6 +325,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         // the next tile's rows: ONE request site (a second one inside the branch above makes the row registers phi nodes, and hipcc
         // resolves them with copies -- i.e. waits for the rows, and for the write-through stores in front of them, right here)
         load_rows(next, true);
+        // ... and the block output leaves BEHIND them (vmcnt counts in order: in front of them, the staging below would wait for the
+        // write-through stores' way to memory as well)
+        if (!any_slow) store_x(cur, publishes(cur));
         store_rows(next, sm + ((it + 1) & 1) * 16 * lda);
         SQ_STAMP(7);
         tp = tpn;
