@@ -1520,6 +1520,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)
             const int tiles = (rows + 15) / 16;
             int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+            if (G > 1024) G = 1024;                                // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
             const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(176)) * sizeof(float);
             (void)hipFuncSetAttribute(l == L - 1 ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
             long long* d_st = nullptr;

@@ -869,6 +869,7 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq,
             if (persist) {
                 const int tiles = (rows + 15) / 16;
                 int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+                if (G > 1024) G = 1024;                            // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
                 const size_t ldsp = (size_t)(32 * tr_lda(176) + 4 * 16 * tr_lda(64)) * sizeof(float);
                 static long long* d_stamps = nullptr;
                 const bool stamp = getenv("QPN_FWDP_STAMPS") != nullptr;
@@ -876,7 +877,8 @@ int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq,
                 if (stamp) QPN_HIP(hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream));
                 if (split) {      // two launches of one workgroup per CU each: the earlier tiles on the main stream, the later ones on the side stream
                     const int t0 = tr_split_tiles(p, l, cut_row, tiles), ncu = qpn_num_cus();
-                    const int G0 = t0 < ncu ? t0 : ncu, G1 = tiles - t0 < ncu ? tiles - t0 : ncu;
+                    const int ncap = ncu < 512 ? ncu : 512;             // (the split's second launch uses the upper half of the scratch rows)
+                    const int G0 = t0 < ncap ? t0 : ncap, G1 = tiles - t0 < ncap ? tiles - t0 : ncap;
                     if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
                     else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
                     QPN_HIP(hipEventRecord(sp->ev[l], stream));

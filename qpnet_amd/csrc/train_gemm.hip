@@ -445,8 +445,7 @@ static const size_t LDS_TN = (size_t)(2 * GKT * GM + 2 * GKT * GN) * sizeof(floa
 
 template <int AL, int EPI>
 static void launch_nn(const GArgs& g, int ntiles_n, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_gemm_nn<AL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NN); attr = true; }
+    (void)hipFuncSetAttribute((const void*)k_gemm_nn<AL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_NN);      // (per device: set on every launch, like launch_tn)
     if (g.M <= 0) return;
     hipLaunchKernelGGL((k_gemm_nn<AL, EPI>), dim3(ntiles_n, (g.M + GM - 1) / GM, g.nb), dim3(256), LDS_NN, stream, g);
 }

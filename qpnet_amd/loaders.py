@@ -81,16 +81,16 @@ class _SampleWindow:
         assert len(x) == len(d) * self.U == h.shape[0] * self.U
         if len(d) == 0:
             return
-        sufmax = np.maximum.accumulate(d[::-1])[::-1]
+        sufmax = np.fmax.accumulate(d[::-1])[::-1]      # (fmax: a NaN factor is ignored, as by the reference's np.nanmax; all-NaN tails stay NaN)
         self.segs.append((np.asarray(x, dtype=np.float32), d, sufmax, h.astype(self.h_dtype, copy=False)))
         self.n_frames += len(d)
 
     def max_factor(self):
         """largest dilated factor among the live samples (what np.nanmax over the reference's d_buffer returns)."""
-        m = -np.inf
+        m = np.nan
         for k, seg in enumerate(self.segs):
-            m = max(m, seg[2][self.f0 if k == 0 else 0])
-        return m
+            m = np.fmax(m, seg[2][self.f0 if k == 0 else 0])
+        return float(m)                                 # (NaN only when every live factor is NaN: np.nanmax's answer as well)
 
     def front(self, frames, samples):
         """first `frames` feature rows and `samples` (= frames*U + 1) samples / sample-rate factors of the window."""

@@ -120,6 +120,7 @@ class QPNet(nn.Module):
         assert [k for k, _ in self.named_parameters()] == [k for k, _ in cfg.param_layout()]
         self._handle = None
         self._handle_dev = None
+        self._qpn_sync_status = False
         self.last_decode_kernel_ms = 0.0
         self.last_decode_plan = ""
         self.sampling_seed = None          # set to an int to pin the sampling-mode random stream
@@ -141,8 +142,21 @@ class QPNet(nn.Module):
             self._handle, self._handle_dev = hp, device
         return L, self._handle
 
+    def check_status(self):
+        """Raise what the device-side checks of the training forwards so far have found (a dilated factor outside the layer input --
+        the reference's gather assert, qpnet.py:294 -- or a target outside [0, n_quantize)); collected without a stream drain.
+        backward(), FlatAdam.step() and the next forward call it too; call it after the last forward of a loop that has none of them."""
+        if self._handle is not None:
+            with torch.cuda.device(self._handle_dev):
+                _lib.check(_lib.lib().qpn_train_status_collect(self._handle))
+
     def _release(self):
         if self._handle is not None:
+            try:
+                self.check_status()
+            except Exception as e:          # (a destructor must not raise: say it)
+                import logging
+                logging.warning("qpnet_amd: unreported device-side status at release: %s", e)
             _lib.lib().qpn_destroy(self._handle)
             self._handle = None
 

@@ -28,13 +28,17 @@ def _on_parameter_registered(module, name, param):
 
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_on_parameter_registered)
+# ... and whenever a sub-module is registered (`model.x = other_module` brings parameters without registering any)
+torch.nn.modules.module.register_module_module_registration_hook(_on_parameter_registered)
 
 
 def model_params(model):
     """list(model.parameters()), cached (see above)."""
     c = model.__dict__.get("_qpn_params")
-    if c is None or c[0] != _PARAM_GENERATION[0]:
-        c = (_PARAM_GENERATION[0], list(model.parameters()))
+    # (deletions -- `del model.x` -- fire no hook: the count of registered sub-modules / parameters of the top level is part of the key)
+    key = (_PARAM_GENERATION[0], len(model._modules), len(model._parameters))
+    if c is None or c[0] != key:
+        c = (key, list(model.parameters()))
         model.__dict__["_qpn_params"] = c
     return c[1]
 
@@ -104,12 +108,17 @@ class QPNetFunction(torch.autograd.Function):
         logits = torch.empty((B, BL, model.n_quantize), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            # the reference asserts on the gather bounds inside forward (qpnet.py:294); here the device-side check of the
-            # PREVIOUS forward is collected (no stream drain) and this one's is enqueued behind the kernels: raised one call late
+            # The reference asserts on the gather bounds inside forward (qpnet.py:294).  Here the device-side check is enqueued behind
+            # the kernels and collected (no stream drain) at the first of: this forward's backward (so an out-of-range factor is raised
+            # BEFORE the optimizer step it would feed), FlatAdam.step, the next forward, model.check_status().  A forward that records no
+            # graph (torch.no_grad() / eval loops: nothing else of this model may ever run) checks synchronously.
             _lib.check(L.qpn_train_status_collect(hd))
             _lib.check(L.qpn_train_forward(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                            x.data_ptr(), h.data_ptr(), d.data_ptr(), logits.data_ptr(), stream))
-            _lib.check(L.qpn_train_status_enqueue(hd, stream))
+            if model._qpn_sync_status:
+                _lib.check(L.qpn_train_status(hd, stream))
+            else:
+                _lib.check(L.qpn_train_status_enqueue(hd, stream))
         ctx.model = model
         ctx.generation = int(L.qpn_train_generation(hd))
         ctx.keep = (x, h, d)                                  # inputs must outlive backward (the workspace points into them)
@@ -123,6 +132,8 @@ class QPNetFunction(torch.autograd.Function):
         if int(L.qpn_train_generation(hd)) != ctx.generation:
             raise RuntimeError("qpnet_amd: backward of a forward whose activations have been replaced by a later forward of the "
                                "same model (one outstanding forward per model; run validation forwards after backward)")
+        with torch.cuda.device(dev):
+            _lib.check(L.qpn_train_status_collect(hd))       # the forward's gather-bounds / target check (its copy finished long ago)
         flat = model._flat
         # a FRESH buffer per backward: autograd keeps (or accumulates into) the views it is handed, so they must not
         # alias memory a later backward writes
@@ -166,7 +177,10 @@ def qpnet_forward(model, x, h, dilated_factors, blength):
     h = h.to(dev, torch.float32).contiguous()
     d = dilated_factors.to(dev, torch.float32).contiguous()
     ensure_flat(model, dev)
-    return QPNetFunction.apply(model, x, h, d, BL, maxd, *model_params(model))
+    params = model_params(model)
+    # no graph will be recorded (no_grad, or no parameter wants a gradient): no backward will come to collect the status
+    model._qpn_sync_status = not (torch.is_grad_enabled() and any(p.requires_grad for p in params))
+    return QPNetFunction.apply(model, x, h, d, BL, maxd, *params)
 
 
 # ---------------------------------------------------------------- Adam state in torch.optim.Adam's state_dict layout
@@ -237,6 +251,8 @@ class FlatAdam(torch.optim.Optimizer):
             raise RuntimeError("FlatAdam.step before the first forward/backward of the model")
         dev = flat.device
         L, hd = model._native(dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.qpn_train_status_collect(hd))       # a pending forward check (no-op after a backward has collected it)
         params = model_params(model)
         g = _flat_grad_of(params)
         if g is None:                                # grads came from elsewhere (or some are None): gather them
@@ -282,7 +298,9 @@ class FusedTrainer:
     extra elementwise launch or allocation in the step.
     state_dict()/load_state_dict() use torch.optim.Adam's layout (resume of reference-made checkpoints and vice versa)."""
 
-    STATUS_EVERY = 100          # steps between checks of the device-side status word (bad taps / targets; reference asserts)
+    # The device-side status word (bad taps / targets; the reference asserts in-line, qpnet.py:294, qpnet_train.py:525) is copied to pinned
+    # memory behind every step and looked at when the NEXT step starts (no stream drain): a bad chunk is raised one step late, i.e. with
+    # one Adam update applied, not up to 99 as when it was read every 100 steps.  check_status() collects the last one.
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
         self.model = model
@@ -330,6 +348,7 @@ class FusedTrainer:
         loss = C.c_double(0.0)
         multi = self.world > 1
         with torch.cuda.device(dev):
+            _lib.check(L.qpn_train_status_collect(hd))       # the previous step's check
             # forward + CrossEntropyLoss + dL/dlogits in one call (the loss stays on the device unless asked for)
             _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                                 x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
@@ -348,9 +367,14 @@ class FusedTrainer:
                                           self.g.data_ptr() + 4 * flat.numel() if multi else None, stream))
             if want_loss:
                 _lib.check(L.qpn_train_loss(hd, C.byref(loss), stream))
-            if want_loss or self.step_count % self.STATUS_EVERY == 1:
-                _lib.check(L.qpn_train_status(hd, stream))
+                _lib.check(L.qpn_train_status(hd, stream))   # (the stream has just been drained for the loss: in-step, like the reference)
+            else:
+                _lib.check(L.qpn_train_status_enqueue(hd, stream))
         return loss.value if want_loss else None
+
+    def check_status(self):
+        """Raise what the device-side check of the last step(want_loss=False) found (see QPNet.check_status)."""
+        self.model.check_status()
 
     def forward_loss(self, x, h, t, d, blength, maxd=None):
         """forward + mean CE only (validation, reference qpnet_validate.py:409-430)."""

@@ -169,6 +169,66 @@ def test_other_geometries_bitwise_vs_oracle(geo, cuda, oracle):
     np.testing.assert_array_equal(y, oracle.decode(cfg, flat, h, d, x, n)["samples"])
 
 
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_upsampling_factor_zero_decode_vs_oracle(cfgname, cuda, oracle):
+    """upsampling_factor = 0 (reference src/nets/qpnet.py:203,343: no upsampling layer, the features arrive at sample rate): greedy and
+    sampling streams against the C oracle; n_samples counts samples directly."""
+    import dataclasses
+    import torch
+    from qpnet_amd.config import TINY, PAPER
+    cfg_u = TINY if cfgname == "tiny" else PAPER
+    cfg0 = dataclasses.replace(cfg_u, upsampling_factor=0)
+    flat = synth.make_weights(cfg0, 19)
+    m = util.build_model(cfg0, flat, cuda)
+    x, h, d, n = synth.decode_inputs(cfg_u, 7, 23, 1.0)
+    h0 = np.ascontiguousarray(np.repeat(h, cfg_u.upsampling_factor, axis=1))          # (n_aux, T): one feature column per sample
+    assert h0.shape[1] == d.size == n + 1
+    for mode in ("argmax", "sampling"):
+        m.sampling_seed = 99
+        y = m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h0[None]).to(cuda), [n], d[None], mode=mode)[0]
+        r = oracle.decode(cfg0, flat, h0, d, x, n, mode=mode, seed=99, row=0)
+        np.testing.assert_array_equal(y, r["samples"], err_msg=mode)
+
+
+def test_other_class_count_decode_and_train_vs_oracle(cuda, oracle):
+    """n_quantize = 128 (the reference takes it as a constructor argument, qpnet.py:174): greedy and sampling streams bit-exact against
+    the C oracle (the sampling spec lays Q / 64 classes on a lane), training logits / loss / gradients against the numpy oracle; a class
+    count the sampling spec does not cover is refused with a message, not mis-sampled."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd import _lib
+    from qpnet_amd.config import QPNetConfig
+    cfg = QPNetConfig(n_quantize=128, n_resch=64, n_skipch=128, dilationF_depth=2, dilationF_repeat=1, dilationA_depth=2, dilationA_repeat=1)
+    flat = synth.make_weights(cfg, 29)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, d, n = synth.decode_inputs(cfg, 6, 31, 1.0)
+    for mode in ("argmax", "sampling"):
+        m.sampling_seed = 5
+        y = m.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode=mode)[0]
+        np.testing.assert_array_equal(y, oracle.decode(cfg, flat, h, d, x, n, mode=mode, seed=5, row=0)["samples"], err_msg=mode)
+        assert y.max() < 128
+    xb, hb, tb, db, bb = synth.train_inputs(cfg, 500, 8, 4000)
+    BL = int(bb[0])
+    mt = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = [torch.from_numpy(np.ascontiguousarray(a)).to(cuda) for a in (xb, hb, tb, db, bb)]
+    logits = mt(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, 128), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in mt.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, xb, hb, db, bb)
+    oloss, dl = TO.ce_loss(lg, tb[:, -BL:])
+    og = TO.backward(cfg, flat, caches, dl)
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=2e-5, rtol=0)
+    assert np.abs(grad - og).max() <= 2e-5 * np.abs(og).max()
+    cfg96 = QPNetConfig(n_quantize=96, n_resch=32, n_skipch=32, dilationF_depth=2, dilationF_repeat=1, dilationA_depth=1, dilationA_repeat=1)
+    m96 = util.build_model(cfg96, synth.make_weights(cfg96, 3), cuda)
+    x, h, d, n = synth.decode_inputs(cfg96, 3, 31, 1.0)
+    with pytest.raises(_lib.QpnError) as e:
+        m96.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), [n], d[None], mode="sampling")
+    assert "n_quantize" in str(e.value)
+
+
 @pytest.mark.parametrize("case", DECODE_CASES2, ids=[c["name"] for c in DECODE_CASES2])
 def test_decode_worst_case_pitch_and_long_seeds(case, cuda, golden_dir, oracle):
     """Reference streams at the corpus pitch floor with 0.5x F0 scaling (maxd ~ 123: the deepest rings the path meets,
@@ -432,9 +492,9 @@ def _paper_batch(B, lo=6, span=9, seed0=300):
 @pytest.mark.parametrize("B,mode", [(49, "argmax"), (64, "sampling"), (100, "argmax")])
 def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
     """decode_batch_size is a free parameter of the reference (--batch_size, src/bin/qpnet_decode.py:52).  More rows than the 48
-    five-role groups a 256-CU device holds resident: groups take a second utterance, stepped alternately (and beyond 96 rows,
-    equal-sized launches); whatever the plan, EVERY row equals its single-row oracle stream (sampling: the Philox key is the
-    caller's row number)."""
+    five-role groups a 256-CU device holds resident: groups take a second utterance, stepped alternately, or a third (97-144 rows:
+    one launch of three per group is cheaper than two launches); whatever the plan, EVERY row equals its single-row oracle stream
+    (sampling: the Philox key is the caller's row number).  Plans of SEVERAL launches: test_two_launch_plan below."""
     import torch
     cfg, specs = _paper_batch(B)
     flat = synth.make_weights(cfg, 13)
@@ -458,6 +518,36 @@ def test_batches_beyond_one_pipelined_launch(B, mode, cuda, oracle):
         b = int(order[k])
         x, h, d, n = synth.decode_inputs(cfg, specs[b][1], specs[b][0], specs[b][2])
         r = oracle.decode(cfg, flat, h, d, x, n, maxd=maxd, mode=mode, seed=4242, row=b)
+        np.testing.assert_array_equal(outs[k], r["samples"], err_msg="row %d (%s)" % (b, m.last_decode_plan))
+
+
+@pytest.mark.parametrize("mode", ["argmax", "sampling"])
+def test_two_launch_plan(mode, cuda, oracle, monkeypatch):
+    """A plan of TWO pipelined launches (descriptor slices d_utts + first, the exchange block cleared per launch, ring offsets keyed by the
+    sorted position): with at most two utterances per group (QPN_PIPE_NU=2, read at qpn_create) 100 rows exceed the 96 one launch
+    holds on a 256-CU device.  Every row equals its single-row oracle stream."""
+    import re
+    import torch
+    monkeypatch.setenv("QPN_PIPE_NU", "2")
+    B = 100
+    cfg, specs = _paper_batch(B, lo=5, span=5, seed0=900)
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)               # (a new module: its handle is created under the knob)
+    m.sampling_seed = 777
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode=mode)
+    mt = re.match(r"pipe rows=(\d+) waves=(\d+) x (\d+) \((\d) per group\); one-cu rows=(\d+)", m.last_decode_plan)
+    assert mt, m.last_decode_plan
+    n_pipe, n_waves, per, per_group, n_one = map(int, mt.groups())
+    if torch.cuda.get_device_properties(cuda).multi_processor_count == 256:
+        assert n_waves == 2 and per_group == 2 and n_pipe == B and n_one == 0, m.last_decode_plan
+    order = np.argsort(ns, kind="stable")
+    assert [len(o) for o in outs] == [ns[b] for b in order]
+    maxd = int(np.ceil(np.nanmax(bd)))
+    for k in range(B):
+        b = int(order[k])
+        x, h, d, n = synth.decode_inputs(cfg, specs[b][1], specs[b][0], specs[b][2])
+        r = oracle.decode(cfg, flat, h, d, x, n, maxd=maxd, mode=mode, seed=777, row=b)
         np.testing.assert_array_equal(outs[k], r["samples"], err_msg="row %d (%s)" % (b, m.last_decode_plan))
 
 

@@ -185,3 +185,17 @@ def test_decode_generator_equals_reference_generator(case, golden_dir):
     # the caller's feature arrays are not modified by the F0 scaling
     _, feats2, _, _ = generator_corpus(case["corpus_seed"], case["frames"], None, case["f0"], case["U"])
     assert all(np.array_equal(a, b) for a, b in zip(feats, feats2))
+
+
+def test_sample_window_max_factor_ignores_nan_like_nanmax():
+    """The reference takes np.nanmax over the live dilated factors (src/bin/qpnet_train.py _receptive_field): a NaN factor is skipped,
+    it does not hide the segment it sits in."""
+    from qpnet_amd.loaders import _SampleWindow
+    U = 4
+    w = _SampleWindow(3, np.float32, U)
+    d1 = np.array([5.0, np.nan, 9.0, 2.0]); d2 = np.array([np.nan, 7.0, 3.0])
+    w.append(np.zeros(len(d1) * U), np.zeros((len(d1), 3), np.float32), d1)
+    w.append(np.zeros(len(d2) * U), np.zeros((len(d2), 3), np.float32), d2)
+    assert w.max_factor() == np.nanmax(np.concatenate([d1, d2])) == 9.0
+    w.f0 = 3                                             # the first three frames of the first segment are consumed
+    assert w.max_factor() == np.nanmax(np.concatenate([d1[3:], d2])) == 7.0

@@ -76,16 +76,16 @@ rank = int(sys.argv[1]); world = int(sys.argv[2]); out = sys.argv[3]
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 dist.init_process_group("gloo", rank=rank, world_size=world)
 from qpnet_amd import synth, parallel
-from qpnet_amd.config import TINY
+from qpnet_amd.config import TINY, PAPER
 from qpnet_amd.train import FusedTrainer, ensure_flat
 import util
-cfg = TINY
+cfg = {{"tiny": TINY, "paper": PAPER}}[sys.argv[4]]
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 m = util.build_model(cfg, synth.make_weights(cfg, 3 + rank), dev).train()      # deliberately different: broadcast must fix it
 parallel.broadcast_parameters(ensure_flat(m, dev), 0)
 tr = FusedTrainer(m, lr=1e-4, world_size=world)
-bls = [300, 410, 350, 280]                                                       # unequal batch_length across ranks
+bls = [int(v) for v in sys.argv[5].split(",")]                                  # unequal batch_length across ranks
 losses = []
 for ci in parallel.shard_indices(4, rank, world):
     x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
@@ -97,25 +97,29 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cuda, tmp_path):
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, cuda, tmp_path):
     """Two fresh child processes share GPU 0 and exchange over gloo (RCCL refuses two ranks on one device); each runs the
     product's FusedTrainer(world_size=2) on chunks of unequal batch_length.  Final weights must be bit-identical across
-    the ranks and equal the numpy oracle trained on the UNION batch of every step (row-weighted mean)."""
+    the ranks and equal the numpy oracle trained on the UNION batch of every step (row-weighted mean).
+    [paper: BASELINE config[2]'s geometry; its forward is the one-launch residual stack (csrc/train_stack.hip), whose two
+    processes' persistent workgroups share the card here -- positions are handed out by tickets, so neither needs all of its
+    workgroups resident to finish.]"""
     from oracle import train_oracle as TO
     port = 29500 + os.getpid() % 2000
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT))
     env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     outs = [str(tmp_path / ("r%d.npz" % r)) for r in range(2)]
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r]], env=env) for r in range(2)]
+    cfg = TINY if cfgname == "tiny" else PAPER
+    bls = [300, 410, 350, 280] if cfgname == "tiny" else [1400, 1750, 1500, 1250]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r], cfgname, ",".join(map(str, bls))], env=env) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=420) == 0
     r0, r1 = np.load(outs[0]), np.load(outs[1])
     np.testing.assert_array_equal(r0["w"], r1["w"])                 # replicas stay bit-identical
-    cfg = TINY
     flat = synth.make_weights(cfg, 3)
     opt = TO.Adam(flat.size)
-    bls = [300, 410, 350, 280]
     for step in range(2):
         gs, ns, ls = [], [], []
         for ci in (2 * step, 2 * step + 1):

@@ -559,22 +559,175 @@ def test_forward_needs_no_maxd_read_back(cuda):
     np.testing.assert_allclose(lg_bound, full[:, 137:], atol=1e-6, rtol=0)      # the last rows of the longer window are the same rows
 
 
-def test_forward_status_is_raised_one_call_late(cuda):
-    """the gather-bounds check of forward i (reference: assert inside forward, qpnet.py:294) is collected without a stream
-    drain at forward i+1 (qpn_train_status_enqueue / _collect)."""
+def test_forward_status_is_raised_before_the_optimizer_step(cuda):
+    """The reference asserts on the gather bounds inside forward (qpnet.py:294).  Here the device-side check costs no stream drain in a
+    training loop: a forward that records a graph enqueues it, and backward() -- i.e. BEFORE any optimizer step the bad chunk could feed --
+    collects it; a forward under torch.no_grad() (nothing else may follow it) checks in the call; model.check_status() collects on demand."""
     import torch
     from qpnet_amd import _lib
     from qpnet_amd.config import TINY
     cfg = TINY
-    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda)
+    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda).train()
     x, h, t, d, b = synth.train_inputs(cfg, 600, 41, 30000)
     xt, ht, dt, bt = _to(cuda, x, h, d, b)
     bad = dt * 40.0                                               # taps far outside the chunk
     with torch.no_grad():
-        m(xt, ht, bad, torch.from_numpy(b))                       # returns: nothing has been read back yet
         with pytest.raises(_lib.QpnError) as e:
-            m(xt, ht, dt, torch.from_numpy(b))
+            m(xt, ht, bad, torch.from_numpy(b))                   # the LAST forward of an eval loop must not go unreported
         assert e.value.code == -4
         lg = m(xt, ht, dt, torch.from_numpy(b))                   # reported once; the module keeps working
-        m(xt, ht, dt, torch.from_numpy(b))
     assert np.isfinite(lg.cpu().numpy()).all()
+    w0 = m.flat_parameters().clone()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    logits = m(xt, ht, bad, torch.from_numpy(b))                  # training forward: returns, nothing has been read back
+    with pytest.raises(_lib.QpnError) as e:
+        logits.sum().backward()
+    assert e.value.code == -4
+    assert torch.equal(m.flat_parameters(), w0)                   # ... and no update was applied
+    logits = m(xt, ht, dt, torch.from_numpy(b)); logits.sum().backward(); opt.step()
+    m(xt, ht, bad, torch.from_numpy(b))                           # a graph-recording forward with no backward behind it ...
+    with pytest.raises(_lib.QpnError):
+        m.check_status()                                          # ... is collected on demand
+    m.check_status()
+
+
+def test_fused_step_reports_a_bad_chunk_at_the_next_step(cuda):
+    """FusedTrainer.step(want_loss=False) never drains the stream: the status word of step i is copied behind it and raised when step i+1
+    starts (one update late, not up to 99 as when it was read every 100 steps); check_status() collects the last step's."""
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import FusedTrainer
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 41, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    maxd = int(np.ceil(d).max())
+    tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)
+    tr.step(xt, ht, tt, dt * 40.0, b, want_loss=False, maxd=maxd)          # bad chunk: enqueued, not yet seen
+    with pytest.raises(_lib.QpnError) as e:
+        tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)
+    assert e.value.code == -4
+    tr.step(xt, ht, tt, dt * 40.0, b, want_loss=False, maxd=maxd)
+    with pytest.raises(_lib.QpnError):
+        tr.check_status()
+    tr.check_status()
+
+
+def _u0_inputs(cfg_u, bl, seed, ml):
+    """a chunk for an upsampling_factor = 0 model: the features arrive at SAMPLE rate (reference qpnet.py:263: no upsampling layer)."""
+    import dataclasses
+    x, h, t, d, b = synth.train_inputs(cfg_u, bl, seed, ml)
+    cfg0 = dataclasses.replace(cfg_u, upsampling_factor=0)
+    h0 = np.ascontiguousarray(np.repeat(h, cfg_u.upsampling_factor, axis=2)[:, :, :x.shape[1] + 3])
+    return cfg0, x, h0, t, d, b
+
+
+@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
+def test_upsampling_factor_zero_train_vs_oracle(cfgname, cuda):
+    """upsampling_factor = 0 (reference src/nets/qpnet.py:203,263: no ConvTranspose2d, h is consumed as given, aligned at its END):
+    logits, loss and every gradient tensor against the numpy oracle; the state_dict has no upsampling.* keys."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import TINY, PAPER
+    cfg0, x, h0, t, d, b = _u0_inputs(TINY if cfgname == "tiny" else PAPER, 700, 33, 5000)
+    flat = synth.make_weights(cfg0, 17)
+    m = util.build_model(cfg0, flat, cuda).train()
+    assert not any(k.startswith("upsampling") for k in m.state_dict())
+    BL = int(b[0])
+    xt, ht, tt, dt, bt = _to(cuda, x, h0, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg0.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg0, flat, x, h0, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    og = TO.backward(cfg0, flat, caches, dl)
+    assert abs(loss.item() - float(oloss)) < 1e-4                  # north_star tolerance
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=2e-5, rtol=0)
+    scale = np.abs(og).max()
+    offs, _ = cfg0.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        assert np.abs(grad[o:o + n] - og[o:o + n]).max() <= 2e-5 * scale + 1e-4 * np.abs(og[o:o + n]).max(), "grad mismatch in " + k
+
+
+def test_full_size_batch2_step_vs_oracle(cuda):
+    """Two full-size chunks per step (batch_length 20000, B = 2: the rows of both items in every contraction, the stack queue's positions
+    over two batch items): loss within the north_star tolerance and every gradient tensor against the numpy oracle."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    x, h, t, d, b = synth.train_inputs(cfg, 20000, 5017, 30000, f0_lo=55.0, f0_hi=300.0)
+    xs = np.random.RandomState(9).randint(0, cfg.n_quantize, size=x.shape[1] + 1).astype(np.int64)
+    x = np.stack([x[0], xs[:-1]]); t = np.stack([t[0], xs[1:]])      # second row: same features (one chunk geometry), another waveform
+    h = np.concatenate([h, h]); d = np.concatenate([d, d]); b = np.concatenate([b, b])
+    BL = int(b[0])
+    m = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=5e-5, rtol=0)
+    og = TO.backward(cfg, flat, caches, dl)
+    scale = np.abs(og).max()
+    offs, _ = cfg.param_offsets()
+    for k, (o, shp) in offs.items():
+        n = int(np.prod(shp))
+        a, r = grad[o:o + n], og[o:o + n]
+        assert np.abs(a - r).max() <= 2e-4 * scale + 2e-3 * np.abs(r).max(), "grad mismatch in " + k
+
+
+def test_forward_maxd_bound_on_paper_with_a_long_chunk(cuda):
+    """train.forward_maxd on the BASELINE geometry with a chunk LONGER than RF + batch_length (the bound then exceeds the true ceil(max d)
+    by far: the layers' row ranges, the tap tables and the stack queue's tile counts all change): same logits as with the exact value."""
+    import torch
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.train import forward_maxd
+    cfg = PAPER
+    m = util.build_model(cfg, synth.make_weights(cfg, 13), cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, 6000, 43, 30000)
+    xt, ht, dt, _ = _to(cuda, x, h, d, b)
+    b2 = torch.tensor([int(b[0]) - 2500])                      # the same chunk with a shorter batch_length
+    true_maxd = int(np.ceil(d).max())
+    assert forward_maxd(m, x.shape[1], h.shape[2], d.shape[1], int(b2[0]), dt) > true_maxd + 100
+    with torch.no_grad():
+        lg_bound = m(xt, ht, dt, b2).cpu().numpy()
+        m.read_back_maxd = True
+        lg_exact = m(xt, ht, dt, b2).cpu().numpy()
+    np.testing.assert_allclose(lg_bound, lg_exact, atol=1e-6, rtol=0)
+
+
+def test_stack_queue_equals_per_layer_launches(cuda, monkeypatch):
+    """The one-launch residual stack (csrc/train_stack.hip: a work queue over (layer, tile) positions, rows handed between workgroups
+    write-through behind flag words) runs the per-layer kernels' arithmetic in their order: logits BIT-identical to QPN_STACK_QUEUE=0,
+    on a full-size chunk and on two batch items; its counters are readable and no wait was abandoned."""
+    import ctypes as C
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    for bl, seed, batch in ((20000, 5000, 1), (900, 78, 2)):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, seed, 30000, f0_lo=55.0, f0_hi=300.0)
+        if batch == 2:
+            x = np.concatenate([x, (x + 7) % cfg.n_quantize]); h = np.concatenate([h, h]); d = np.concatenate([d, d]); b = np.concatenate([b, b])
+        xt, ht, dt, bt = _to(cuda, x, h, d, b)
+        outs = []
+        for q in ("1", "0"):
+            monkeypatch.setenv("QPN_STACK_QUEUE", q)
+            m = util.build_model(cfg, flat, cuda)
+            with torch.no_grad():
+                outs.append(m(xt, ht, dt, bt).cpu().numpy())
+            if q == "1":
+                st = (C.c_uint * 16)()
+                _lib.check(_lib.lib().qpn_train_stack_stats(m._handle, st, 16, None))
+                assert st[1] == 0                                  # the abort word
+        assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
