@@ -85,7 +85,7 @@ def max_over_ranks(v, world, dev):
 
 def measured_traffic():
     """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (committed under profiles/)."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -290,6 +290,42 @@ def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=30):
     return steps / (time.perf_counter() - t0)
 
 
+def runner_loop_rate(m, tr, cfg, dev, steps=150):
+    """What `python -m qpnet_amd.run_train` does per iteration (runners.run_train: loaders.train_generator -> PinnedStager -> a depth-2
+    prefetch thread -> FusedTrainer.step(want_loss=True): the loss is read back every step, as the reference reads loss.item(),
+    src/bin/qpnet_train.py:533) on an in-memory corpus of synthetic utterances of VCC2018 shape."""
+    import torch
+    from qpnet_amd import loaders, synth
+    from qpnet_amd.runners import PinnedStager, Prefetcher
+    U = cfg.upsampling_factor
+    rs = np.random.RandomState(0)
+    utts = []
+    for i in range(24):
+        nf = int(rs.randint(600, 1200))                 # 3-6 s utterances
+        utts.append((rs.uniform(-1, 1, nf * U + 5).astype(np.float32), synth.make_features(nf, 400 + i, 45.0, 300.0)))
+    mean, scale = synth.scaler_stats()
+    np.random.seed(1)
+    gen = loaders.train_generator(utts, cfg.receptiveCausal_field, cfg.receptiveF_field, cfg.receptiveA_field, 22050,
+                                  wav_transform=loaders.mu_law_transform(cfg.n_quantize), feat_transform=lambda h: (h - mean) / scale,
+                                  batch_length=20000, max_length=30000, upsampling_factor=U, shuffle=True)
+    stage = PinnedStager(dev)
+
+    def batches():
+        for bx, bh, bt, bd, bb in gen:
+            dv = stage({"x": bx, "h": bh, "t": bt, "d": bd})
+            yield dv["x"], dv["h"], dv["t"], dv["d"], bb, int(np.ceil(float(bd.max())))
+    stream = Prefetcher(batches())
+    for _ in range(5):
+        bx, bh, bt, bd, bb, maxd = next(stream)
+        tr.step(bx, bh, bt, bd, bb, want_loss=True, maxd=maxd)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        bx, bh, bt, bd, bb, maxd = next(stream)
+        tr.step(bx, bh, bt, bd, bb, want_loss=True, maxd=maxd)
+    torch.cuda.synchronize()
+    return steps / (time.perf_counter() - t0)
+
+
 def run_train(args, rank, local, world):
     import ctypes as C
     import torch
@@ -311,7 +347,9 @@ def run_train(args, rank, local, world):
         parallel.broadcast_parameters(ensure_flat(m, dev))          # every rank starts from rank 0's parameters
     # utterance-sharded synthetic chunks: rank r consumes chunks r, r+world, ...
     nchunks = 4
-    host_batches = [synth.train_inputs(cfg, 20000, 5000 + 17 * (rank + world * i), 30000, f0_lo=55.0, f0_hi=300.0) for i in range(nchunks)]
+    # SURVEY 8d's config[2] shape: batch_length 20000 / max_length 30000, the corpus' pitch floor 45 Hz in every chunk -> ceil(max d) 62,
+    # RF 946, (RF + BL) % 110 trimmed: 20 900 samples per chunk, 19 954 output rows
+    host_batches = [synth.train_inputs(cfg, 20000, 5000 + 17 * (rank + world * i), 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True) for i in range(nchunks)]
     batches = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in hb] for hb in host_batches]
     # the loader knows ceil(max d) of a chunk on the host (it built d there), so the step needs no device read-back
     maxds = [int(np.ceil(hb[3]).max()) for hb in host_batches]
@@ -363,17 +401,25 @@ def run_train(args, rank, local, world):
                    "backend": BACKEND, "world_size": (dist.get_world_size() if dist.is_initialized() else 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None,
-                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, the weight-gradient launches of one step)" % (measured_traffic() or {}).get("_file"),
+                     "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_by_group", {}).get(PG_NAMES[dom],
+                                    (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None),
+                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, the launches of the named group in one step; commit %s)"
+                                       % ((measured_traffic() or {}).get("_file"), (measured_traffic() or {}).get("commit", "?")),
+                     "step_traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step_all_kernels"),
                      "kernel": PG_NAMES[dom],
                      "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
+                     # the whole step against the same peak: algorithmic FLOPs of every group / the timed loop's ms_per_step
+                     "step_flops": total_flops, "step_achieved": total_flops / (dt / args.steps) / 1e12,
+                     "step_frac": total_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
                      "note": "achieved = algorithmic FLOPs of the dominant kernel group (all its launches in one step) / its summed "
                              "device time from HIP events on the launch stream; step_tflops = whole step"},
     }
     if world == 1 and not args.no_cpu:
         # the drop-in path north_star describes: the reference's own loop on this module (weights keep training; timing only)
+        # the loop `python -m qpnet_amd.run_train` runs: generator + pinned staging + prefetch thread + step(want_loss=True)
+        out["runner_loop_steps_per_s"] = runner_loop_rate(m, tr, cfg, dev)
         out["dropin_loop_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=False)
         out["dropin_loop_flat_adam_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=True)
     if rank == 0 and world == 1 and not args.no_cpu:

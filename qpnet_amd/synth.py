@@ -90,7 +90,7 @@ def decode_inputs(cfg: QPNetConfig, n_frames: int, seed: int = 1, f0_factor: flo
 
 
 def train_inputs(cfg: QPNetConfig, batch_length: int, seed: int = 1, max_length: int = 30000,
-                 f0_lo: float = 80.0, f0_hi: float = 300.0, batch_size: int = 1):
+                 f0_lo: float = 80.0, f0_hi: float = 300.0, batch_size: int = 1, pin_f0_floor: bool = False):
     """One training batch shaped like ``train_generator`` yields it
     (reference src/bin/qpnet_train.py:250-327): x (B,T) int64, h (B,n_aux,F) f32,
     t (B,T) int64 targets, d (B,T) f32, blength (B,) int64."""
@@ -100,6 +100,8 @@ def train_inputs(cfg: QPNetConfig, batch_length: int, seed: int = 1, max_length:
     n_frames = (max_length + batch_length) // U + 8
     for b in range(batch_size):
         h = make_features(n_frames, seed + 1000 * b, f0_lo, f0_hi, cfg.n_aux)
+        if pin_f0_floor:      # the lowest pitch of the chunk IS the stated floor, so ceil(max d) -- and with it the receptive field -- is the stated one
+            h[int(np.argmin(h[:min(n_frames, 150), 1])), 1] = np.float32(f0_lo)
         d = harness.dilated_factor(harness.batch_f0(h, 0), FS, DENSE_FACTOR)
         d = harness.extend_time(d[:, None], U)[:, 0].astype(np.float32)
         rf, bl, h_bs, x_bs = harness.train_chunk_geometry(cfg, d, batch_length, max_length)

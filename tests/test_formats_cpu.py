@@ -44,6 +44,26 @@ def test_hdf5_roundtrip_and_errors(h5stub, tmp_path):
     np.testing.assert_array_equal(loaders.read_features(str(tmp_path / "b.npy")), w)
 
 
+def test_hdf5_against_a_real_h5py(tmp_path):
+    """On any box that HAS h5py (this image does not: skipped here) the /world wrappers meet real HDF5 files: one written by h5py the way
+    the reference's feature extraction writes it (utils.py:90-128: a float dataset under /world) is read by loaders.read_hdf5 / shape_hdf5,
+    and one written by loaders.write_hdf5 is opened by h5py."""
+    h5py = pytest.importorskip("h5py")
+    assert "stubs" not in getattr(h5py, "__file__", "")
+    w = np.random.RandomState(1).randn(57, 39).astype(np.float32)
+    f = str(tmp_path / "real.h5")
+    with h5py.File(f, "w") as fh:
+        fh.create_dataset("/world", data=w)
+        fh.create_dataset("/world_stats/mean", data=w.mean(0))
+    np.testing.assert_array_equal(loaders.read_hdf5(f, "/world"), w)
+    np.testing.assert_array_equal(loaders.read_features(f), w)
+    assert tuple(loaders.shape_hdf5(f, "/world")) == w.shape
+    g = str(tmp_path / "mine.h5")
+    loaders.write_hdf5(g, "/world", w * 3)
+    with h5py.File(g, "r") as fh:
+        np.testing.assert_array_equal(fh["/world"][()], w * 3)
+
+
 def test_scaler_stats_like_calc_stats(h5stub, tmp_path):
     """calc_stats.py:19-37: StandardScaler.partial_fit over dims 1.., uv dim keeps mean 0 / scale 1; read back the way
     the task scripts rebuild their scaler (qpnet_train.py:433-436)."""
