@@ -153,6 +153,9 @@ int qpn_train_status(qpn_handle* h, void* stream);
  * step i is raised at step i+1 (reference: assert at step i, qpnet.py:294), and no step is serialised for it. */
 int qpn_train_status_enqueue(qpn_handle* h, void* stream);
 int qpn_train_status_collect(qpn_handle* h);
+/* ... every enqueued check EXCEPT the newest one: never waits for the work the device still has queued (a fused training loop calls it
+ * at the start of every step and reports a bad chunk two steps late at most; reference: the in-line asserts of qpnet.py:294, qpnet_train.py:525). */
+int qpn_train_status_collect_lagged(qpn_handle* h);
 
 /* torch.nn.CrossEntropyLoss() (mean) on the logits above and, optionally, its gradient
  * (reference src/bin/qpnet_train.py:430,526-528; a target outside [0, n_quantize) is clamped and flagged: qpn_train_status

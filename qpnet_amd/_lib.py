@@ -42,6 +42,7 @@ SYMBOLS = [
     ("qpn_train_status", _i, [_vp, _vp]),
     ("qpn_train_status_enqueue", _i, [_vp, _vp]),
     ("qpn_train_status_collect", _i, [_vp]),
+    ("qpn_train_status_collect_lagged", _i, [_vp]),
     ("qpn_train_forward_loss", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     ("qpn_train_loss", _i, [_vp, C.POINTER(C.c_double), _vp]),
     ("qpn_ce_loss", _i, [_vp, _vp, _vp, _i64, _i, _i, _vp, C.POINTER(C.c_double), _vp]),

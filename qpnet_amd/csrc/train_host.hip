@@ -28,7 +28,7 @@ struct TrainState {
     float* d_ws; size_t ws_cap;               // one arena, carved per call
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
-    int* h_status_pinned; hipEvent_t ev_status; bool status_pending;      // qpn_train_status_enqueue / _collect: the deferred check
+    int* h_status_pinned; hipEvent_t ev_status[2]; bool status_pending[2]; int status_newest;      // qpn_train_status_enqueue / _collect: the deferred check, two slots
     bool fwd_valid;
     bool loss_clear;                          // the loss accumulator is zero (cleared by the forward's refresh kernel, consumed by one CE call)
     bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
@@ -295,9 +295,10 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
     QPN_HIP(hipMemset(t->d_status, 0, 64));
-    t->h_status_pinned = nullptr; t->ev_status = nullptr; t->status_pending = false;
+    t->h_status_pinned = nullptr; t->ev_status[0] = t->ev_status[1] = nullptr; t->status_pending[0] = t->status_pending[1] = false; t->status_newest = 0;
     QPN_HIP(hipHostMalloc((void**)&t->h_status_pinned, 64, hipHostMallocDefault));
-    QPN_HIP(hipEventCreateWithFlags(&t->ev_status, hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_status[0], hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_status[1], hipEventDisableTiming));
     QPN_HIP(hipMalloc(&t->d_loss, 64 * sizeof(double)));
     if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -358,7 +359,7 @@ void qpn_train_destroy(TrainState* t) {
     void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct, t->d_sq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
-    if (t->ev_status) (void)hipEventDestroy(t->ev_status);
+    for (int i = 0; i < 2; ++i) if (t->ev_status[i]) (void)hipEventDestroy(t->ev_status[i]);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -519,7 +520,7 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) QPN_HIP(hipMemset(h->train->d_status, 0, sizeof(int)));          // sticky until read: reported once
-    h->train->status_pending = false;
+    h->train->status_pending[0] = h->train->status_pending[1] = false;
     return status_to_rc(st);
 }
 
@@ -530,28 +531,48 @@ static int status_to_rc(int st) {
     return QPN_OK;
 }
 
-// The same check without draining the stream: _enqueue copies the (sticky) status word to pinned memory behind the work
-// enqueued so far and returns; _collect -- typically at the start of the NEXT forward -- waits for that copy only (long done)
-// and reports it.  An out-of-range tap / target of step i is then raised at step i+1 instead of serialising every step.
+// The same check without draining the stream: _enqueue copies the (sticky) status word to pinned memory behind the work enqueued so
+// far and returns; _collect waits for the copies only and reports them.  Two slots: _collect_lagged looks at every enqueued check
+// EXCEPT the newest -- a training loop that calls it at the start of step i + 1 never waits for step i (whose kernels the device still has
+// queued while the host enqueues the next step), and reports a bad chunk two steps late at most.
+static int status_collect_slot(TrainState* t, int slot) {
+    if (!t->status_pending[slot]) return QPN_OK;
+    QPN_HIP(hipEventSynchronize(t->ev_status[slot]));
+    t->status_pending[slot] = false;
+    const int st = t->h_status_pinned[slot];
+    if (st) {
+        QPN_HIP(hipMemset(t->d_status, 0, sizeof(int)));              // sticky until read: reported once ...
+        const int other = slot ^ 1;                                   // ... also where the other slot copied the same sticky bits before this clear
+        if (t->status_pending[other]) {
+            QPN_HIP(hipEventSynchronize(t->ev_status[other]));
+            t->h_status_pinned[other] &= ~st;
+            if (!t->h_status_pinned[other]) t->status_pending[other] = false;
+        }
+    }
+    return status_to_rc(st);
+}
 extern "C" int qpn_train_status_enqueue(qpn_handle* h, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!h->train) { qpn_set_error("no training call yet"); return QPN_ESTATE; }
     TrainState* t = h->train;
-    if (t->status_pending) { rc = qpn_train_status_collect(h); if (rc) return rc; }
-    QPN_HIP(hipMemcpyAsync(t->h_status_pinned, t->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
-    QPN_HIP(hipEventRecord(t->ev_status, (hipStream_t)stream_));
-    t->status_pending = true;
+    const int slot = t->status_newest ^ 1;
+    rc = status_collect_slot(t, slot); if (rc) return rc;            // (two enqueues old: long done)
+    QPN_HIP(hipMemcpyAsync(t->h_status_pinned + slot, t->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    QPN_HIP(hipEventRecord(t->ev_status[slot], (hipStream_t)stream_));
+    t->status_pending[slot] = true; t->status_newest = slot;
     return QPN_OK;
 }
 extern "C" int qpn_train_status_collect(qpn_handle* h) {
     int rc = need_dev(h); if (rc) return rc;
-    if (!h->train || !h->train->status_pending) return QPN_OK;
+    if (!h->train) return QPN_OK;
     TrainState* t = h->train;
-    QPN_HIP(hipEventSynchronize(t->ev_status));
-    t->status_pending = false;
-    const int st = *t->h_status_pinned;
-    if (st) QPN_HIP(hipMemset(t->d_status, 0, sizeof(int)));          // sticky until read: reported once
-    return status_to_rc(st);
+    rc = status_collect_slot(t, t->status_newest ^ 1); if (rc) return rc;
+    return status_collect_slot(t, t->status_newest);
+}
+extern "C" int qpn_train_status_collect_lagged(qpn_handle* h) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train) return QPN_OK;
+    return status_collect_slot(h->train, h->train->status_newest ^ 1);
 }
 
 extern "C" int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, int64_t tgt_stride, int B, int BL,

@@ -299,8 +299,9 @@ class FusedTrainer:
     state_dict()/load_state_dict() use torch.optim.Adam's layout (resume of reference-made checkpoints and vice versa)."""
 
     # The device-side status word (bad taps / targets; the reference asserts in-line, qpnet.py:294, qpnet_train.py:525) is copied to pinned
-    # memory behind every step and looked at when the NEXT step starts (no stream drain): a bad chunk is raised one step late, i.e. with
-    # one Adam update applied, not up to 99 as when it was read every 100 steps.  check_status() collects the last one.
+    # memory behind every step; a step starts by looking at the copy made TWO steps earlier (the previous step is still queued on the
+    # device while the host enqueues this one: waiting for it would idle the GPU).  A bad chunk is raised two steps late at most, not up to 99
+    # as when the word was read every 100 steps.  check_status() collects everything outstanding.
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, process_group=None, world_size=1):
         self.model = model
@@ -348,7 +349,7 @@ class FusedTrainer:
         loss = C.c_double(0.0)
         multi = self.world > 1
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_train_status_collect(hd))       # the previous step's check
+            _lib.check(L.qpn_train_status_collect_lagged(hd))       # the check of the step before the previous one (never waits for queued work)
             # forward + CrossEntropyLoss + dL/dlogits in one call (the loss stays on the device unless asked for)
             _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                                 x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],

@@ -592,8 +592,8 @@ def test_forward_status_is_raised_before_the_optimizer_step(cuda):
 
 
 def test_fused_step_reports_a_bad_chunk_at_the_next_step(cuda):
-    """FusedTrainer.step(want_loss=False) never drains the stream: the status word of step i is copied behind it and raised when step i+1
-    starts (one update late, not up to 99 as when it was read every 100 steps); check_status() collects the last step's."""
+    """FusedTrainer.step(want_loss=False) never drains the stream: the status word of step i is copied behind it and raised when step i+2
+    starts at the latest (not up to 99 steps late as when it was read every 100 steps); check_status() collects everything outstanding."""
     import torch
     from qpnet_amd import _lib
     from qpnet_amd.config import TINY
@@ -607,7 +607,8 @@ def test_fused_step_reports_a_bad_chunk_at_the_next_step(cuda):
     tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)
     tr.step(xt, ht, tt, dt * 40.0, b, want_loss=False, maxd=maxd)          # bad chunk: enqueued, not yet seen
     with pytest.raises(_lib.QpnError) as e:
-        tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)
+        tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)             # (may still be queued on the device ...)
+        tr.step(xt, ht, tt, dt, b, want_loss=False, maxd=maxd)             # ... two steps later it has been seen
     assert e.value.code == -4
     tr.step(xt, ht, tt, dt * 40.0, b, want_loss=False, maxd=maxd)
     with pytest.raises(_lib.QpnError):

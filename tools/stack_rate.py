@@ -9,7 +9,7 @@ import util
 cuda = torch.device("cuda:0")
 m = util.build_model(PAPER, synth.make_weights(PAPER, 13), cuda).train()
 tr = FusedTrainer(m, lr=1e-4)
-hbs = [synth.train_inputs(PAPER, 20000, 5000 + 17 * i, 30000, f0_lo=55.0, f0_hi=300.0) for i in range(4)]
+hbs = [synth.train_inputs(PAPER, 20000, 5000 + 17 * i, 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True) for i in range(4)]      # bench.py's shape
 bts = [[torch.from_numpy(np.ascontiguousarray(a)).to(cuda) for a in hb[:4]] for hb in hbs]
 maxds = [int(np.ceil(hb[3]).max()) for hb in hbs]
 for i in range(30): tr.step(*bts[i % 4], hbs[i % 4][4], want_loss=False, maxd=maxds[i % 4])
