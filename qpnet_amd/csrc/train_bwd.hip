@@ -1372,7 +1372,10 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
     return QPN_OK;
 }
 
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, hipStream_t stream) {
+bool qpn_stack_bwd_fits(const TrainParams& p);
+int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, hipStream_t stream);
+
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
     constexpr int MT = TR_MT, TM = 16 * MT;
@@ -1514,7 +1517,11 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
     const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && off32 && !split && !(getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 0);
     const int wg_per_cu = getenv("QPN_LAYER_BWD_WGS") ? atoi(getenv("QPN_LAYER_BWD_WGS")) : 2;
-    for (int l = L - 1; l >= 0; --l) {
+    // the whole stack's backward as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE_BWD=0 (or
+    // QPN_STACK_QUEUE=0) keeps a launch per layer
+    const bool stack_q = persist && sq && sq->flags && p.qctl && mid == L && qpn_stack_bwd_fits(p) && !getenv("QPN_BWDP_STAMPS");
+    if (stack_q) { const int rcq = qpn_launch_stack_bwd(p, bw, *sq, stream); if (rcq) return rcq; }
+    for (int l = L - 1; l >= 0 && !stack_q; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
         if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)

@@ -54,6 +54,7 @@ struct TrainParams {
     float* scratch_rows;      // [B * 1024 workgroups][2][128] floats nobody reads: target of the persistent kernels' out-of-range row stores
     unsigned* qctl;           // control words of the stack work queues (train_stack.hip), control words and sub-queue heads zeroed by k_train_prep; or nullptr
     int4* qtab;               // [qtotal + 1][2] tile table of the forward queue, written by k_train_prep (tr_queue_entry_fwd); or nullptr
+    int4* qtab_b;             // ... and of the backward queue (tr_queue_entry_bwd)
     int qtotal;               // positions of a queue: sum over layers of B * qT[l]
     int qP[TR_MAXL + 1];      // first position of layer l (forward order)
     int qT[TR_MAXL];          // 16-row tiles per batch item in layer l
@@ -126,6 +127,37 @@ __device__ __forceinline__ void tr_queue_entry_fwd(const TrainParams& p, int pos
     }
     a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0), first, n);
     b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, 0);
+}
+
+// The backward queue runs the layers from the last to the first (position blocks in that order, tiles by ascending rows).  Entry of tile
+// (l, t), rows n0 .. n0 + 15 of layer l's OUTPUT gradient (= grads w.r.t. X[l + 1]):
+//   a = {n0, layer | batch item << 8 | last layer << 24 | valid << 25 | adaptive << 26, first producer position, producer positions}
+//   b = {row offset (l * B + b) * N1 of the layer's arrays, tap table offset, b * N1, float offset of the skip-path gate grads b * BL * LC + l * C}
+// producers: the tiles of layer l + 1 whose own rows or pitch-tap scatter touch rows n0 .. n0 + 15 of its INPUT gradient, i.e. its rows
+// n0 .. n0 + 15 + reach(l + 1) (autograd of the gather, reference src/nets/qpnet.py:295-298, 626-640)
+__device__ __forceinline__ void tr_queue_entry_bwd(const TrainParams& p, int pos, int4& a, int4& b) {
+    const bool valid = pos < p.qtotal;
+    const int ps = valid ? pos : 0;
+    int k = 0, base = 0;                              // k-th processed layer = layer L - 1 - k
+    for (int j = 0; j + 1 < p.L; ++j) { const int n = p.B * p.qT[p.L - 1 - j]; if (ps >= base + n) { base += n; k = j + 1; } else break; }
+    const int l = p.L - 1 - k;
+    const int r = ps - base, T = p.qT[l];
+    const int bi = r / T, t = r - bi * T;
+    const TrLayer ly = p.layers[l];
+    const int n0 = ly.s_out + 16 * t;
+    int first = 0, n = 0;
+    if (valid && l < p.L - 1) {
+        const TrLayer up = p.layers[l + 1];
+        const int reach = up.s_out - up.s_in;
+        int lo = n0 - up.s_out; if (lo < 0) lo = 0;
+        int hi = n0 + 15 + reach; if (hi > p.N1 - 1) hi = p.N1 - 1;
+        hi -= up.s_out;
+        const int t_lo = lo >> 4, t_hi = hi >> 4;
+        const int pbase = base - p.B * p.qT[l + 1];   // layer l + 1 is the block in front of this one
+        first = pbase + bi * p.qT[l + 1] + t_lo; n = t_hi - t_lo + 1;
+    }
+    a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0) | (ly.adaptive ? 1 << 26 : 0), first, n);
+    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, bi * p.BL * p.LC + l * p.C);
 }
 
 // Host-side only: the second stream and events of the two-part time split of the layer kernels (owned by TrainState).

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
         for (int pos = blockIdx.x * 256 + threadIdx.x; pos <= p.qtotal; pos += gridDim.x * 256) {
             int4 ea, eb; tr_queue_entry_fwd(p, pos, ea, eb);
             p.qtab[2 * pos] = ea; p.qtab[2 * pos + 1] = eb;
+            if (p.qtab_b) { tr_queue_entry_bwd(p, pos, ea, eb); p.qtab_b[2 * pos] = ea; p.qtab_b[2 * pos + 1] = eb; }
         }
     for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += gridDim.x * 256) {
         if (it < nX) {

@@ -10,7 +10,7 @@
 int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq, hipStream_t stream);
 void qpn_stack_fill(TrainParams& p);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, const StackQ* sq, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
@@ -38,6 +38,7 @@ struct TrainState {
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
     TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
+    int64_t bwd_generation;                                  // generation of the forward the last backward belonged to
     unsigned* d_sq; size_t sq_pos_cap, sq_per_dir;                           // stack work queues (train_stack.hip): [16 control words | forward flags | backward flags]
     StackQ sqf, sqb;
 };
@@ -151,7 +152,7 @@ static int train_init(qpn_handle* h) {
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
-    t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
+    t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; t->bwd_generation = -1; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -453,10 +454,11 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
         }
         p.qctl = t->d_sq;
         p.qtab = (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
+        p.qtab_b = p.qtab + 2 * (t->sq_pos_cap + 1);
         const unsigned epoch = (unsigned)((t->generation + 1) % 0xFFFFFFFFll) + 1u;      // (generation is bumped below; never 0)
         StackQ& f = t->sqf; StackQ& bq = t->sqb;
         f.flags = t->d_sq + TR_QHDR_WORDS; f.head = t->d_sq + 1024; f.abort = t->d_sq + 1; f.stats = t->d_sq + 4; f.epoch = epoch; f.total = p.qtotal; f.tab = p.qtab;
-        bq.flags = f.flags + t->sq_per_dir; bq.head = f.head + 8 * TR_QHEAD_STRIDE; bq.abort = f.abort; bq.stats = t->d_sq + 8; bq.epoch = epoch; bq.total = p.qtotal; bq.tab = p.qtab + 2 * (t->sq_pos_cap + 1);
+        bq.flags = f.flags + t->sq_per_dir; bq.head = f.head + 8 * TR_QHEAD_STRIDE; bq.abort = f.abort; bq.stats = t->d_sq + 8; bq.epoch = epoch; bq.total = p.qtotal; bq.tab = p.qtab_b;
     }
     p.flat = d_flat; p.wp = (const float4*)t->d_wp; p.bp = t->d_bp; p.x = d_x; p.h = d_h; p.d = d_dfac; p.logits = d_logits;
     // ---- refresh the fragment-ordered weights / packed biases from the current parameters
@@ -618,7 +620,11 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
-    return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_) : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, (hipStream_t)stream_);
+    // (the backward queue's heads and flags belong to ONE backward per forward: a repeated backward of the same forward runs a launch per layer)
+    const bool first_bwd = t->bwd_generation != t->generation;
+    t->bwd_generation = t->generation;
+    return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_)
+                       : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,

@@ -49,7 +49,7 @@ __device__ __forceinline__ float sq_tanh(float z) { return 2.0f * __builtin_amdg
 // i.e. behind one memory channel (measured: waits of 20-180 us on flags published long before).
 __host__ __device__ __forceinline__ static unsigned sq_fidx(unsigned pos) { return (pos >> 5) * SQ_FLINE + (pos & 31u); }
 
-struct SqTile { int n0, meta, dfirst, dn, xrow, tapb, hrow, pos; };       // wave-uniform (SGPRs); meta: layer | batch item << 8 | last << 24 | valid << 25
+struct SqTile { int n0, meta, dfirst, dn, xrow, tapb, hrow, dgs, pos; };       // wave-uniform (SGPRs); meta: layer | batch item << 8 | last << 24 | valid << 25
 __device__ __forceinline__ bool sq_valid(const SqTile& d) { return (d.meta >> 25) & 1; }
 __device__ __forceinline__ bool sq_last(const SqTile& d) { return (d.meta >> 24) & 1; }
 __device__ __forceinline__ int sq_layer(const SqTile& d) { return d.meta & 255; }
@@ -65,7 +65,7 @@ __device__ __forceinline__ SqRaw sq_fetch(const StackQ& q, int pos) {
 __device__ __forceinline__ SqTile sq_take(const SqRaw& r) {
     SqTile d;
     d.n0 = sq_rfl(r.a.x); d.meta = sq_rfl(r.a.y); d.dfirst = sq_rfl(r.a.z); d.dn = sq_rfl(r.a.w);
-    d.xrow = sq_rfl(r.b.x); d.tapb = sq_rfl(r.b.y); d.hrow = sq_rfl(r.b.z); d.pos = r.pos;
+    d.xrow = sq_rfl(r.b.x); d.tapb = sq_rfl(r.b.y); d.hrow = sq_rfl(r.b.z); d.dgs = sq_rfl(r.b.w); d.pos = r.pos;
     return d;
 }
 
@@ -340,6 +340,262 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
     if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
 }
 
+// ------------------------------------------------------------------------------------------------ backward
+// The layer backward of k_layer_bwd_p (train_bwd.hip: dg = dXout . Wr^T + skip-path grads, dz = dg * gate', d[x_cur | x_past | aux] = dZ . W1^T,
+// the pitch-tap part scattered to its tap rows) over the same kind of queue, layers from the last to the first.  What is handed between
+// workgroups here: the own-row part of the input gradient (write-through rows, a unique writer) and the scattered part (float atomics --
+// they execute at the memory side -- for the adaptive blocks, write-through rows for the fixed ones); a tile is published when both have
+// completed (vmcnt counts the atomics too), and its consumers -- the tiles of the layer below whose rows it touched -- read both parts with
+// sc1 loads.  dZ, sigma / tanh, the skip-path grads and the aux-feature gradient are not handed over inside the launch (plain accesses / atomics).
+// dynamic LDS: staging {Dx | Sg | Th | Dg}[2][16][ldx] | Dz [16][ldz] | Os [16][ldo] | control words
+template <int NTK>
+__global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw, StackQ q) {
+    constexpr int C = 64;
+    constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
+    constexpr int NJ = (NTK + 3) / 4;
+    extern __shared__ float sm[];
+    float* Dz = sm + 8 * 16 * ldx;
+    float* Os = Dz + 16 * ldz;
+    int* ctl = (int*)(Os + 16 * ldo);
+    const int Ap = p.Ap, N1 = p.N1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = sq_rfl(tid >> 6);
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const int zrow = tid >> 6, zc2 = (tid & 63) * 2;
+    const int arow = lane & 15, ak = lane >> 4;
+    const int c = 16 * wave + (lane & 15);
+    const int win0 = N1 - p.BL;
+    const unsigned xbytes = (unsigned)N1 * C * 4u;
+    const size_t nDX = (size_t)p.B * N1 * C;
+    float* const dmy = p.scratch_rows + (size_t)blockIdx.x * 2 * 128;       // two 512-byte scratch rows per workgroup
+
+    float4 wr[4], w1[NJ][8];
+    auto load_weights = [&](int l, bool last) {
+        const TrLayer ly = p.layers[l];
+        const float4* Wrt = p.wp + ly.wrt_f4; const float4* W1t = p.wp + ly.w1t_f4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { const float4 v = Wrt[((size_t)ks * 4 + wave) * 64 + lane]; wr[ks] = last ? make_float4(0.f, 0.f, 0.f, 0.f) : v; }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nt = wave + 4 * j < NTK ? wave + 4 * j : NTK - 1;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) w1[j][ks] = W1t[((size_t)ks * NTK + nt) * 64 + lane];
+        }
+    };
+    auto rsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
+    float4 ra, rb2, rsg, rth, rdg;
+    auto load_rows = [&](const SqTile& d) {
+        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
+        const unsigned o = __umul24((unsigned)nn, (unsigned)C) + 4u * sc4;
+        // grads w.r.t. this layer's output = the input gradient of the layer above (nothing for the last layer: dropped by the range check)
+        const unsigned ob = sq_last(d) ? SQ_OOB : o * 4u;
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc(bw.DXA[0] + (size_t)d.xrow * C + nDX), (int)ob, 0, SQ_SC1);
+        const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc(bw.DXB[0] + (size_t)d.xrow * C + nDX), (int)ob, 0, SQ_SC1);
+        ra = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        rb2 = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
+        rsg = *(const float4*)(p.SG + (size_t)d.xrow * C + o); rth = *(const float4*)(p.TH + (size_t)d.xrow * C + o);
+        const int nw = nn >= win0 ? nn - win0 : 0;
+        rdg = *(const float4*)(bw.DGS + (size_t)d.dgs + (__umul24((unsigned)nw, (unsigned)p.LC) + 4u * sc4));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_rows = [&](const SqTile& d, float* B) {
+        const int n = d.n0 + srow;
+        const bool in = n < N1;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 dx = (in && !sq_last(d)) ? make_float4(ra.x + rb2.x, ra.y + rb2.y, ra.z + rb2.z, ra.w + rb2.w) : z;
+        const float4 sg = in ? rsg : z, th = in ? rth : z, dg = (in && n >= win0) ? rdg : z;
+        float* d0 = B + (size_t)srow * ldx + 4 * sc4;
+        *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
+        float* d1 = d0 + 16 * ldx; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
+        float* d2 = d1 + 16 * ldx; *(float2*)d2 = make_float2(th.x, th.y); *(float2*)(d2 + 2) = make_float2(th.z, th.w);
+        float* d3 = d2 + 16 * ldx; *(float2*)d3 = make_float2(dg.x, dg.y); *(float2*)(d3 + 2) = make_float2(dg.z, dg.w);
+    };
+    int tprow[4], tpnext[4];
+    auto load_taps = [&](const SqTile& d, int (&tp)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int n = d.n0 + 4 * wave + i; tp[i] = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1]; }
+    };
+    // the tile's outputs (behind B3: Os and the tile's Dx are complete in LDS)
+    auto outputs = [&](const SqTile& d, const float* Dx) {
+        const bool adaptive = (d.meta >> 26) & 1;
+        const int dil = p.layers[sq_layer(d)].dilation;
+        {   // own-row part (+ residual path): 16 bytes per thread, write-through
+            const int n = d.n0 + srow;
+            const float2 o0 = *(const float2*)(Os + (size_t)srow * ldo + 4 * sc4), o1 = *(const float2*)(Os + (size_t)srow * ldo + 4 * sc4 + 2);
+            const float2 x0 = *(const float2*)(Dx + (size_t)srow * ldx + 4 * sc4), x1 = *(const float2*)(Dx + (size_t)srow * ldx + 4 * sc4 + 2);
+            const u32x4 v = {__float_as_uint(o0.x + x0.x), __float_as_uint(o0.y + x0.y), __float_as_uint(o1.x + x1.x), __float_as_uint(o1.y + x1.y)};
+            const unsigned off = n < N1 ? (__umul24((unsigned)n, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc(bw.DXA[0] + (size_t)d.xrow * C), (int)off, 0, SQ_SC1);
+            if (!adaptive) {   // fixed block: the tap row n - dilation has this one writer
+                const float2 p0 = *(const float2*)(Os + (size_t)srow * ldo + C + 4 * sc4), p1 = *(const float2*)(Os + (size_t)srow * ldo + C + 4 * sc4 + 2);
+                const u32x4 w = {__float_as_uint(p0.x), __float_as_uint(p0.y), __float_as_uint(p1.x), __float_as_uint(p1.y)};
+                const int tr = n - dil;
+                const unsigned offb = (n < N1 && tr >= 0) ? (__umul24((unsigned)tr, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(w, rsrc(bw.DXB[0] + (size_t)d.xrow * C), (int)offb, 0, SQ_SC1);
+            }
+        }
+        float* DBout = bw.DXB[0] + (size_t)d.xrow * C;
+        float* DH = bw.DHUP + (size_t)d.hrow * Ap;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // wave w owns rows 4w .. 4w+3, lane = channel: one 256-byte row per instruction
+            const int r = 4 * wave + i, n = d.n0 + r;
+            const bool in = n < N1;
+            if (adaptive) {                // gather backward (collisions): ONE full-row float-atomic instruction per tap row
+                float* db = DBout + (__umul24((unsigned)tprow[i], (unsigned)C) + lane);
+                atomicAdd(in ? db : dmy + 128 + lane, Os[(size_t)r * ldo + C + lane]);
+            }
+            if (lane < Ap) {
+                float* dh = DH + (__umul24((unsigned)n, (unsigned)Ap) + lane);
+                atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);
+            }
+        }
+    };
+    auto publishes = [&](const SqTile& d) { return sq_valid(d) && sq_layer(d) > 0; };     // (layer 0's input gradient feeds later kernels only)
+
+    int zero_v; asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const int NQ = q.nq, sub = (blockIdx.x / 8) % NQ;
+    unsigned* const head = q.head + sub * TR_QHEAD_STRIDE + zero_v;
+    if (tid == 0) {
+        ctl[8] = 0;
+        const unsigned k0 = atomicAdd(head, 1u); ctl[0] = (int)(k0 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k1 = atomicAdd(head, 1u); ctl[1] = (int)(k1 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k2 = atomicAdd(head, 1u); ctl[2] = (int)(k2 * NQ + sub);
+    }
+    __syncthreads();
+    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1]))), nn = sq_take(sq_fetch(q, sq_rfl(ctl[2])));
+    if (!sq_valid(cur)) return;
+    SqTile prev = cur; prev.meta = 0;
+    int lw = sq_layer(cur);
+    load_weights(lw, sq_last(cur));
+    sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
+    load_rows(cur);
+    load_taps(cur, tprow);
+    store_rows(cur, sm);
+    load_taps(next, tpnext);
+    bool cur_published = false;
+    for (int it = 0;; ++it) {
+        float* Dx = sm + (it & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
+        const bool last = sq_last(cur);
+        unsigned rtk = 0;
+        if (tid == 0) rtk = atomicAdd(head, 1u);
+        if (sq_layer(cur) != lw) { lw = sq_layer(cur); load_weights(lw, last); }
+        const bool pub_prev = publishes(prev) && !cur_published;
+        TR_LDS_BARRIER();                                          // B1: this tile's staged rows complete; Dz / Os free
+        // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
+        float xa[4][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { const float* ap = Dx + (size_t)arow * ldx + 16 * ks + ak; xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12]; }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+        if (!last) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks += 2) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], wr[ks].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][0], wr[ks + 1].x, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], wr[ks].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][1], wr[ks + 1].y, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], wr[ks].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][2], wr[ks + 1].z, a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], wr[ks].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][3], wr[ks + 1].w, a1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * (lane >> 4) + i;
+            const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
+            const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
+            Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
+            Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
+        }
+        if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
+        TR_LDS_BARRIER();                                          // B2
+        const SqRaw raw3 = sq_fetch(q, sq_rfl(ctl[(it + 3) & 3]));
+        const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;
+        unsigned fv0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fv1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+        asm volatile("" ::: "memory");
+        // ---- d[x_cur | x_past | aux] = dZ . W1
+        float za[8][4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { const float* zp = Dz + (size_t)arow * ldz + 16 * ks + ak; za[ks][0] = zp[0]; za[ks][1] = zp[4]; za[ks][2] = zp[8]; za[ks][3] = zp[12]; }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][0], w1[j][ks].x, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][1], w1[j][ks].y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][2], w1[j][ks].z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][3], w1[j][ks].w, acc[j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // publish point: the previous tile's outputs (rows and atomics) left a whole tile ago; younger than them in this wave's queue are the
+        // rows and taps requested for this tile (consumed long ago), the ticket in wave 0, the table entry and the two flag words: counted wait
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nt = wave + 4 * j;
+            if (nt >= NTK) continue;                               // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Os[(size_t)(4 * (lane >> 4) + i) * ldo + 16 * nt + (lane & 15)] = acc[j][i];
+        }
+        asm volatile("" : "+v"(fv0), "+v"(fv1));                   // the flag words are looked at HERE
+        bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+        asm volatile("" ::: "memory");
+        {   // dZ rows to global (512 B each; read by the weight-gradient kernels behind this launch)
+            float* DZg = bw.DZ + (size_t)cur.xrow * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = zrow + 4 * k;
+                float* d = DZg + (__umul24((unsigned)(cur.n0 + r), 2u * C) + zc2);
+                d = cur.n0 + r < N1 ? d : dmy + zc2;
+                *(float2*)d = *(const float2*)(Dz + (size_t)r * ldz + zc2);
+            }
+        }
+        if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
+        TR_LDS_BARRIER();                                          // B3
+        int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
+        cur_published = false;
+        if (any_slow) {
+            if (tid == 0) atomicAdd(q.stats + 2, 1u);
+            if (!ready) {
+                const unsigned g0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), g1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+                ready = fn <= 128 && __all(g0 == q.epoch && g1 == q.epoch);
+            }
+            if (lane == 0) ctl[12 + wave] = ready ? 0 : 1;
+            TR_LDS_BARRIER();
+            any_slow = sq_rfl(ctl[12] | ctl[13] | ctl[14] | ctl[15]);
+        }
+        if (any_slow) {
+            if (tid == 0) atomicAdd(q.stats, 1u);
+            outputs(cur, Dx);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR_LDS_BARRIER();
+            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch);
+            cur_published = true;
+            if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
+        }
+        load_rows(next);
+        if (!any_slow) outputs(cur, Dx);
+        int tpn2[4]; load_taps(nn, tpn2);
+        store_rows(next, sm + ((it + 1) & 1) * 4 * 16 * ldx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { tprow[i] = tpnext[i]; tpnext[i] = tpn2[i]; }
+        prev = cur; cur = next; next = nn; nn = sq_take(raw3);
+        if (!sq_valid(cur)) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_LDS_BARRIER();
+    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool qpn_stack_fwd_fits(const TrainParams& p) {
     if (getenv("QPN_STACK_QUEUE") && atoi(getenv("QPN_STACK_QUEUE")) == 0) return false;
@@ -368,5 +624,26 @@ int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stre
     QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);      // every sub-queue needs a puller (a workgroup's home: (blockIdx / 8) % nq)
     hipLaunchKernelGGL((k_stack_fwd<11>), dim3(G), dim3(256), lds, stream, p, qq);
+    return QPN_OK;
+}
+
+bool qpn_stack_bwd_fits(const TrainParams& p) {
+    if (getenv("QPN_STACK_QUEUE_BWD") && atoi(getenv("QPN_STACK_QUEUE_BWD")) == 0) return false;
+    return qpn_stack_fwd_fits(p) && p.Ap <= 64 && (int64_t)p.B * p.BL * p.LC < (1ll << 31) && (int64_t)p.N1 * (p.LC > 2 * p.C ? p.LC : 2 * p.C) < (1ll << 32);
+}
+
+int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, hipStream_t stream) {
+    constexpr int ldx = ((64 + 29) / 32) * 32 + 2, ldz = ((128 + 29) / 32) * 32 + 2, ldo = ((176 + 29) / 32) * 32 + 2;
+    const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 64;
+    // 1.5 workgroups per CU: the skip / post-net weight gradients run on the side stream while this launch is resident (qpn_launch_bwd), and a
+    // launch that fills every CU twice over leaves them no room -- measured on the overlapped step: 0.846 ms with 2 per CU, 0.776 with 1.5,
+    // 0.778 with 1, 0.790 for the eight per-layer launches
+    int G = qpn_num_cus() * 3 / 2;
+    if (const char* e = getenv("QPN_STACK_WGS_BWD")) { const int v = atoi(e); if (v >= 1 && v <= 4096) G = v; }
+    if (G > q.total) G = q.total;
+    if (G > 1024) G = 1024;
+    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_bwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);
+    hipLaunchKernelGGL((k_stack_bwd<11>), dim3(G), dim3(256), lds, stream, p, bw, qq);
     return QPN_OK;
 }

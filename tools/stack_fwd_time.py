@@ -9,7 +9,7 @@ import util
 cuda = torch.device("cuda:0")
 m = util.build_model(PAPER, synth.make_weights(PAPER, 13), cuda).train()
 tr = FusedTrainer(m, lr=1e-4)
-hb = synth.train_inputs(PAPER, 20000, 5000, 30000, f0_lo=55.0, f0_hi=300.0)
+hb = synth.train_inputs(PAPER, 20000, 5000, 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True)
 bt = [torch.from_numpy(np.ascontiguousarray(a)).to(cuda) for a in hb[:4]]
 maxd = int(np.ceil(hb[3]).max())
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
