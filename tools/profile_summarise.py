@@ -13,7 +13,7 @@ def find(pattern):
     return f[0] if f else None
 
 
-for what in ("train", "decode", "default", "default_dec"):
+for what in ("train", "train2", "decode", "default", "default_dec"):
     f = find("%s_stats/**/*kernel_stats.csv" % what)
     if f:
         rows = list(csv.reader(open(f)))
@@ -85,7 +85,21 @@ wg = [(k, v) for k, v in per.get("train", {}).items() if "k_wgrad" in k]
 if wg:
     steps = 3.0    # 1 warmup + 2 timed steps in the PMC runs (the profiled extra steps of bench.py are included: see calls)
     calls = max(v["calls"] for _, v in wg)
-    traffic["train"] = {"kernel": "k_wgrad3/k_wgrad2 (5 launches per step)", "workload": "paper-size step, chunk 20680 samples",
-                        "hbm_bytes_per_step": sum(v["hbm_bytes"] / max(v["calls"], 1) * (2 if "1, 4, 4" in k else 1) for k, v in wg)}
+    nsteps = max(per["train"].get("k_train_prep", {}).get("calls", 0), 1)          # steps of the profiled command (timed + warm-up + bench.py's per-group steps)
+    GROUP = (("k_train_prep", "prep+pack"), ("k_refresh", "prep+pack"), ("k_stack_fwd", "k_layer_fwd"), ("k_layer_fwd", "k_layer_fwd"), ("k_post_fwd", "k_post_fwd"),
+             ("k_ce", "k_ce"), ("k_post_bwd", "k_post_bwd"), ("k_wgrad", "k_wgrad"), ("k_stack_bwd", "k_layer_bwd"), ("k_layer_bwd", "k_layer_bwd"),
+             ("k_reduce_grad", "grad_tail"), ("k_up_bwd", "grad_tail"), ("k_causal_bwd", "grad_tail"), ("k_zero_dx", "k_post_bwd"), ("k_adam", "k_adam"))
+    by_group = defaultdict(float)
+    for k, v in per["train"].items():
+        for key, grp in GROUP:
+            if key in k:
+                by_group[grp] += v["hbm_bytes"] / nsteps
+                break
+    traffic["train"] = {"kernel": "k_wgrad3 (5 launches per step)", "workload": "paper-size step, chunk 20900 samples (RF 946 + 19954), QPN_TRAIN_SERIAL=1",
+                        "steps_profiled": nsteps,
+                        "hbm_bytes_per_step": by_group.get("k_wgrad", 0.0),
+                        "hbm_bytes_by_group": {k: round(v) for k, v in by_group.items()},
+                        "hbm_bytes_per_step_all_kernels": round(sum(v["hbm_bytes"] for k, v in per["train"].items() if k.startswith(("k_", "void k_"))) / nsteps)}
+traffic["commit"] = os.environ.get("QPN_COMMIT", "?")
 json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
