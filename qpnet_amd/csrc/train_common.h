@@ -100,6 +100,8 @@ struct StackQ {
     unsigned* abort;          // raised when a wait timed out: every workgroup stops waiting and drains
     const int4* tab;          // tile table [total + 1][2] (entry total: the invalid tile)
     unsigned epoch;           // never 0; a new one per forward
+    unsigned epoch_pub;       // what a published flag carries: the epoch (a test hook makes it differ, so that every wait runs out)
+    unsigned spin_limit;      // polls before a wait gives up
     int total, nq;            // positions; sub-queues in use
 };
 

@@ -39,6 +39,7 @@ struct TrainState {
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
     TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
     int64_t bwd_generation;                                  // generation of the forward the last backward belonged to
+    bool stack_disabled;                                     // a stack-queue launch gave up once (status bit 4): this handle keeps to a launch per layer
     unsigned* d_sq; size_t sq_pos_cap, sq_per_dir;                           // stack work queues (train_stack.hip): [16 control words | forward flags | backward flags]
     StackQ sqf, sqb;
 };
@@ -152,7 +153,7 @@ static int train_init(qpn_handle* h) {
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
     memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
-    t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; t->bwd_generation = -1; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
+    t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; t->bwd_generation = -1; t->stack_disabled = false; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -452,9 +453,9 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
             QPN_HIP(hipMemsetAsync(t->d_sq, 0, nsq * sizeof(unsigned), stream));
             t->sq_pos_cap = cap; t->sq_per_dir = per_dir;
         }
-        p.qctl = t->d_sq;
-        p.qtab = (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
-        p.qtab_b = p.qtab + 2 * (t->sq_pos_cap + 1);
+        p.qctl = t->stack_disabled ? nullptr : t->d_sq;          // (nullptr: no queue launches, no tables)
+        p.qtab = t->stack_disabled ? nullptr : (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
+        p.qtab_b = t->stack_disabled ? nullptr : p.qtab + 2 * (t->sq_pos_cap + 1);
         const unsigned epoch = (unsigned)((t->generation + 1) % 0xFFFFFFFFll) + 1u;      // (generation is bumped below; never 0)
         StackQ& f = t->sqf; StackQ& bq = t->sqb;
         f.flags = t->d_sq + TR_QHDR_WORDS; f.head = t->d_sq + 1024; f.abort = t->d_sq + 1; f.stats = t->d_sq + 4; f.epoch = epoch; f.total = p.qtotal; f.tab = p.qtab;
@@ -522,13 +523,14 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) QPN_HIP(hipMemset(h->train->d_status, 0, sizeof(int)));          // sticky until read: reported once
+    if (st & 4) h->train->stack_disabled = true;
     h->train->status_pending[0] = h->train->status_pending[1] = false;
     return status_to_rc(st);
 }
 
 static int status_to_rc(int st) {
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
-    if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup (QPN_STACK_QUEUE=0 selects a launch per layer)"); return QPN_ENODEV; }
+    if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup: this step's results are invalid; the handle runs a launch per layer from here on (QPN_STACK_QUEUE=0 selects that from the start)"); return QPN_ENODEV; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;
 }
@@ -542,6 +544,7 @@ static int status_collect_slot(TrainState* t, int slot) {
     QPN_HIP(hipEventSynchronize(t->ev_status[slot]));
     t->status_pending[slot] = false;
     const int st = t->h_status_pinned[slot];
+    if (st & 4) t->stack_disabled = true;
     if (st) {
         QPN_HIP(hipMemset(t->d_status, 0, sizeof(int)));              // sticky until read: reported once ...
         const int other = slot ^ 1;                                   // ... also where the other slot copied the same sticky bits before this clear

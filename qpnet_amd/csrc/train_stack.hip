@@ -25,7 +25,7 @@
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define SQ_SC1 16                                   // aux bits of the raw buffer builtins: sc1 (agent-scope / write-through)
 #define SQ_OOB 0x80000000u                          // a buffer offset beyond every descriptor's range: the access is dropped
-#define SQ_SPIN_LIMIT (1u << 22)
+#define SQ_SPIN_LIMIT (1u << 22)                    // polls of ~1-2 us: several seconds
 #define SQ_FLINE 1056u                              // words between the 128-byte lines of the flag array
 #define SQ_NQ 8                                     // sub-queues (head words 128 bytes apart)
 
@@ -86,7 +86,7 @@ __device__ __forceinline__ int sq_wait(const StackQ& q, int first, int n, int la
             if ((spins & 63u) == 63u && sq_ld(q.abort)) { rc = 0; break; }      // (one word for the whole chip: looked at rarely)
             ++spins;
             if (bound && spins >= bound) { rc = 2; break; }
-            if (spins > SQ_SPIN_LIMIT) { if (lane == 0) { sq_st(q.abort, 1u); atomicOr(status, 4); } rc = 0; break; }
+            if (spins > q.spin_limit) { if (lane == 0) { sq_st(q.abort, 1u); atomicOr(status, 4); } rc = 0; break; }
             if (spins > 2) __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         if (lane == 0) {
             const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
         }
         __builtin_amdgcn_sched_barrier(0);
         SQ_STAMP(3);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
             store_x(cur, publishes(cur));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TR_LDS_BARRIER();
-            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch);
+            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch_pub);
             cur_published = true;
             if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
         }
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
     // the last tile's output has left; publish it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TR_LDS_BARRIER();
-    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (lane == 0) {
             const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             outputs(cur, Dx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TR_LDS_BARRIER();
-            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch);
+            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch_pub);
             cur_published = true;
             if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
         }
@@ -593,10 +593,16 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TR_LDS_BARRIER();
-    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch);
+    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// tests/test_train_gpu.py::test_stack_queue_that_gives_up_...: QPN_TEST_STACK_GIVES_UP=1 makes the published flags carry another value than the
+// consumers expect and shortens the waits, so the first dependent tile runs out, raises the abort word and the launch drains
+static void sq_test_hook(StackQ& q) {
+    q.epoch_pub = q.epoch; q.spin_limit = SQ_SPIN_LIMIT;
+    if (const char* e = getenv("QPN_TEST_STACK_GIVES_UP")) if (atoi(e) == 1) { q.epoch_pub = q.epoch ^ 0x55555555u; q.spin_limit = 2000u; }
+}
 bool qpn_stack_fwd_fits(const TrainParams& p) {
     if (getenv("QPN_STACK_QUEUE") && atoi(getenv("QPN_STACK_QUEUE")) == 0) return false;
     return p.C == 64 && p.Ktp == 176 && p.L >= 1 && p.L <= TR_MAXL && p.B < 65536 && (int64_t)p.N1 * p.C * 4 <= (1ll << 30) &&
@@ -623,6 +629,7 @@ int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stre
     if (G > 1024) G = 1024;                                      // (scratch rows: one pair per workgroup)
     QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);      // every sub-queue needs a puller (a workgroup's home: (blockIdx / 8) % nq)
+    sq_test_hook(qq);
     hipLaunchKernelGGL((k_stack_fwd<11>), dim3(G), dim3(256), lds, stream, p, qq);
     return QPN_OK;
 }
@@ -644,6 +651,7 @@ int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ&
     if (G > 1024) G = 1024;
     QPN_HIP(hipFuncSetAttribute((const void*)k_stack_bwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);
+    sq_test_hook(qq);
     hipLaunchKernelGGL((k_stack_bwd<11>), dim3(G), dim3(256), lds, stream, p, bw, qq);
     return QPN_OK;
 }

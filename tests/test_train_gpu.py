@@ -733,3 +733,27 @@ def test_stack_queue_equals_per_layer_launches(cuda, monkeypatch):
                 _lib.check(_lib.lib().qpn_train_stack_stats(m._handle, st, 16, None))
                 assert st[1] == 0                                  # the abort word
         assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+def test_stack_queue_that_gives_up_is_reported_and_replaced(cuda, monkeypatch):
+    """Every wait of the one-launch residual stack is bounded.  With the published flags made unrecognisable (QPN_TEST_STACK_GIVES_UP=1: the
+    situation of a peer workgroup that never runs) the first dependent tile's wait runs out, the launch drains, the step is REPORTED as invalid
+    (status bit 4 -> QPN_ENODEV) -- and the handle runs a launch per layer from then on: the next forward is correct."""
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    x, h, t, d, b = synth.train_inputs(cfg, 1500, 91, 30000)
+    xt, ht, dt, bt = _to(cuda, x, h, d, b)
+    ref = util.build_model(cfg, flat, cuda)
+    with torch.no_grad():
+        good = ref(xt, ht, dt, bt).cpu().numpy()
+    m = util.build_model(cfg, flat, cuda)
+    monkeypatch.setenv("QPN_TEST_STACK_GIVES_UP", "1")
+    with torch.no_grad():
+        with pytest.raises(_lib.QpnError) as e:
+            m(xt, ht, dt, bt)
+        assert e.value.code == -2 and "residual stack" in str(e.value)
+        again = m(xt, ht, dt, bt).cpu().numpy()               # the hook is still set: this forward no longer uses the queue
+    assert np.array_equal(again.view(np.uint32), good.view(np.uint32))
