@@ -173,13 +173,13 @@ def run_decode(args, rank, local, world):
     us = k_ms * 1e3 / max(ns)                      # device time per generated sample of one utterance (rows run concurrently)
     pipelined = B <= 48 and os.environ.get("QPN_DECODE_PIPE", "1") != "0"
     if pipelined:
-        # five CUs per utterance, weights resident: per sample 4 hand-offs (0.44 us each inside an XCD) + 22 dependent stages
-        # (LDS write -> barrier -> LDS read -> 16-FMA chain, 0.205 us each): profiles/r02_hop_microbench.txt
-        floor, kernel, cus = 4 * 0.44 + 22 * 0.205, "k_decode_pipe", 5 * B
+        # five CUs per utterance, weights resident: per sample 4 hand-offs (0.421 us each inside an XCD) + 22 dependent stages
+        # (LDS write -> barrier -> LDS read -> 16-FMA chain, 0.213 us each): profiles/r04_hop_microbench.txt (re-measured in round 4)
+        floor, kernel, cus = 4 * 0.421 + 22 * 0.213, "k_decode_pipe", 5 * B
         bound = "latency (4 cross-CU hand-offs + 22 dependent matvec stages per sample)"
         note = ("five persistent workgroups (five CUs) per utterance -- fixed stack, adaptive stack, fixed-stack skip, skip + post-1, post-2 + pick -- "
                 "every critical-path weight tile resident in VGPRs / LDS, hand-offs by 8-byte {tag, value} granules; floor = the "
-                "microbenchmarked cost of the hand-offs and dependent stages of one sample (profiles/r02_hop_microbench.txt); "
+                "microbenchmarked cost of the hand-offs and dependent stages of one sample (profiles/r04_hop_microbench.txt); "
                 "HBM sees only the per-sample inputs/outputs (172 B algorithmic)")
     else:
         floor, kernel, cus = 11.65, "k_decode_fast" if cfg.n_resch <= 64 else "k_decode", B       # profiles/r01_l2_stream_floor.txt
