@@ -23,7 +23,14 @@
 #include "train_common.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define SQ_SC1 16                                   // aux bits of the raw buffer builtins: sc1 (agent-scope / write-through)
+#ifndef SQ_EXP
+#define SQ_EXP 0
+#endif
+#if SQ_EXP & 2
+#define SQ_SC1 0
+#else
+#define SQ_SC1 16
+#endif                                   // aux bits of the raw buffer builtins: sc1 (agent-scope / write-through)
 #define SQ_OOB 0x80000000u                          // a buffer offset beyond every descriptor's range: the access is dropped
 #define SQ_SPIN_LIMIT (1u << 22)                    // polls of ~1-2 us: several seconds
 #define SQ_FLINE 1056u                              // words between the 128-byte lines of the flag array
@@ -43,11 +50,26 @@ __device__ __forceinline__ float sq_tanh(float z) { return 2.0f * __builtin_amdg
 #else
 #define SQ_STAMP(i) do { } while (0)
 #endif
+#ifdef QPN_STACK_STAMPS_BWD                         // the same for the backward queue (its counters start 4 words later: same control words)
+#define SQ_STAMPB(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 5 && tid == 0 && it < 25) q.stats[592 + 8 * it + (i)] = (unsigned)t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SQ_STAMPB(i) do { } while (0)
+#endif
 
 // Flag words: 32 consecutive positions share a 128-byte line (a consumer's producer range is 2-3 lines), consecutive LINES lie 4224 bytes
 // apart: the ~1000 flags the frontier of the queue polls and publishes at any moment would otherwise sit in ONE 4 KB stretch of memory,
 // i.e. behind one memory channel (measured: waits of 20-180 us on flags published long before).
 __host__ __device__ __forceinline__ static unsigned sq_fidx(unsigned pos) { return (pos >> 5) * SQ_FLINE + (pos & 31u); }
+
+// Wave priority: two workgroups share a CU, so every SIMD holds one wave of each; while one of them issues its MFMA block back to back the other
+// one's address arithmetic, LDS and memory instructions have to get between them -- the wave in an MFMA block runs at the lowest priority, everything
+// else above it
+#ifdef SQ_NOPRIO
+#define SQ_PRIO(x) do { } while (0)
+#else
+#define SQ_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 
 struct SqTile { int n0, meta, dfirst, dn, xrow, tapb, hrow, dgs, pos; };       // wave-uniform (SGPRs); meta: layer | batch item << 8 | last << 24 | valid << 25
 __device__ __forceinline__ bool sq_valid(const SqTile& d) { return (d.meta >> 25) & 1; }
@@ -86,7 +108,11 @@ __device__ __forceinline__ int sq_wait(const StackQ& q, int first, int n, int la
             if ((spins & 63u) == 63u && sq_ld(q.abort)) { rc = 0; break; }      // (one word for the whole chip: looked at rarely)
             ++spins;
             if (bound && spins >= bound) { rc = 2; break; }
-            if (spins > q.spin_limit) { if (lane == 0) { sq_st(q.abort, 1u); atomicOr(status, 4); } rc = 0; break; }
+            if (spins > q.spin_limit) {
+#ifdef QPN_STACK_DEBUG
+                if (sq_ld(q.abort) == 0u) { const unsigned long long miss = __ballot(v != q.epoch); if (lane == 0) { q.stats[24] = (unsigned)first; q.stats[25] = (unsigned)n; q.stats[26] = (unsigned)base; q.stats[27] = (unsigned)miss; q.stats[28] = (unsigned)(miss >> 32); q.stats[29] = blockIdx.x; q.stats[30] = q.epoch; } if (lane == (int)__ffsll(miss) - 1) q.stats[31] = v; }
+#endif
+                if (lane == 0) { sq_st(q.abort, 1u); atomicOr(status, 4); } rc = 0; break; }
             if (spins > 2) __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -232,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
             xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12];
         }
         __builtin_amdgcn_sched_barrier(0);
+        SQ_PRIO(0);
         f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -240,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][0].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][1].z, a1, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][0].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][1].w, a1, 0, 0, 0);
         }
+        SQ_PRIO(2);
         __builtin_amdgcn_sched_barrier(0);
         SQ_STAMP(2);
         // publish point: younger than the previous tile's row stores are only this trip's tap load and, in wave 0, the ticket
@@ -274,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
                 ga[ks][0] = gp[0]; ga[ks][1] = gp[4]; ga[ks][2] = gp[8]; ga[ks][3] = gp[12];
             }
             __builtin_amdgcn_sched_barrier(0);
+            SQ_PRIO(0);
             f32x4 ar0 = (f32x4){0, 0, 0, 0}, ar1 = (f32x4){0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 4; ks += 2) {
@@ -282,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
                 ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][2], wr[ks].z, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][2], wr[ks + 1].z, ar1, 0, 0, 0);
                 ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
             }
+            SQ_PRIO(2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * (lane >> 4) + i;
@@ -654,36 +684,49 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) w1[j][ks] = W1t[((size_t)ks * NTK + nt) * 64 + lane];
         }
+        // waited for HERE, on the layer change's own path: left to the first MFMA that reads them, the wait lands on every tile's path (hipcc merges
+        // the two paths' pending counts), where it waits for the previous tile's outputs instead
+        static_assert(NJ == 3, "the operand list below names every float4 of wr / w1");
+        asm volatile("" :: "v"(wr[0].w), "v"(wr[1].w), "v"(wr[2].w), "v"(wr[3].w),
+                     "v"(w1[0][0].w), "v"(w1[0][1].w), "v"(w1[0][2].w), "v"(w1[0][3].w), "v"(w1[0][4].w), "v"(w1[0][5].w), "v"(w1[0][6].w), "v"(w1[0][7].w),
+                     "v"(w1[1][0].w), "v"(w1[1][1].w), "v"(w1[1][2].w), "v"(w1[1][3].w), "v"(w1[1][4].w), "v"(w1[1][5].w), "v"(w1[1][6].w), "v"(w1[1][7].w),
+                     "v"(w1[2][0].w), "v"(w1[2][1].w), "v"(w1[2][2].w), "v"(w1[2][3].w), "v"(w1[2][4].w), "v"(w1[2][5].w), "v"(w1[2][6].w), "v"(w1[2][7].w));
     };
     auto rsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
+    // the rows of a tile come from two places: what this layer's forward and the post-net's backward left (sigma, tanh, the skip-path gradient:
+    // nobody inside the launch writes them) and the gradient the layer above hands over (write-through rows and atomics of other workgroups)
     float4 ra, rb2, rsg, rth, rdg;
-    auto load_rows = [&](const SqTile& d) {
-        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
-        const unsigned o = __umul24((unsigned)nn, (unsigned)C) + 4u * sc4;
-        // grads w.r.t. this layer's output = the input gradient of the layer above (nothing for the last layer: dropped by the range check)
-        const unsigned ob = sq_last(d) ? SQ_OOB : o * 4u;
+    auto row_off = [&](const SqTile& d) { const int n = d.n0 + srow, nn_ = n < N1 ? n : N1 - 1; return __umul24((unsigned)nn_, (unsigned)C) + 4u * sc4; };
+    auto load_own = [&](const SqTile& d) {
+        const unsigned o = row_off(d);
+        const int n = d.n0 + srow, nn_ = n < N1 ? n : N1 - 1;
+        rsg = *(const float4*)(p.SG + (size_t)d.xrow * C + o); rth = *(const float4*)(p.TH + (size_t)d.xrow * C + o);
+        const int nw = nn_ >= win0 ? nn_ - win0 : 0;
+        rdg = *(const float4*)(bw.DGS + (size_t)d.dgs + (__umul24((unsigned)nw, (unsigned)p.LC) + 4u * sc4));
+    };
+    auto load_ab = [&](const SqTile& d, float4& a4, float4& b4_) {      // (nothing for the last layer: dropped by the range check)
+        const unsigned ob = sq_last(d) ? SQ_OOB : row_off(d) * 4u;
         const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc(bw.DXA[0] + (size_t)d.xrow * C + nDX), (int)ob, 0, SQ_SC1);
         const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc(bw.DXB[0] + (size_t)d.xrow * C + nDX), (int)ob, 0, SQ_SC1);
-        ra = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-        rb2 = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
-        rsg = *(const float4*)(p.SG + (size_t)d.xrow * C + o); rth = *(const float4*)(p.TH + (size_t)d.xrow * C + o);
-        const int nw = nn >= win0 ? nn - win0 : 0;
-        rdg = *(const float4*)(bw.DGS + (size_t)d.dgs + (__umul24((unsigned)nw, (unsigned)p.LC) + 4u * sc4));
-        __builtin_amdgcn_sched_barrier(0);
+        a4 = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        b4_ = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
     };
-    auto store_rows = [&](const SqTile& d, float* B) {
+    auto store_own = [&](const SqTile& d, float* B) {
         const int n = d.n0 + srow;
         const bool in = n < N1;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 dx = (in && !sq_last(d)) ? make_float4(ra.x + rb2.x, ra.y + rb2.y, ra.z + rb2.z, ra.w + rb2.w) : z;
         const float4 sg = in ? rsg : z, th = in ? rth : z, dg = (in && n >= win0) ? rdg : z;
-        float* d0 = B + (size_t)srow * ldx + 4 * sc4;
-        *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
-        float* d1 = d0 + 16 * ldx; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
+        float* d1 = B + (size_t)(16 + srow) * ldx + 4 * sc4; *(float2*)d1 = make_float2(sg.x, sg.y); *(float2*)(d1 + 2) = make_float2(sg.z, sg.w);
         float* d2 = d1 + 16 * ldx; *(float2*)d2 = make_float2(th.x, th.y); *(float2*)(d2 + 2) = make_float2(th.z, th.w);
         float* d3 = d2 + 16 * ldx; *(float2*)d3 = make_float2(dg.x, dg.y); *(float2*)(d3 + 2) = make_float2(dg.z, dg.w);
     };
-    int tprow[4], tpnext[4];
+    auto store_dx = [&](const SqTile& d, float* B, const float4& a4, const float4& b4_) {
+        const int n = d.n0 + srow;
+        const float4 dx = (n < N1 && !sq_last(d)) ? make_float4(a4.x + b4_.x, a4.y + b4_.y, a4.z + b4_.z, a4.w + b4_.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d0 = B + (size_t)srow * ldx + 4 * sc4;
+        *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
+    };
+    int tprow[4];
     auto load_taps = [&](const SqTile& d, int (&tp)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int n = d.n0 + 4 * wave + i; tp[i] = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1]; }
@@ -692,6 +735,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
     auto outputs = [&](const SqTile& d, const float* Dx) {
         const bool adaptive = (d.meta >> 26) & 1;
         const int dil = p.layers[sq_layer(d)].dilation;
+#if !(SQ_EXP & 16)
         {   // own-row part (+ residual path): 16 bytes per thread, write-through
             const int n = d.n0 + srow;
             const float2 o0 = *(const float2*)(Os + (size_t)srow * ldo + 4 * sc4), o1 = *(const float2*)(Os + (size_t)srow * ldo + 4 * sc4 + 2);
@@ -707,12 +751,14 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
                 __builtin_amdgcn_raw_buffer_store_b128(w, rsrc(bw.DXB[0] + (size_t)d.xrow * C), (int)offb, 0, SQ_SC1);
             }
         }
+#endif
         float* DBout = bw.DXB[0] + (size_t)d.xrow * C;
         float* DH = bw.DHUP + (size_t)d.hrow * Ap;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // wave w owns rows 4w .. 4w+3, lane = channel: one 256-byte row per instruction
             const int r = 4 * wave + i, n = d.n0 + r;
             const bool in = n < N1;
+#if !(SQ_EXP & 1)
             if (adaptive) {                // gather backward (collisions): ONE full-row float-atomic instruction per tap row
                 float* db = DBout + (__umul24((unsigned)tprow[i], (unsigned)C) + lane);
                 atomicAdd(in ? db : dmy + 128 + lane, Os[(size_t)r * ldo + C + lane]);
@@ -721,6 +767,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
                 float* dh = DH + (__umul24((unsigned)n, (unsigned)Ap) + lane);
                 atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);
             }
+#endif
         }
     };
     auto publishes = [&](const SqTile& d) { return sq_valid(d) && sq_layer(d) > 0; };     // (layer 0's input gradient feeds later kernels only)
@@ -734,33 +781,47 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         asm volatile("" ::: "memory");
         const unsigned k1 = atomicAdd(head, 1u); ctl[1] = (int)(k1 * NQ + sub);
         asm volatile("" ::: "memory");
-        const unsigned k2 = atomicAdd(head, 1u); ctl[2] = (int)(k2 * NQ + sub);
+        const unsigned k2 = atomicAdd(head, 1u); ctl[16] = (int)(k2 * NQ + sub);
     }
     __syncthreads();
-    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1]))), nn = sq_take(sq_fetch(q, sq_rfl(ctl[2])));
+    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1])));
     if (!sq_valid(cur)) return;
     SqTile prev = cur; prev.meta = 0;
     int lw = sq_layer(cur);
     load_weights(lw, sq_last(cur));
     sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
-    load_rows(cur);
+    load_own(cur); load_ab(cur, ra, rb2);
     load_taps(cur, tprow);
-    store_rows(cur, sm);
-    load_taps(next, tpnext);
+    store_own(cur, sm); store_dx(cur, sm, ra, rb2);
     bool cur_published = false;
+    // the flag words live in a buffer descriptor too: the publishing store is ONE unconditional instruction (every lane but one aims beyond the range)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)q.flags, 0, (int)((sq_fidx((unsigned)q.total) + 64u) * 4u), 0x00020000);
+    // Per tile: three barriers, ONE wait for everything that can be asked early, one counted wait for the two rows that cannot.
+    //   B1  the tile's staged rows are complete;  dg = dXout . Wr + skip-path gradient, dz = dg * gate'  -> Dz
+    //   B2  the request group: the NEXT tile's own-layer rows and taps, its producers' flags, the table entry of the position two tiles ahead
+    //       (its ticket was taken up at the previous tile's wait), the ticket of the one three ahead;  then d[x_cur | x_past | aux] = dZ . W1
+    //       -- 96 MFMAs, ~3.7k cycles, which is what the group needs to come back --
+    //       the wait (vmcnt 0): rows / taps / table entry / ticket are taken up; the next tile's handed-over rows are requested if its flags
+    //       are all there; the previous tile is published (its outputs left in front of the group, a whole tile ago)
+    //       own-layer rows and this tile's products -> LDS, dZ rows -> memory
+    //   B3  every wave knows whether all four found the flags.  Yes: the handed-over rows (counted wait: only the publishing store and the dZ
+    //       stores are younger) -> LDS, then the tile's outputs leave -- nobody looks at them before the next tile's wait.  No: outputs, drain,
+    //       the tile is PUBLISHED, and only then do the waves wait and fetch those rows.
+    // [vmcnt counts in order: a request consumed anywhere else costs a memory latency whatever its own age -- with the rows requested behind B3
+    //  and the ticket at the top of the tile a tile took 15.7k cycles (3.7k of them MFMA issue), 10k with every global access removed.]
     for (int it = 0;; ++it) {
         float* Dx = sm + (it & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
+        float* Bn = sm + ((it + 1) & 1) * 4 * 16 * ldx;           // the next tile's staging buffer (last read by the previous tile's outputs, in front of B1)
         const bool last = sq_last(cur);
-        unsigned rtk = 0;
-        if (tid == 0) rtk = atomicAdd(head, 1u);
         if (sq_layer(cur) != lw) { lw = sq_layer(cur); load_weights(lw, last); }
         const bool pub_prev = publishes(prev) && !cur_published;
-        TR_LDS_BARRIER();                                          // B1: this tile's staged rows complete; Dz / Os free
-        // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
+        SQ_STAMPB(0);
+        TR_LDS_BARRIER();                                          // B1
         float xa[4][4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { const float* ap = Dx + (size_t)arow * ldx + 16 * ks + ak; xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12]; }
         __builtin_amdgcn_sched_barrier(0);
+        SQ_PRIO(0);
         f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
         if (!last) {
 #pragma unroll
@@ -771,6 +832,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
                 a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], wr[ks].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][3], wr[ks + 1].w, a1, 0, 0, 0);
             }
         }
+        SQ_PRIO(2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * (lane >> 4) + i;
@@ -779,39 +841,64 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
             Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
         }
-        if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
+        SQ_STAMPB(1);
         TR_LDS_BARRIER();                                          // B2
-        const SqRaw raw3 = sq_fetch(q, sq_rfl(ctl[(it + 3) & 3]));
+        // ---- the request group
+        const SqRaw raw2 = sq_fetch(q, sq_rfl(ctl[16 + (it & 1)]));
         const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;
         unsigned fv0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fv1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+        load_own(next);
+        int tpn[4]; load_taps(next, tpn);
+        unsigned rtk = 0;
+        if (tid == 0) rtk = atomicAdd(head, 1u);
         asm volatile("" ::: "memory");
-        // ---- d[x_cur | x_past | aux] = dZ . W1
         float za[8][4];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) { const float* zp = Dz + (size_t)arow * ldz + 16 * ks + ak; za[ks][0] = zp[0]; za[ks][1] = zp[4]; za[ks][2] = zp[8]; za[ks][3] = zp[12]; }
         __builtin_amdgcn_sched_barrier(0);
+        SQ_PRIO(0);
         f32x4 acc[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][0], w1[j][ks].x, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][1], w1[j][ks].y, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][2], w1[j][ks].z, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][3], w1[j][ks].w, acc[j], 0, 0, 0);
+#define SQB_MFMA(ks) do { \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][0], w1[j][ks].x, acc[j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][1], w1[j][ks].y, acc[j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][2], w1[j][ks].z, acc[j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[ks][3], w1[j][ks].w, acc[j], 0, 0, 0); } while (0)
+        SQB_MFMA(0); SQB_MFMA(1); SQB_MFMA(2); SQB_MFMA(3);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the previous tile is published HALFWAY through the contraction: its outputs left ~3.7k cycles ago (the end of the previous tile, the gate
+        // phase, half of this one), and every quarter of a tile by which a flag is early is one by which its consumer's look is less likely to miss.
+        // Counted wait: the request group is younger than those outputs -- eleven requests (twelve in wave 0: the ticket); the count waited down to is
+        // two BELOW that, so a group hipcc manages to issue with fewer instructions still cannot let an output through
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        {
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool pub = pub_prev && (sq_rfl(old) & 3) == 3;      // the wave that gets here LAST
+            const unsigned foff = (pub && lane == 0) ? sq_fidx((unsigned)prev.pos) * 4u : SQ_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(q.epoch_pub, frs, (int)foff, 0, SQ_SC1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        // publish point: the previous tile's outputs (rows and atomics) left a whole tile ago; younger than them in this wave's queue are the
-        // rows and taps requested for this tile (consumed long ago), the ticket in wave 0, the table entry and the two flag words: counted wait
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (lane == 0) {
-            const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
-        }
+        SQB_MFMA(4); SQB_MFMA(5); SQB_MFMA(6); SQB_MFMA(7);
+#undef SQB_MFMA
+        SQ_PRIO(2);
+        __builtin_amdgcn_sched_barrier(0);
+        SQ_STAMPB(2);
+        // ---- the wait
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (hipcc does not see that wait: every register the group loaded is named here, or its own wait for the youngest of them -- the taps, the
+        //  ticket -- lands behind the publishing store and the outputs, in the middle of their way to memory)
+        asm volatile("" : "+v"(fv0), "+v"(fv1), "+v"(rtk), "+v"(tpn[0]), "+v"(tpn[1]), "+v"(tpn[2]), "+v"(tpn[3]));
+        SQ_STAMPB(3);
+        bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+#if SQ_EXP & 32
+        ready = true;
+#endif
+        load_ab(next, ra, rb2);                                    // (not final if the flags are not all there: fetched again on that path)
+        store_own(next, Bn);
+        const SqTile n2 = sq_take(raw2);
+        if (tid == 0) ctl[16 + ((it + 1) & 1)] = (int)(rtk * NQ + sub);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -820,9 +907,8 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
 #pragma unroll
             for (int i = 0; i < 4; ++i) Os[(size_t)(4 * (lane >> 4) + i) * ldo + 16 * nt + (lane & 15)] = acc[j][i];
         }
-        asm volatile("" : "+v"(fv0), "+v"(fv1));                   // the flag words are looked at HERE
-        bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
-        asm volatile("" ::: "memory");
+        SQ_STAMPB(4);
+#if !(SQ_EXP & 4)
         {   // dZ rows to global (512 B each; read by the weight-gradient kernels behind this launch)
             float* DZg = bw.DZ + (size_t)cur.xrow * 2 * C;
 #pragma unroll
@@ -833,11 +919,15 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
                 *(float2*)d = *(const float2*)(Dz + (size_t)r * ldz + zc2);
             }
         }
+#endif
         if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
+        SQ_STAMPB(5);
         TR_LDS_BARRIER();                                          // B3
+        SQ_STAMPB(6);
         int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
+        const int any_late = any_slow;                             // some wave's early request for the handed-over rows went out in front of a missing flag
         cur_published = false;
-        if (any_slow) {
+        if (any_slow) {                                            // a second look (one memory latency) before the tile gives its outputs up early
             if (tid == 0) atomicAdd(q.stats + 2, 1u);
             if (!ready) {
                 const unsigned g0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), g1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
@@ -847,7 +937,10 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             TR_LDS_BARRIER();
             any_slow = sq_rfl(ctl[12] | ctl[13] | ctl[14] | ctl[15]);
         }
-        if (any_slow) {
+        // the handed-over rows are waited for HERE, in front of the branch (counted: only the dZ stores are younger): hipcc's
+        // control flow has a path around both arms, and a row register it believes pending is waited for at the top of the next tile -- behind the outputs
+        asm volatile("" : "+v"(ra.w), "+v"(rb2.w));
+        if (any_slow) {      // a producer of the next tile is still at work: this tile is published BEFORE anybody waits (a wait is only ever for positions below everything the workgroup holds back)
             if (tid == 0) atomicAdd(q.stats, 1u);
             outputs(cur, Dx);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -855,14 +948,20 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch_pub);
             cur_published = true;
             if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
+            float4 la, lb; load_ab(next, la, lb);
+            store_dx(next, Bn, la, lb);
+        } else if (any_late) {                                     // the second look found them: the rows once more (a memory latency), nothing else changes
+            float4 la, lb; load_ab(next, la, lb);
+            store_dx(next, Bn, la, lb);
+            outputs(cur, Dx);
+        } else {
+            store_dx(next, Bn, ra, rb2);
+            outputs(cur, Dx);
         }
-        load_rows(next);
-        if (!any_slow) outputs(cur, Dx);
-        int tpn2[4]; load_taps(nn, tpn2);
-        store_rows(next, sm + ((it + 1) & 1) * 4 * 16 * ldx);
+        SQ_STAMPB(7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { tprow[i] = tpnext[i]; tpnext[i] = tpn2[i]; }
-        prev = cur; cur = next; next = nn; nn = sq_take(raw3);
+        for (int i = 0; i < 4; ++i) tprow[i] = tpn[i];
+        prev = cur; cur = next; next = n2;
         if (!sq_valid(cur)) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -927,7 +1026,7 @@ bool qpn_stack_bwd_fits(const TrainParams& p) {
 
 int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, hipStream_t stream) {
     constexpr int ldx = ((64 + 29) / 32) * 32 + 2, ldz = ((128 + 29) / 32) * 32 + 2, ldo = ((176 + 29) / 32) * 32 + 2;
-    const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 64;
+    const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 128;
     // 1.5 workgroups per CU: the skip / post-net weight gradients run on the side stream while this launch is resident (qpn_launch_bwd), and a
     // launch that fills every CU twice over leaves them no room -- measured on the overlapped step: 0.846 ms with 2 per CU, 0.776 with 1.5,
     // 0.778 with 1, 0.790 for the eight per-layer launches

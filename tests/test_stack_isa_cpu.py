@@ -1,0 +1,36 @@
+"""The backward work-queue kernel publishes the previous tile in the MIDDLE of its 96-MFMA contraction behind a COUNTED wait (csrc/train_stack.hip,
+k_stack_bwd: `s_waitcnt vmcnt(9)`, 10 in wave 0): everything older than the tile's request group -- i.e. the previous tile's outputs -- must have
+completed, the group itself stays in flight.  That count is only right while hipcc issues the group as at least that many instructions (it is
+written as eleven requests, twelve in wave 0).  This test compiles the file to gfx950 assembly and counts them."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_request_group_of_the_backward_queue_is_at_least_as_long_as_the_counted_wait(tmp_path):
+    out = tmp_path / "stack.s"
+    src = os.path.join(ROOT, "qpnet_amd", "csrc", "train_stack.hip")
+    subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function", "-S", "--cuda-device-only",
+                    "-I" + os.path.dirname(src), src, "-o", str(out)], check=True, capture_output=True, timeout=600)
+    text = out.read_text().split("\n")
+    start = next(i for i, l in enumerate(text) if re.match(r"^_Z11k_stack_bwd\w*:", l))
+    end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+    body = text[start:end]
+    counted = [i for i, l in enumerate(body) if re.search(r"s_waitcnt vmcnt\((9|10)\)\s*$", l)]
+    assert len(counted) == 2, "the two counted waits (waves 1-3 / wave 0) of the publish point"
+    first = counted[0]
+    barrier = max(i for i in range(first) if "s_barrier" in body[i])                       # B2
+    vmem = [l for l in body[barrier:first] if re.search(r"^\s*(global|buffer)_(load|store|atomic)", l)]
+    loads = [l for l in vmem if "_load_" in l]
+    atomics = [l for l in vmem if "_atomic_" in l]
+    assert not [l for l in vmem if "_store_" in l], "nothing may be stored between B2 and the publish point"
+    assert len(loads) >= 9, "requests of the group: %d" % len(loads)                        # waves 1-3 wait down to 9
+    assert len(loads) + len(atomics) >= 10 and len(atomics) == 1                            # wave 0 (its ticket) waits down to 10
+    mfma_before = sum("v_mfma" in l for l in body[barrier:first])
+    assert 40 <= mfma_before <= 56, "the publish point sits halfway through the 96-MFMA contraction (%d in front of it)" % mfma_before
