@@ -204,6 +204,12 @@ int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d
  * the work queues as the last step left them -- [1] abort raised; forward [4..6] / backward [8..10]: escalations (a workgroup published
  * everything it held before waiting without a bound), polls spent waiting, waves that did not find their producers' flags at first look.  Synchronises the stream. */
 int qpn_train_stack_stats(qpn_handle* h, unsigned* h_out, int n, void* stream);
+/* Data-parallel step, two buckets (no reference counterpart: its DataParallel wrap, src/bin/qpnet_train.py:416-423, never runs with more than one
+ * GPU).  After qpn_train_backward_ex(append_scale = 1) has been enqueued: [*first, *first + *count) is the tail of the exchange buffer -- the
+ * post-net gradient blocks and the 4-float row-count trailer -- which the side stream completes while the layer backward is still running, and
+ * `stream` is made to wait for exactly that (an event, no host wait).  The caller all-reduces that range on `stream`, the rest [0, *first) on
+ * the stream the backward was enqueued on, and joins the two before qpn_adam_step_ex.  *count = 0: nothing finished early, exchange the whole buffer. */
+int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream);
 int qpn_train_profile_begin(qpn_handle* h, void* stream);
 int qpn_train_profile_mark(qpn_handle* h, int group, void* stream);   /* attribute the work enqueued since the previous mark to `group` */
 int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);

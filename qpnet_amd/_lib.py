@@ -49,6 +49,7 @@ SYMBOLS = [
     ("qpn_adam_step", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     ("qpn_train_stack_stats", _i, [_vp, C.POINTER(C.c_uint), _i, _vp]),
+    ("qpn_train_early_bucket", _i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
     ("qpn_train_profile_begin", _i, [_vp, _vp]),
     ("qpn_train_profile_mark", _i, [_vp, _i, _vp]),
     ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),

@@ -1504,6 +1504,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
         if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0);
+        // the post-net block of the flat gradient (and, with up_side, the zeroing and the row-count trailer behind it) is final from here on:
+        // a data-parallel caller exchanges that bucket while the layer backward still runs (qpn_train_early_bucket)
+        if (early_reduce && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
     }
     // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
     // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of

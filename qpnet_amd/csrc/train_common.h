@@ -88,6 +88,7 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
     int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
+    hipEvent_t ev_early; int* early_recorded;                // recorded on the side stream behind the early reduction when it also wrote the trailer (qpn_train_early_bucket)
 };
 
 #define TR_QHEAD_STRIDE 1056   // words between sub-queue heads (4224 bytes: different memory channels)

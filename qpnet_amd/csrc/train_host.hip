@@ -37,6 +37,7 @@ struct TrainState {
     TrainGemm gm;
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
+    hipEvent_t ev_early; int early_recorded; int64_t early_first;   // qpn_train_early_bucket: the flat-gradient tail that is final before the layer backward ends
     TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
     int64_t bwd_generation;                                  // generation of the forward the last backward belonged to
     bool stack_disabled;                                     // a stack-queue launch gave up once (status bit 4): this handle keeps to a launch per layer
@@ -151,7 +152,7 @@ static int train_init(qpn_handle* h) {
     t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
     t->d_gdst = t->d_gdst_list = t->d_gzero = nullptr; t->n_gzero = 0;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
-    t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr;
+    t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr; t->ev_early = nullptr; t->early_recorded = 0; t->early_first = -1;
     memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
     t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; t->bwd_generation = -1; t->stack_disabled = false; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
@@ -271,6 +272,8 @@ static int train_init(qpn_handle* h) {
     for (int l = 0; l < L; ++l) for (int s = 0; s < S; ++s) gs[g.layers[l].skipb + s] = bw.g_bs + s;
     bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
     bw.g_early1 = go;
+    // the post-net blocks close the flat parameter order (state_dict order, qpnet.py): with the trailer behind them one contiguous early bucket
+    t->early_first = (g.post1_b == g.post1_w + (int64_t)S * S && g.post2_w == g.post1_b + S && g.post2_b == g.post2_w + (int64_t)Q * S && g.post2_b + Q == g.n_params) ? g.post1_w : -1;
     for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
     for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
     // causal conv table: dW[c][q][tap] = sum_t dX0[t][c] * onehot(x[t-1+tap])[q] is one more time contraction (k_wgrad3 mode 4)
@@ -345,6 +348,7 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, evf));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, evf));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, evf));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_early, evf));
     if (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) {     // opt-in experiment: no extra hardware queue otherwise
         QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
         for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
@@ -366,6 +370,7 @@ void qpn_train_destroy(TrainState* t) {
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->ev_mid) (void)hipEventDestroy(t->ev_mid);
+    if (t->ev_early) (void)hipEventDestroy(t->ev_early);
     if (t->split.side) (void)hipStreamDestroy(t->split.side);
     for (int l = 0; l < TR_MAXL; ++l) if (t->split.ev[l]) (void)hipEventDestroy(t->split.ev[l]);
     if (t->split.fork) (void)hipEventDestroy(t->split.fork);
@@ -623,11 +628,23 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
+    t->early_recorded = 0; bw.ev_early = t->ev_early; bw.early_recorded = (append_scale && t->early_first >= 0) ? &t->early_recorded : nullptr;
     // (the backward queue's heads and flags belong to ONE backward per forward: a repeated backward of the same forward runs a launch per layer)
     const bool first_bwd = t->bwd_generation != t->generation;
     t->bwd_generation = t->generation;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_)
                        : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
+}
+
+extern "C" int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!first || !count) { qpn_set_error("bad early_bucket arguments"); return QPN_EINVAL; }
+    *first = 0; *count = 0;
+    TrainState* t = h->train;
+    if (!t || !t->early_recorded) return QPN_OK;            // this backward finished nothing early (one stream, no upsampling kernel, a plain backward): one exchange
+    *first = t->early_first; *count = t->bw.n_params - t->early_first + 4;
+    QPN_HIP(hipStreamWaitEvent((hipStream_t)stream_, t->ev_early, 0));
+    return QPN_OK;
 }
 
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,

@@ -8,6 +8,7 @@ workspace (sized for 288 GB of HBM: whole-chunk activations stay resident), so a
 the same model before the first one's backward would replace them.  Every forward gets a generation
 number from the library; a backward whose forward is no longer the current one raises instead of
 using the wrong activations."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -310,6 +311,8 @@ class FusedTrainer:
         self.m = self.v = self.g = None
         self.pg, self.world = process_group, world_size
         self._logits = None
+        self.last_buckets = (0, 0)
+        self._early = None            # the stream the early bucket of the gradient exchange runs on (world_size > 1)
 
     def _buffers(self, flat):
         if self.m is None or self.m.device != flat.device or self.m.numel() != flat.numel():
@@ -357,8 +360,17 @@ class FusedTrainer:
             if multi:
                 # g <- n_r * grad_r with n_r appended; SUM over ranks; Adam divides by the summed row count on the device
                 _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 1, stream))
-                from .parallel import exchange
-                exchange(self.g, self.pg)
+                # two buckets: the tail the side stream has finished already can go out under the layer backward (qpn_train_early_bucket)
+                from .parallel import exchange_two_buckets
+                first, count = C.c_int64(0), C.c_int64(0)
+                if self._early is None:
+                    self._early = torch.cuda.Stream(dev)
+                # (opt-in, QPN_EXCHANGE_BUCKETS=2.  Measured with RCCL at one rank: the second call costs 18 us of stream time, 0.841 -> 0.859 ms a
+                #  step; what it can hide at 8 ranks is a quarter of the bandwidth term of a 2.3 MB, latency-bound all-reduce -- DESIGN.md section 7)
+                if os.environ.get("QPN_EXCHANGE_BUCKETS", "1") == "2":
+                    _lib.check(L.qpn_train_early_bucket(hd, C.byref(first), C.byref(count), self._early.cuda_stream))
+                exchange_two_buckets(self.g, first.value, count.value, self.pg, self._early if count.value else None)
+                self.last_buckets = (first.value, count.value)       # (what the last step exchanged early; (0, 0): one exchange)
                 L.qpn_train_profile_mark(hd, 9, stream)      # QPN_PG_ALLREDUCE (no-op unless a profile is being taken)
             else:
                 _lib.check(L.qpn_train_backward(hd, self._dlogits.data_ptr(), self.g.data_ptr(), stream))

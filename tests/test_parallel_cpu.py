@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, two_buckets=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,19 +35,22 @@ def _worker(rank, world, port, out):
         BL = int(b[0])
         loss, dl = TO.ce_loss(lg, t[:, -BL:])
         g = torch.from_numpy(TO.backward(cfg, flat, caches, dl))
-        parallel.allreduce_mean_gradient(g, x.shape[0] * BL)
+        # two buckets: the post-net blocks (the tail of the flat order) + trailer first, the rest behind them -- what FusedTrainer does on the GPU
+        early = flat.size - (cfg.n_skipch * cfg.n_skipch + cfg.n_skipch + cfg.n_quantize * cfg.n_skipch + cfg.n_quantize) if two_buckets else None
+        parallel.allreduce_mean_gradient(g, x.shape[0] * BL, early_first=early)
         opt.step(flat, g.numpy())
     out[rank] = flat
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_global_batch():
+@pytest.mark.parametrize("two_buckets", [False, True])
+def test_two_rank_step_equals_global_batch(two_buckets):
     mp.set_start_method("spawn", force=True)
     mgr = mp.Manager()
     out = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [mp.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if two_buckets else 0)
+    procs = [mp.Process(target=_worker, args=(r, 2, port, out, two_buckets)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

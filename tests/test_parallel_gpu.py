@@ -91,14 +91,14 @@ for ci in parallel.shard_indices(4, rank, world):
     x, h, t, d, b = synth.train_inputs(cfg, bls[ci], 900 + ci, 30000)
     xs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, h, t, d, b)]
     losses.append(tr.step(*xs))
-np.savez(out, w=m.flat_parameters().cpu().numpy(), losses=np.array(losses))
+np.savez(out, w=m.flat_parameters().cpu().numpy(), losses=np.array(losses), buckets=np.array(tr.last_buckets, dtype=np.int64))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("cfgname", ["tiny", "paper"])
-def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, cuda, tmp_path):
+@pytest.mark.parametrize("cfgname,buckets", [("tiny", 1), ("tiny", 2), ("paper", 2)])
+def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, buckets, cuda, tmp_path):
     """Two fresh child processes share GPU 0 and exchange over gloo (RCCL refuses two ranks on one device); each runs the
     product's FusedTrainer(world_size=2) on chunks of unequal batch_length.  Final weights must be bit-identical across
     the ranks and equal the numpy oracle trained on the UNION batch of every step (row-weighted mean).
@@ -109,7 +109,7 @@ def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, cuda, tmp_path):
     port = 29500 + os.getpid() % 2000
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QPN_EXCHANGE_BUCKETS=str(buckets))
     outs = [str(tmp_path / ("r%d.npz" % r)) for r in range(2)]
     cfg = TINY if cfgname == "tiny" else PAPER
     bls = [300, 410, 350, 280] if cfgname == "tiny" else [1400, 1750, 1500, 1250]
@@ -118,6 +118,13 @@ def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, cuda, tmp_path):
         assert p.wait(timeout=420) == 0
     r0, r1 = np.load(outs[0]), np.load(outs[1])
     np.testing.assert_array_equal(r0["w"], r1["w"])                 # replicas stay bit-identical
+    # QPN_EXCHANGE_BUCKETS=2: the exchange went out as two buckets: the post-net blocks + trailer (final while the layer backward still runs) first, the rest behind them
+    n_post = cfg.n_skipch * cfg.n_skipch + cfg.n_skipch + cfg.n_quantize * cfg.n_skipch + cfg.n_quantize
+    for r in (r0, r1):
+        if buckets == 2:
+            assert int(r["buckets"][1]) == n_post + 4 and int(r["buckets"][0]) + n_post == r0["w"].size
+        else:
+            assert int(r["buckets"][1]) == 0
     flat = synth.make_weights(cfg, 3)
     opt = TO.Adam(flat.size)
     for step in range(2):
