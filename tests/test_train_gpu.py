@@ -299,6 +299,57 @@ def test_grad_accumulation_and_zero_grad_in_place(cuda):
     assert _flat_grad_of(params) is None
 
 
+def test_anchored_backward_has_loss_backward_semantics(cuda, monkeypatch):
+    """The drop-in module's backward when every parameter trains (the reference trainer, qpnet_train.py:527-531): one anchor leaf in the graph, the
+    120 gradients assigned by the backward itself as views of ONE persistent buffer (train._anchored_backward).  It must behave like autograd's own
+    accumulation: same values as the classic path (QPN_DROPIN_FLAT_GRAD=0), a second backward adds, a gradient somebody replaced is added to in
+    place, and a model with a frozen parameter goes the classic way (its frozen parameter gets no gradient)."""
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import _flat_grad_of
+    cfg = TINY
+    crit = torch.nn.CrossEntropyLoss()
+
+    def loss_of(m, seed):
+        x, h, t, d, b = synth.train_inputs(cfg, 500, seed, 30000)
+        xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+        return crit(m(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -int(b[0]):].reshape(-1))
+
+    def flat_grad(m):
+        return torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+
+    monkeypatch.setenv("QPN_DROPIN_FLAT_GRAD", "0")
+    mc = util.build_model(cfg, synth.make_weights(cfg, 21), cuda).train()
+    loss_of(mc, 71).backward(); c1 = flat_grad(mc)
+    mc.zero_grad(set_to_none=True); loss_of(mc, 72).backward(); c2 = flat_grad(mc)
+    assert "_qpn_gflat" not in mc.__dict__
+    monkeypatch.delenv("QPN_DROPIN_FLAT_GRAD")
+    m = util.build_model(cfg, synth.make_weights(cfg, 21), cuda).train()
+    scale = float(c1.abs().max())
+    loss_of(m, 71).backward()
+    params = list(m.parameters())
+    buf = _flat_grad_of(params)
+    assert buf is not None and buf.data_ptr() == m.__dict__["_qpn_gflat"][1].data_ptr()          # consecutive views of the persistent buffer
+    assert float((flat_grad(m) - c1).abs().max()) <= 1e-5 * scale
+    loss_of(m, 72).backward()                                                                     # accumulates (one add)
+    assert float((flat_grad(m) - (c1 + c2)).abs().max()) <= 1e-5 * scale
+    m.zero_grad(set_to_none=True); loss_of(m, 72).backward()                                      # the usual step: written in place, same buffer
+    assert _flat_grad_of(params).data_ptr() == buf.data_ptr()
+    assert float((flat_grad(m) - c2).abs().max()) <= 1e-5 * scale
+    params[3].grad = params[3].grad.clone(); params[5].grad = None                                # somebody touched two of them
+    loss_of(m, 71).backward()
+    assert float((flat_grad(m) - (c1 + c2)).abs()[: sum(p.numel() for p in params[:5])].max()) <= 1e-5 * scale
+    o5 = sum(p.numel() for p in params[:5]); n5 = params[5].numel()
+    assert float((params[5].grad.reshape(-1) - c1[o5:o5 + n5]).abs().max()) <= 1e-5 * scale      # (the one that had none holds the new gradient only)
+    m.zero_grad(set_to_none=True)
+    params[7].requires_grad_(False)                                                                # a frozen parameter: the classic path
+    loss_of(m, 72).backward()
+    assert params[7].grad is None and params[8].grad is not None
+    g = torch.cat([p.grad.reshape(-1) for i, p in enumerate(params) if i != 7])
+    o7 = sum(p.numel() for p in params[:7]); n7 = params[7].numel()
+    assert float((g - torch.cat([c2[:o7], c2[o7 + n7:]])).abs().max()) <= 1e-5 * scale
+
+
 def test_backward_of_a_replaced_forward_raises(cuda):
     """one outstanding forward per model: a validation forward between forward and backward must not silently feed the
     wrong activations to the backward kernels"""

@@ -45,3 +45,20 @@ for i in range(20):
     opt.step(); t5 = tick()
     for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)): acc[k] += v
 print("serialized ms per stage:", {k: round(v / 20 * 1e3, 3) for k, v in acc.items()})
+# host time per stage (no synchronisation inside the loop: what the Python thread spends enqueuing)
+acc = collections.OrderedDict((k, 0.0) for k in ("forward", "loss", "zero_grad", "backward", "adam"))
+torch.cuda.synchronize()
+tl0 = time.perf_counter()
+for i in range(100):
+    x, h, t, d, b = batches[i % 4]
+    t0 = time.perf_counter(); out = m(x, h, d, b); t1 = time.perf_counter()
+    loss = crit(out.view(-1, cfg.n_quantize), t[:, -out.shape[1]:].reshape(-1)); t2 = time.perf_counter()
+    opt.zero_grad(); t3 = time.perf_counter()
+    loss.backward(); t4 = time.perf_counter()
+    opt.step(); t5 = time.perf_counter()
+    for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)): acc[k] += v
+tl1 = time.perf_counter()
+torch.cuda.synchronize()
+tl2 = time.perf_counter()
+print("that loop: %.3f ms per step on the host, %.3f ms until the device was done" % ((tl1 - tl0) / 100 * 1e3, (tl2 - tl0) / 100 * 1e3))
+print("host ms per stage (unsynchronised loop):", {k: round(v / 100 * 1e3, 3) for k, v in acc.items()})
