@@ -290,10 +290,11 @@ def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=30):
     return steps / (time.perf_counter() - t0)
 
 
-def runner_loop_rate(m, tr, cfg, dev, steps=150):
+def runner_loop_rate(m, tr, cfg, dev, steps=300, sync_loss=False):
     """What `python -m qpnet_amd.run_train` does per iteration (runners.run_train: loaders.train_generator -> PinnedStager -> a depth-2
-    prefetch thread -> FusedTrainer.step(want_loss=True): the loss is read back every step, as the reference reads loss.item(),
-    src/bin/qpnet_train.py:533) on an in-memory corpus of synthetic utterances of VCC2018 shape."""
+    prefetch thread -> FusedTrainer.step(want_loss="lagged"): EVERY step's loss reaches the host, as the reference's loss.item() does
+    (src/bin/qpnet_train.py:533), one step late and without draining the stream; sync_loss: read in-step, the reference's literal order) on
+    an in-memory corpus of synthetic utterances of VCC2018 shape."""
     import torch
     from qpnet_amd import loaders, synth
     from qpnet_amd.runners import PinnedStager, Prefetcher
@@ -315,14 +316,27 @@ def runner_loop_rate(m, tr, cfg, dev, steps=150):
             dv = stage({"x": bx, "h": bh, "t": bt, "d": bd})
             yield dv["x"], dv["h"], dv["t"], dv["d"], bb, int(np.ceil(float(bd.max())))
     stream = Prefetcher(batches())
+    mode = True if sync_loss else "lagged"
     for _ in range(5):
         bx, bh, bt, bd, bb, maxd = next(stream)
-        tr.step(bx, bh, bt, bd, bb, want_loss=True, maxd=maxd)
+        tr.step(bx, bh, bt, bd, bb, want_loss=mode, maxd=maxd)
+    tr.flush_loss()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
+    total, got = 0.0, 0
+    for i in range(steps):
         bx, bh, bt, bd, bb, maxd = next(stream)
-        tr.step(bx, bh, bt, bd, bb, want_loss=True, maxd=maxd)
+        v = tr.step(bx, bh, bt, bd, bb, want_loss=mode, maxd=maxd)
+        if v is not None:
+            total += v; got += 1
+        if not sync_loss and (i + 1) % 100 == 0:          # (run_train's default reporting interval)
+            v = tr.flush_loss()
+            if v is not None:
+                total += v; got += 1
+    v = None if sync_loss else tr.flush_loss()
+    if v is not None:
+        total += v; got += 1
     torch.cuda.synchronize()
+    assert got == steps and np.isfinite(total)
     return steps / (time.perf_counter() - t0)
 
 
@@ -418,8 +432,10 @@ def run_train(args, rank, local, world):
     }
     if world == 1 and not args.no_cpu:
         # the drop-in path north_star describes: the reference's own loop on this module (weights keep training; timing only)
-        # the loop `python -m qpnet_amd.run_train` runs: generator + pinned staging + prefetch thread + step(want_loss=True)
+        # the loop `python -m qpnet_amd.run_train` runs: generator + pinned staging + prefetch thread + step(want_loss="lagged"): every step's loss
+        # reaches the host one step late; ..._sync_loss: read inside the step, the reference's literal order (QPN_RUN_TRAIN_SYNC_LOSS=1)
         out["runner_loop_steps_per_s"] = runner_loop_rate(m, tr, cfg, dev)
+        out["runner_loop_sync_loss_steps_per_s"] = runner_loop_rate(m, tr, cfg, dev, steps=150, sync_loss=True)
         out["dropin_loop_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=False)
         out["dropin_loop_flat_adam_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=True)
     if rank == 0 and world == 1 and not args.no_cpu:

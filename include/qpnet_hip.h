@@ -175,6 +175,12 @@ int qpn_train_forward_loss(qpn_handle* h, const float* d_flat, int B, int64_t T,
                            const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
                            float* d_logits, int want_logits, float* d_dlogits, void* stream);
 int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream);
+/* The same number without draining the stream at every step (the reference reads loss.item() per step, src/bin/qpnet_train.py:533, and
+ * only ever uses the values summed over a reporting interval, :536-541): _enqueue copies this step's loss to pinned memory behind the
+ * step's kernels; _collect(newest = 0) returns the one enqueued ONE call earlier (finished long ago: no wait in practice), newest = 1 the
+ * last one (waits for it).  *h_valid = 0 when there is no such copy (first step, or already collected). */
+int qpn_train_loss_enqueue(qpn_handle* h, void* stream);
+int qpn_train_loss_collect(qpn_handle* h, int newest, double* h_loss, int* h_valid);
 
 /* torch.optim.Adam step (reference src/bin/qpnet_train.py:426-429,531), fp32, in place:
  * d_flat, d_m, d_v (n floats each) updated from d_grad; `step` is the 1-based step count. */

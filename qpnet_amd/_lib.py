@@ -45,6 +45,8 @@ SYMBOLS = [
     ("qpn_train_status_collect_lagged", _i, [_vp]),
     ("qpn_train_forward_loss", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     ("qpn_train_loss", _i, [_vp, C.POINTER(C.c_double), _vp]),
+    ("qpn_train_loss_enqueue", _i, [_vp, _vp]),
+    ("qpn_train_loss_collect", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("qpn_ce_loss", _i, [_vp, _vp, _vp, _i64, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     ("qpn_adam_step", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
     ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),

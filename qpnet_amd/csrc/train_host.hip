@@ -29,6 +29,7 @@ struct TrainState {
     int* d_tap; size_t tap_cap;
     int* d_status; double* d_loss;
     int* h_status_pinned; hipEvent_t ev_status[2]; bool status_pending[2]; int status_newest;      // qpn_train_status_enqueue / _collect: the deferred check, two slots
+    double* h_loss_pinned; hipEvent_t ev_loss[2]; bool loss_pending[2]; int loss_newest;            // qpn_train_loss_enqueue / _collect: the loss read one step late, two slots of 64 partial sums
     bool fwd_valid;
     bool loss_clear;                          // the loss accumulator is zero (cleared by the forward's refresh kernel, consumed by one CE call)
     bool use_gemm;                            // wide stacks (n_resch > 128, or QPN_TRAIN_GEMM=1): the LDS-tiled GEMM path of train_gemm.hip
@@ -302,6 +303,10 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMemset(t->d_status, 0, 64));
     t->h_status_pinned = nullptr; t->ev_status[0] = t->ev_status[1] = nullptr; t->status_pending[0] = t->status_pending[1] = false; t->status_newest = 0;
     QPN_HIP(hipHostMalloc((void**)&t->h_status_pinned, 64, hipHostMallocDefault));
+    t->h_loss_pinned = nullptr; t->ev_loss[0] = t->ev_loss[1] = nullptr; t->loss_pending[0] = t->loss_pending[1] = false; t->loss_newest = 0;
+    QPN_HIP(hipHostMalloc((void**)&t->h_loss_pinned, 2 * 64 * sizeof(double), hipHostMallocDefault));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_loss[0], hipEventDisableTiming));
+    QPN_HIP(hipEventCreateWithFlags(&t->ev_loss[1], hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_status[0], hipEventDisableTiming));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_status[1], hipEventDisableTiming));
     QPN_HIP(hipMalloc(&t->d_loss, 64 * sizeof(double)));
@@ -365,6 +370,8 @@ void qpn_train_destroy(TrainState* t) {
     void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct, t->d_sq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
+    if (t->h_loss_pinned) (void)hipHostFree(t->h_loss_pinned);
+    for (int i = 0; i < 2; ++i) if (t->ev_loss[i]) (void)hipEventDestroy(t->ev_loss[i]);
     for (int i = 0; i < 2; ++i) if (t->ev_status[i]) (void)hipEventDestroy(t->ev_status[i]);
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
@@ -517,6 +524,36 @@ extern "C" int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream_) {
     double sum = 0.0;
     for (int i = 0; i < 64; ++i) sum += parts[i];
     *h_loss = sum;
+    return QPN_OK;
+}
+
+// The loss without draining the stream every step: _enqueue copies this step's 64 partial sums to a pinned slot behind the step's kernels (two
+// slots: the copy of two steps ago is long done when its slot is reused); _collect(newest = 0) returns the sum enqueued one call EARLIER -- complete
+// by the time the host has enqueued another step, so it does not wait in practice --, newest = 1 the last one (waits for it).  *h_valid = 0: no such copy.
+extern "C" int qpn_train_loss_enqueue(qpn_handle* h, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train) { qpn_set_error("qpn_train_loss_enqueue needs a preceding qpn_train_forward_loss / qpn_ce_loss"); return QPN_ESTATE; }
+    TrainState* t = h->train;
+    const int slot = t->loss_newest ^ 1;
+    if (t->loss_pending[slot]) QPN_HIP(hipEventSynchronize(t->ev_loss[slot]));      // (an uncollected copy of two calls ago: dropped)
+    QPN_HIP(hipMemcpyAsync(t->h_loss_pinned + 64 * slot, t->d_loss, 64 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    QPN_HIP(hipEventRecord(t->ev_loss[slot], (hipStream_t)stream_));
+    t->loss_pending[slot] = true; t->loss_newest = slot;
+    return QPN_OK;
+}
+extern "C" int qpn_train_loss_collect(qpn_handle* h, int newest, double* h_loss, int* h_valid) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h_loss || !h_valid) { qpn_set_error("bad loss_collect arguments"); return QPN_EINVAL; }
+    *h_valid = 0; *h_loss = 0.0;
+    if (!h->train) return QPN_OK;
+    TrainState* t = h->train;
+    const int slot = newest ? t->loss_newest : t->loss_newest ^ 1;
+    if (!t->loss_pending[slot]) return QPN_OK;
+    QPN_HIP(hipEventSynchronize(t->ev_loss[slot]));
+    t->loss_pending[slot] = false;
+    double sum = 0.0;
+    for (int i = 0; i < 64; ++i) sum += t->h_loss_pinned[64 * slot + i];
+    *h_loss = sum; *h_valid = 1;
     return QPN_OK;
 }
 

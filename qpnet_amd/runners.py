@@ -117,6 +117,7 @@ class Prefetcher:
     _END = object()
 
     def __init__(self, gen, depth=2):
+        depth = int(os.environ.get("QPN_PREFETCH_DEPTH", depth))
         self.q = queue.Queue(maxsize=depth)
         self.err = None
         self.t = threading.Thread(target=self._run, args=(gen,), daemon=True)
@@ -250,13 +251,22 @@ def run_train(argv=None, update=False):
     stream = Prefetcher(_batches(args, conf, model, True, None, dev, rank, world))      # rank r: chunks r, r+N, r+2N, ...
     loss = total = 0.0
     logging.info("training start!")
+    # The reference reads loss.item() at every step (qpnet_train.py:533) and reports its average over `intervals` steps (:536-541).  Here a step
+    # returns the loss of the step BEFORE it (copied out behind that step's kernels: the device never idles while the host enqueues) and the last
+    # one of an interval is fetched at the report: the same averages, the per-batch debug line one step late.  QPN_RUN_TRAIN_SYNC_LOSS=1: in-step.
+    lagged = os.environ.get("QPN_RUN_TRAIN_SYNC_LOSS", "0") != "1"
     for i in range(iterations, args.iters):
         start = time.time()
         bx, bh, bt, bd, bb, maxd = next(stream)
-        batch_loss = trainer.step(bx, bh, bt, bd, bb, want_loss=True, maxd=maxd)
-        loss += batch_loss
+        batch_loss = trainer.step(bx, bh, bt, bd, bb, want_loss="lagged" if lagged else True, maxd=maxd)
+        if batch_loss is not None:
+            loss += batch_loss
+            logging.debug("batch loss = %.3f" % batch_loss)
         total += time.time() - start
-        logging.debug("batch loss = %.3f (%.3f sec / batch)" % (batch_loss, time.time() - start))
+        if (i + 1) % args.intervals == 0 or (i + 1) % args.checkpoint_interval == 0 or i + 1 == args.iters:
+            last = trainer.flush_loss() if lagged else None
+            if last is not None:
+                loss += last
         if (i + 1) % args.intervals == 0:
             logging.info("(iter:%d) average loss = %.6f (%.3f sec / batch)" % (i + 1, loss / args.intervals, total / args.intervals))
             loss_record.append(loss / args.intervals)

@@ -428,12 +428,27 @@ class FusedTrainer:
             _lib.check(L.qpn_adam_step_ex(hd, flat.data_ptr(), self.g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), flat.numel(),
                                           self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                           self.g.data_ptr() + 4 * flat.numel() if multi else None, stream))
+            if want_loss == "lagged":
+                # this step's loss is copied out behind its kernels; what comes back is the PREVIOUS step's (None at the first step, or right after
+                # flush_loss()): the stream is never drained, and a caller that sums losses over an interval and calls flush_loss() at its end has the same sum
+                _lib.check(L.qpn_train_loss_enqueue(hd, stream))
+                _lib.check(L.qpn_train_status_enqueue(hd, stream))
+                valid = C.c_int(0)
+                _lib.check(L.qpn_train_loss_collect(hd, 0, C.byref(loss), C.byref(valid)))
+                return loss.value if valid.value else None
             if want_loss:
                 _lib.check(L.qpn_train_loss(hd, C.byref(loss), stream))
                 _lib.check(L.qpn_train_status(hd, stream))   # (the stream has just been drained for the loss: in-step, like the reference)
             else:
                 _lib.check(L.qpn_train_status_enqueue(hd, stream))
         return loss.value if want_loss else None
+
+    def flush_loss(self):
+        """The loss of the last step(want_loss="lagged") (waits for that step), or None if it has been returned already."""
+        L, hd = self.model._native(self.model._flat.device)
+        loss, valid = C.c_double(0.0), C.c_int(0)
+        _lib.check(L.qpn_train_loss_collect(hd, 1, C.byref(loss), C.byref(valid)))
+        return loss.value if valid.value else None
 
     def check_status(self):
         """Raise what the device-side check of the last step(want_loss=False) found (see QPNet.check_status)."""

@@ -92,6 +92,31 @@ def test_fused_train_steps_vs_reference(case, cuda, golden_dir):
     np.testing.assert_allclose(w[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
 
 
+def test_lagged_loss_is_every_steps_loss_one_step_late(cuda, golden_dir):
+    """step(want_loss="lagged") -- what run_train does -- returns the PREVIOUS step's loss without draining the stream, flush_loss() the last
+    one: together exactly the losses of step(want_loss=True), i.e. the reference run's (same fixture), each delivered once."""
+    from qpnet_amd.train import FusedTrainer
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES[0]
+    g = np.load(golden_dir + "/train.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    got = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 30000)
+        v = tr.step(*_to(cuda, x, h, t, d, b), want_loss="lagged")
+        assert (v is None) == (step == 0 or step == 2)              # nothing before the first step, nothing right after a flush
+        if v is not None:
+            got.append(v)
+        if step == 1:                                               # a reporting boundary in the middle
+            got.append(tr.flush_loss())
+            assert tr.flush_loss() is None                          # delivered once
+    got.append(tr.flush_loss())
+    assert len(got) == nsteps
+    np.testing.assert_allclose(got, g[name + "_losses"], atol=1e-4, rtol=0)
+    w = m.flat_parameters().cpu().numpy()
+    np.testing.assert_allclose(w[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
 def test_torch_adam_on_views_matches(cuda, golden_dir):
     """the drop-in path the reference trainer uses: torch.optim.Adam over model.parameters()
     (which are views of the flat buffer) + our autograd.Function."""
