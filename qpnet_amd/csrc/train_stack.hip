@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wr[ks] = Wr[((size_t)ks * 4 + wave) * 64 + lane];
         bs = p.bp[ly.bias1 + c]; bt = p.bp[ly.bias1 + C + c]; bb = p.bp[ly.biasr + c];
+        // waited for HERE, on the layer change's own path: left to the first MFMA that reads them, hipcc's wait for the two paths' merged state lands
+        // in front of EVERY tile's first MFMA (`s_waitcnt vmcnt(1)`), i.e. behind the previous tile's write-through block output.  (The builtin, not
+        // `asm`: SIInsertWaitcnts reads an S_WAITCNT that is an instruction and takes everything older as complete; it cannot see into `asm`.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), nothing else
     };
     auto xrsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
     int tp = 0; float4 rc, rp, rx;
@@ -172,6 +176,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         __builtin_amdgcn_sched_barrier(0);                       // (all three requests before anything waits for one of them)
     };
     auto store_rows = [&](const SqTile& d, float* As) {
+        // (all three requests are taken up here by EVERY lane: the lanes without an auxiliary column never read theirs, and a register hipcc believes
+        //  pending is waited for where it is next written -- the next tile's first MFMAs, behind the write-through block output)
+        asm volatile("" : "+v"(rx.w));
         const bool in = d.n0 + srow < N1;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 vc = in ? rc : z, vp = in ? rp : z, vx = (in && aux_real) ? rx : z;
@@ -188,12 +195,16 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         d1 = n0 + orow + 8 < N1 ? d1 : dmy + C;
         *(float2*)d0 = v0; *(float2*)d1 = v1;
     };
+    // (the registers a store read its data from are not written again before the store has completed -- hipcc waits for that --, and they were the
+    //  first accumulators of the next tile: `s_waitcnt vmcnt(1)` behind its first MFMA.  The value stays live until the next publish point instead.)
+    u32x4 xkeep = {0u, 0u, 0u, 0u};
     auto store_x = [&](const SqTile& d, bool go) {                // the block output of tile d (in Xs) -> X[l + 1], write-through, 16 bytes per thread
         const float2 v0 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4), v1 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4 + 2);
         const int n = d.n0 + srow;
         const unsigned o = (go && n < N1) ? (__umul24((unsigned)n, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
         const u32x4 v = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v1.x), __float_as_uint(v1.y)};
         __builtin_amdgcn_raw_buffer_store_b128(v, xrsrc(p.X + (size_t)d.xrow * C + xlayer), (int)o, 0, SQ_SC1);
+        xkeep = v;
     };
     auto publishes = [&](const SqTile& d) { return sq_valid(d) && !sq_last(d); };     // (nothing reads the last block's residual output: no rows, no flag)
 
@@ -271,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         __builtin_amdgcn_sched_barrier(0);
         SQ_STAMP(2);
         // publish point: younger than the previous tile's row stores are only this trip's tap load and, in wave 0, the ticket
-        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F71);                        // vmcnt(1) (the builtin: hipcc's own bookkeeping sees it)
+        asm volatile("" :: "v"(xkeep));
         if (lane == 0) {
             const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
@@ -357,7 +369,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         load_rows(next, true);
         // ... and the block output leaves BEHIND them (vmcnt counts in order: in front of them, the staging below would wait for the
         // write-through stores' way to memory as well)
-        if (!any_slow) store_x(cur, publishes(cur));
+        // (ONE unconditional instruction -- its lanes aim beyond the range when the slow path has stored the tile already --: behind a conditional one
+        //  hipcc's wait for the rows becomes vmcnt(0), i.e. a wait for this store's way to memory)
+        store_x(cur, publishes(cur) && !any_slow);
         store_rows(next, sm + ((it + 1) & 1) * 16 * lda);
         SQ_STAMP(7);
         tp = tpn;
