@@ -333,10 +333,15 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         SQ_STAMP(6);
         asm volatile("" : "+v"(fv0), "+v"(fv1));                   // (the flag words are looked at HERE: left alone hipcc compares them, i.e. waits for them, right behind the loads)
         bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+#if SQ_EXP & 512
+        ready = true;
+#endif
         // sigma / tanh leave BEHIND the look at the flags: vmcnt counts in order, so stores issued in front of it are waited for with it
         asm volatile("" ::: "memory");
+#if !(SQ_EXP & 64)
         store_out(SGs, SG, cur.n0);
         store_out(THs, TH, cur.n0);
+#endif
         if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
         TR_LDS_BARRIER();                                          // B3
         int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
@@ -366,12 +371,18 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         }
         // the next tile's rows: ONE request site (a second one inside the branch above makes the row registers phi nodes, and hipcc
         // resolves them with copies -- i.e. waits for the rows, and for the write-through stores in front of them, right here)
+#if SQ_EXP & 256
+        rc = rp = rx = make_float4(0.25f, 0.5f, 0.125f, 0.75f);
+#else
         load_rows(next, true);
+#endif
         // ... and the block output leaves BEHIND them (vmcnt counts in order: in front of them, the staging below would wait for the
         // write-through stores' way to memory as well)
         // (ONE unconditional instruction -- its lanes aim beyond the range when the slow path has stored the tile already --: behind a conditional one
         //  hipcc's wait for the rows becomes vmcnt(0), i.e. a wait for this store's way to memory)
+#if !(SQ_EXP & 128)
         store_x(cur, publishes(cur) && !any_slow);
+#endif
         store_rows(next, sm + ((it + 1) & 1) * 16 * lda);
         SQ_STAMP(7);
         tp = tpn;
