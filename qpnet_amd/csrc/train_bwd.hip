@@ -1499,14 +1499,16 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
     if (const char* e = getenv("QPN_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= L) mid = v; }
     if (!overlap) mid = L;
+    // experiment (QPN_REDUCE_LATE_SIDE=1): the memory-bound early reduction next to the matrix-bound dW1 instead of next to the latency-bound layer backward
+    const bool reduce_late = early_reduce && getenv("QPN_REDUCE_LATE_SIDE") && atoi(getenv("QPN_REDUCE_LATE_SIDE")) == 1;
     if (overlap) {
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
-        if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0);
+        if (early_reduce && !reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0);
         // the post-net block of the flat gradient (and, with up_side, the zeroing and the row-count trailer behind it) is final from here on:
         // a data-parallel caller exchanges that bucket while the layer backward still runs (qpn_train_early_bucket)
-        if (early_reduce && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
+        if (early_reduce && !reduce_late && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
     }
     // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
     // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
@@ -1594,6 +1596,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (wr_side || up_side || causal_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
+        if (reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0);
         if (up_side) launch_up_bwd(p, bw, side);
         if (wr_side) launch_w1_wr(0, mid, side, 2);
         if (causal_side) launch_causal(side);
