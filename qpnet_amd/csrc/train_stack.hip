@@ -23,6 +23,9 @@
 #include "train_common.h"
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// dev aid, TIMING ONLY (results are invalid): -DSQ_EXP=<bits> removes parts of the queues' memory traffic, to see what each costs --
+// backward: 1 float atomics, 2 plain instead of write-through hand-off (both directions), 4 dZ rows, 16 own-row / fixed-tap stores, 32 every look "ready";
+// forward: 64 sigma / tanh rows, 128 block output, 256 row requests, 512 every look "ready"
 #ifndef SQ_EXP
 #define SQ_EXP 0
 #endif
