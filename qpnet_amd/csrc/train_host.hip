@@ -465,9 +465,15 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
             QPN_HIP(hipMemsetAsync(t->d_sq, 0, nsq * sizeof(unsigned), stream));
             t->sq_pos_cap = cap; t->sq_per_dir = per_dir;
         }
-        p.qctl = t->stack_disabled ? nullptr : t->d_sq;          // (nullptr: no queue launches, no tables)
-        p.qtab = t->stack_disabled ? nullptr : (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
-        p.qtab_b = t->stack_disabled ? nullptr : p.qtab + 2 * (t->sq_pos_cap + 1);
+        // A step captured into a hipGraph replays its launches with the arguments of the capture: the queues' epoch -- a launch argument, a new one
+        // per forward, which is what lets the flags go unzeroed -- would repeat, and every flag of the previous replay would read as published.
+        // While the stream is capturing the stack therefore runs as a launch per layer.
+        hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap_st);
+        const bool no_queue = t->stack_disabled || cap_st != hipStreamCaptureStatusNone;
+        p.qctl = no_queue ? nullptr : t->d_sq;                   // (nullptr: no queue launches, no tables)
+        p.qtab = no_queue ? nullptr : (int4*)(t->d_sq + TR_QHDR_WORDS + 2 * t->sq_per_dir);
+        p.qtab_b = no_queue ? nullptr : p.qtab + 2 * (t->sq_pos_cap + 1);
         const unsigned epoch = (unsigned)((t->generation + 1) % 0xFFFFFFFFll) + 1u;      // (generation is bumped below; never 0)
         StackQ& f = t->sqf; StackQ& bq = t->sqb;
         f.flags = t->d_sq + TR_QHDR_WORDS; f.head = t->d_sq + 1024; f.abort = t->d_sq + 1; f.stats = t->d_sq + 4; f.epoch = epoch; f.total = p.qtotal; f.tab = p.qtab;

@@ -401,8 +401,12 @@ class FusedTrainer:
         stream = torch.cuda.current_stream(dev).cuda_stream
         loss = C.c_double(0.0)
         multi = self.world > 1
+        # (a step being captured into a hipGraph -- torch.cuda.graph -- may not wait for events or read anything back: no status bookkeeping, the
+        #  caller checks with check_status() outside the graph; the library runs the stack as a launch per layer while a stream is capturing)
+        capturing = torch.cuda.is_current_stream_capturing()
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_train_status_collect_lagged(hd))       # the check of the step before the previous one (never waits for queued work)
+            if not capturing:
+                _lib.check(L.qpn_train_status_collect_lagged(hd))   # the check of the step before the previous one (never waits for queued work)
             # forward + CrossEntropyLoss + dL/dlogits in one call (the loss stays on the device unless asked for)
             _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                                 x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
@@ -439,7 +443,7 @@ class FusedTrainer:
             if want_loss:
                 _lib.check(L.qpn_train_loss(hd, C.byref(loss), stream))
                 _lib.check(L.qpn_train_status(hd, stream))   # (the stream has just been drained for the loss: in-step, like the reference)
-            else:
+            elif not capturing:
                 _lib.check(L.qpn_train_status_enqueue(hd, stream))
         return loss.value if want_loss else None
 
