@@ -526,7 +526,9 @@ def run_default_geometry(local):
                                            "note": "floor = (2L+3) x 1.46 us (the kernel's own all-gather edge with no arithmetic and no weight stream, measured: "
                                                    "profiles/r04_allgather_floor.txt -- 51 us per sample, i.e. above the 45.35 us of real time before a weight is read) + "
                                                    "96.6 MB / 8.6 TB/s (Infinity-Cache gather rate, whole chip); at B = 20 every utterance group re-streams the weights "
-                                                   "(weight_stream_achieved_TBps is the aggregate), so the stream, not the hops, binds"}}
+                                                   "(weight_stream_achieved_TBps is the aggregate); sharing one stream among three utterances of a group was built and "
+                                                   "measured (profiles/r04_coop_shared_stream.txt): 97.8 -> 91.8 k samples/s, so at B = 20 neither the hops nor the stream "
+                                                   "bind but the instruction work of a row (FMA chunk + DPP tree) summed over the chip"}}
     dec["reference_cpu_samples_per_s"] = 40
     dec["kernel"] = "k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= CUs whose row slices are whole tiles)"
     out["decode"] = dec
