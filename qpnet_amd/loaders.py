@@ -244,12 +244,20 @@ def read_wav(path):
 
 
 def _h5py():
+    """h5py, or -- where only the HDF5 C library is installed (this image) -- the same few calls on libhdf5 itself (qpnet_amd/_hdf5.py): either
+    way the files are real HDF5, the format the reference's feature extraction writes and its trainers read (utils.py:43-128)."""
     try:
         import h5py
         return h5py
-    except ImportError as e:     # not installed in the build image
-        raise ImportError("h5py is required for the reference's .h5 feature files (utils.py:43-92); "
-                          "use feature_format 'npy' or pass arrays to decode_generator / train_generator instead") from e
+    except ImportError:
+        pass
+    try:
+        from . import _hdf5
+        _hdf5._lib()
+        return _hdf5
+    except ImportError as e:
+        raise ImportError("neither h5py nor an HDF5 library (libhdf5, QPN_LIBHDF5=<path>) is available for the reference's .h5 feature files "
+                          "(utils.py:43-92); use feature_format 'npy' or pass arrays to decode_generator / train_generator instead") from e
 
 
 def read_hdf5(hdf5_name, hdf5_path):
@@ -261,6 +269,22 @@ def read_hdf5(hdf5_name, hdf5_path):
         if hdf5_path not in f:
             raise KeyError("There is no such a data in hdf5 file. (%s)" % hdf5_path)
         return f[hdf5_path][()]
+
+
+def check_hdf5(hdf5_name, hdf5_path):
+    """reference utils.check_hdf5 (utils.py:19-40): the file exists and holds that dataset."""
+    if not os.path.exists(hdf5_name):
+        return False
+    with _h5py().File(hdf5_name, "r") as f:
+        return hdf5_path in f
+
+
+def shape_hdf5(hdf5_name, hdf5_path):
+    """reference utils.shape_hdf5 (utils.py:71-88): the dataset's shape without reading it (the reference exits where this raises)."""
+    if not check_hdf5(hdf5_name, hdf5_path):
+        raise KeyError("There is no such a file or dataset. (%s, %s)" % (hdf5_name, hdf5_path))
+    with _h5py().File(hdf5_name, "r") as f:
+        return tuple(f[hdf5_path].shape)
 
 
 def write_hdf5(hdf5_name, hdf5_path, write_data, is_overwrite=True):

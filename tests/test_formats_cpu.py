@@ -1,5 +1,5 @@
 """CPU: on-disk formats and optimizer-state layout either side of the hot path: HDF5 wrappers
-(through a stand-in h5py module), scaler statistics, pickled model.conf, Adam state in torch.optim.Adam's layout, the
+(on h5py or, as in this image, on the HDF5 C library itself; a stand-in module only where neither exists), scaler statistics, pickled model.conf, Adam state in torch.optim.Adam's layout, the
 weighted gradient-exchange protocol."""
 import argparse
 import os
@@ -15,15 +15,71 @@ from qpnet_amd.config import TINY
 STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stubs")
 
 
+def _real_hdf5_backend():
+    """h5py, or qpnet_amd._hdf5 on an installed libhdf5 (what loaders._h5py() picks), or None."""
+    try:
+        import h5py
+        if "stubs" not in getattr(h5py, "__file__", ""):
+            return h5py
+    except ImportError:
+        pass
+    try:
+        from qpnet_amd import _hdf5
+        _hdf5._lib()
+        return _hdf5
+    except ImportError:
+        return None
+
+
 @pytest.fixture
 def h5stub(monkeypatch):
-    try:
-        import h5py  # noqa: F401  (a real h5py, if present, is what gets tested)
-    except ImportError:
+    """the wrappers run on real HDF5 wherever h5py or the HDF5 C library exists (this image has the library); only otherwise on the pickle stand-in"""
+    if _real_hdf5_backend() is None:
         monkeypatch.syspath_prepend(STUBS)
         monkeypatch.delitem(sys.modules, "h5py", raising=False)
     yield
     sys.modules.pop("h5py", None) if "stubs" in getattr(sys.modules.get("h5py"), "__file__", "") else None
+
+
+def _hdf5_tool(name):
+    import shutil
+    for d in (None, "/opt/conda/bin", "/usr/bin", "/usr/local/bin"):
+        p = shutil.which(name) if d is None else os.path.join(d, name)
+        if p and os.path.exists(p):
+            return p
+    return None
+
+
+def test_hdf5_files_meet_the_hdf5_projects_own_tools(tmp_path):
+    """The /world wrappers against REAL HDF5 without h5py: a file loaders.write_hdf5 wrote (through libhdf5, qpnet_amd/_hdf5.py) is listed by h5ls and
+    its data dumped by h5dump bit for bit -- groups created on the way for /world/mean as h5py does --, and a file h5import built from text, i.e. one
+    this repo's code never touched, is read by loaders.read_hdf5 / shape_hdf5 / read_features (reference utils.py:43-128)."""
+    import subprocess
+    backend = _real_hdf5_backend()
+    h5dump, h5ls, h5import = _hdf5_tool("h5dump"), _hdf5_tool("h5ls"), _hdf5_tool("h5import")
+    if backend is None or not (h5dump and h5ls and h5import):
+        pytest.skip("needs h5py or libhdf5, and the HDF5 command-line tools")
+    assert loaders._h5py() is backend
+    w = np.random.RandomState(2).randn(41, 39)
+    f = str(tmp_path / "mine.h5")
+    loaders.write_hdf5(f, "/world", w.astype(np.float32))
+    loaders.write_hdf5(f, "/world_stats/mean", w.mean(0))
+    loaders.write_hdf5(f, "/world_stats/scale", w.std(0))
+    listing = subprocess.run([h5ls, "-r", f], capture_output=True, text=True, check=True).stdout
+    assert "/world " in listing and "Dataset {41, 39}" in listing and "/world_stats/scale" in listing and "Group" in listing
+    for path, ref in (("/world", w.astype(np.float32)), ("/world_stats/mean", w.mean(0))):
+        raw = str(tmp_path / "raw.bin")
+        subprocess.run([h5dump, "-d", path, "-b", "LE", "-o", raw, f], capture_output=True, check=True)
+        np.testing.assert_array_equal(np.fromfile(raw, dtype=ref.dtype.newbyteorder("<")).reshape(ref.shape), ref)
+    txt = str(tmp_path / "w.txt")
+    np.savetxt(txt, w, fmt="%.17g")
+    g = str(tmp_path / "imported.h5")
+    subprocess.run([h5import, txt, "-dims", "41,39", "-path", "/world", "-type", "TEXTFP", "-size", "64", "-o", g], capture_output=True, check=True)
+    np.testing.assert_array_equal(loaders.read_hdf5(g, "/world"), w)
+    np.testing.assert_array_equal(loaders.read_features(g), w)
+    assert tuple(loaders.shape_hdf5(g, "/world")) == w.shape
+    with pytest.raises(KeyError):
+        loaders.read_hdf5(g, "/world/mean")
 
 
 def test_hdf5_roundtrip_and_errors(h5stub, tmp_path):

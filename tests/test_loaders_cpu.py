@@ -85,11 +85,25 @@ def test_wav_writer_matches_reference_scaling(tmp_path):
     assert fs == 22050 and np.array_equal(back, pcm)
 
 
-def test_hdf5_helpers_fail_loudly_without_h5py():
-    import importlib.util, pytest
-    if importlib.util.find_spec("h5py") is not None:
-        pytest.skip("h5py present")
-    with pytest.raises(ImportError):
+def test_hdf5_helpers_fail_loudly_without_any_hdf5(monkeypatch):
+    """no h5py and no HDF5 C library: the .h5 helpers raise an ImportError that names the way out (no silent stand-in); a missing file is its own error"""
+    import builtins, pytest
+    from qpnet_amd import _hdf5
+    real_import = builtins.__import__
+
+    def no_h5py(name, *a, **k):
+        if name == "h5py":
+            raise ImportError("no h5py (test)")
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, "__import__", no_h5py)
+
+    def no_lib():
+        raise ImportError("no HDF5 library found (test)")
+    monkeypatch.setattr(_hdf5, "_lib", no_lib)
+    with pytest.raises(ImportError, match="QPN_LIBHDF5"):
+        loaders.read_hdf5("nope.h5", "/world")
+    monkeypatch.undo()
+    with pytest.raises((FileNotFoundError, ImportError)):
         loaders.read_hdf5("nope.h5", "/world")
 
 

@@ -1,5 +1,6 @@
 """GPU: the task entry points (python -m qpnet_amd.run_train|run_update|run_validate|run_decode) on a small synthetic
-corpus of .wav + .npy feature files: stages 1-3 of run_QP.sh on the native path, incl. checkpoint resume."""
+corpus of .wav + feature files -- .npy, and the reference's own format: HDF5 files with a /world dataset and a stats file with /world/mean and
+/world/scale (src/utils/utils.py:43-128, calc_stats.py), read through h5py or libhdf5 --: stages 1-3 of run_QP.sh on the native path, incl. checkpoint resume."""
 import argparse
 import os
 
@@ -13,7 +14,7 @@ from qpnet_amd.config import TINY
 pytestmark = pytest.mark.gpu
 
 
-def _corpus(root, n=3, frames=45):
+def _corpus(root, n=3, frames=45, fmt="npy"):
     from scipy.io import wavfile
     U = TINY.upsampling_factor
     os.makedirs(root + "/wav"); os.makedirs(root + "/feat")
@@ -23,21 +24,35 @@ def _corpus(root, n=3, frames=45):
         h = synth.make_features(frames + 3 * i, 700 + i)
         x = (rs.uniform(-0.8, 0.8, (frames + 3 * i) * U + 11) * 32767).astype(np.int16)
         wavfile.write("%s/wav/u%02d.wav" % (root, i), 22050, x)
-        np.save("%s/feat/u%02d.npy" % (root, i), h)
+        if fmt == "h5":
+            loaders.write_hdf5("%s/feat/u%02d.h5" % (root, i), "/world", h)       # what feature_extract.py writes (:337-343)
+        else:
+            np.save("%s/feat/u%02d.npy" % (root, i), h)
         feats.append(h)
     st = loaders.calc_stats(feats)
-    np.savez(root + "/stats.npz", mean=st.mean_, scale=st.scale_)
+    if fmt == "h5":
+        loaders.write_hdf5(root + "/stats.h5", "/world/mean", st.mean_)          # calc_stats.py:33-36
+        loaders.write_hdf5(root + "/stats.h5", "/world/scale", st.scale_)
+    else:
+        np.savez(root + "/stats.npz", mean=st.mean_, scale=st.scale_)
     return root
 
 
-def test_train_update_validate_decode_entry_points(cuda, tmp_path, oracle):
+@pytest.mark.parametrize("fmt", ["npy", "h5"])
+def test_train_update_validate_decode_entry_points(fmt, cuda, tmp_path, oracle):
     import torch
     from qpnet_amd import runners
-    root = _corpus(str(tmp_path / "corpus"))
+    if fmt == "h5":
+        try:
+            loaders._h5py()
+        except ImportError:
+            pytest.skip("neither h5py nor libhdf5 here")
+    root = _corpus(str(tmp_path / "corpus"), fmt=fmt)
     exp = str(tmp_path / "exp")
-    common = ["--waveforms", root + "/wav", "--feats", root + "/feat", "--stats", root + "/stats.npz"]
+    stats = root + ("/stats.h5" if fmt == "h5" else "/stats.npz")
+    common = ["--waveforms", root + "/wav", "--feats", root + "/feat", "--stats", stats]
     geo = ["--n_resch", "32", "--n_skipch", "32", "--dilationF_depth", "2", "--dilationF_repeat", "1", "--dilationA_depth", "1",
-           "--dilationA_repeat", "1", "--feature_format", "npy", "--batch_length", "1500", "--max_length", "4000", "--verbose", "0"]
+           "--dilationA_repeat", "1", "--feature_format", fmt, "--batch_length", "1500", "--max_length", "4000", "--verbose", "0"]
     conf = exp + "/model.conf"
     assert runners.run_train(common + geo + ["--expdir", exp, "--config", conf, "--iters", "6", "--checkpoint_interval", "3",
                                              "--intervals", "2", "--resume", exp + "/none.pkl"]) == 0
@@ -67,23 +82,24 @@ def test_train_update_validate_decode_entry_points(cuda, tmp_path, oracle):
     assert list(val) == ["checkpoint-final.pkl"] and 0 < val["checkpoint-final.pkl"] < 10
     # decode (greedy so the oracle can check it), wav files named by feature id
     out = str(tmp_path / "wav_out")
-    assert runners.run_decode(["--feats", root + "/feat", "--stats", root + "/stats.npz", "--config", conf, "--checkpoint",
+    assert runners.run_decode(["--feats", root + "/feat", "--stats", stats, "--config", conf, "--checkpoint",
                                exp + "/checkpoint-final.pkl", "--outdir", out + "/feat_id.wav", "--batch_size", "2", "--mode", "argmax",
                                "--intervals", "2000", "--verbose", "0"]) == 0
     from scipy.io import wavfile
     sd = torch.load(exp + "/checkpoint-final.pkl", map_location="cpu")["model"]
     flat = np.concatenate([v.numpy().ravel() for v in sd.values()]).astype(np.float32)
-    sc = loaders.read_scaler_stats(root + "/stats.npz")
+    sc = loaders.read_scaler_stats(stats)
+    feat = lambda i: loaders.read_features("%s/feat/u%02d.%s" % (root, i, fmt))
     for i in range(3):
         fs, w = wavfile.read("%s/u%02d.wav" % (out, i))
-        h = np.load("%s/feat/u%02d.npy" % (root, i))
+        h = feat(i)
         assert fs == 22050 and w.dtype == np.int16 and len(w) == h.shape[0] * TINY.upsampling_factor - 1
     # the shortest utterance re-decoded by the oracle from the checkpoint == the wav that was written
-    h = np.load(root + "/feat/u00.npy")
+    h = feat(0)
     from qpnet_amd import harness
     d = harness.extend_time(harness.dilated_factor(harness.batch_f0(h), 22050, 8)[:, None], TINY.upsampling_factor)[:, 0]
     # batch-level maxd: u00 was decoded together with u01 (batch_size 2, sorted by length)
-    h1 = np.load(root + "/feat/u01.npy")
+    h1 = feat(1)
     d1 = harness.dilated_factor(harness.batch_f0(h1), 22050, 8)
     maxd = int(np.ceil(max(d.max(), d1.max())))
     hn = sc.transform(h).astype(np.float32)
