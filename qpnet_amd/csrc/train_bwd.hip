@@ -1339,10 +1339,10 @@ void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t st
 // the skip / post-net part of the slab reduction, launched on the side stream right behind those weight gradients
 // tail: this launch also zeroes the entries no slab feeds and appends the trailer (then the final reduction must not: the upsampling
 // kernel's gradient is added onto those zeros in between, see qpn_launch_bwd)
-static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail) {
+static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail, int nch_side) {
     const int64_t n = (int64_t)(bw.g_early1 - bw.g_early0) + (tail ? bw.n_gzero + 4 : 0);
     hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, tail);
+                       nch_side, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, tail);
 }
 static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t st) {
     const UpArgs u = up_args(p, bw);
@@ -1409,6 +1409,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     // profiling (bench roofline) and QPN_TRAIN_SERIAL=1 keep everything on the one stream.  [Per-layer dW1/dWr launches
     // on a second side stream were tried too: 64 workgroups per launch are too few, 680 steps/s.]
     const int nch = bw.nch;
+    int nch_side_ = nch;      // time chunks (= partial slabs) of the skip / post-net contractions, which run on the side stream under the layer backward and are reduced by a launch of their own
     Wg2 wbase; memset(&wbase, 0, sizeof(wbase));
     wbase.slab = bw.slab; wbase.gstage = bw.gstage; wbase.nb = B; wbase.C = C; wbase.Ap = p.Ap; wbase.hup = p.HUP; wbase.tap = p.TAP; wbase.ncol_groups = 1;
     bool ok = true;
@@ -1420,7 +1421,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
             w.ncol_groups = wgrad_col_groups(w.M, w.N);
             for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; w.tap_off[l] = -1; }
-            ok = ok && wgrad2_any(w, nch, st);
+            ok = ok && wgrad2_any(w, nch_side_, st);
         }
         {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
             w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
@@ -1439,11 +1440,11 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
                 w.nlayers = 2;
                 w.A_lstride = (size_t)(bw.DY0 - bw.dlogits); w.B_lstride = (size_t)(p.S0 - p.Y0);
                 w.row0A[1] = w.row0B[1] = 0; w.R[1] = BL; w.tap_off[1] = -1; w.goff[1] = bw.g_p1; w.gbias[1] = bw.g_bp1;
-                ok = ok && wgrad2_any(w, nch, st);
+                ok = ok && wgrad2_any(w, nch_side_, st);
             } else {
-            ok = ok && wgrad2_any(w, nch, st);
+            ok = ok && wgrad2_any(w, nch_side_, st);
             w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
-            ok = ok && wgrad2_any(w, nch, st);
+            ok = ok && wgrad2_any(w, nch_side_, st);
             }
             }
         }
@@ -1499,13 +1500,18 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
     if (const char* e = getenv("QPN_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= L) mid = v; }
     if (!overlap) mid = L;
+    // (only with the early reduction: otherwise ONE launch reduces every block with one slab count)
+    if (early_reduce) {
+        nch_side_ = nch <= 48 ? nch : 48;       // measured on the overlapped step: 64 -> 48 chunks makes each of these launches slower alone and the step faster
+        if (const char* e = getenv("QPN_WGRAD_CHUNKS_SIDE")) { const int v = atoi(e); if (v >= 1 && v <= nch) nch_side_ = v; }
+    }
     // experiment (QPN_REDUCE_LATE_SIDE=1): the memory-bound early reduction next to the matrix-bound dW1 instead of next to the latency-bound layer backward
     const bool reduce_late = early_reduce && getenv("QPN_REDUCE_LATE_SIDE") && atoi(getenv("QPN_REDUCE_LATE_SIDE")) == 1;
     if (overlap) {
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
-        if (early_reduce && !reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0);
+        if (early_reduce && !reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
         // the post-net block of the flat gradient (and, with up_side, the zeroing and the row-count trailer behind it) is final from here on:
         // a data-parallel caller exchanges that bucket while the layer backward still runs (qpn_train_early_bucket)
         if (early_reduce && !reduce_late && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
@@ -1596,7 +1602,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
     if (wr_side || up_side || causal_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        if (reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0);
+        if (reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
         if (up_side) launch_up_bwd(p, bw, side);
         if (wr_side) launch_w1_wr(0, mid, side, 2);
         if (causal_side) launch_causal(side);
