@@ -428,7 +428,10 @@ def run_train(args, rank, local, world):
                      "step_frac": total_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
                      "note": "achieved = algorithmic FLOPs of the dominant kernel group (all its launches in one step) / its summed "
-                             "device time from HIP events on the launch stream; step_tflops = whole step"},
+                             "device time from HIP events on the launch stream; step_tflops = whole step.  Groups are timed on ONE stream; "
+                             "the timed steps run the skip / post-net weight gradients and the early slab reduction on a side stream under the layer "
+                             "backward, and there those two launches use 48 time chunks instead of the one-stream 64 (each slower alone -- 70 vs 59 us -- "
+                             "the overlapped step faster: 0.760 vs 0.772 ms)"},
     }
     if world == 1 and not args.no_cpu:
         # the drop-in path north_star describes: the reference's own loop on this module (weights keep training; timing only)
