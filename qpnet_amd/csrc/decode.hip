@@ -849,6 +849,19 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     h->d_xch = nullptr; h->xch_cap = 0; h->single_cu_ok = true;
     h->d_utts = nullptr; h->utts_cap = 0; h->ev0 = h->ev1 = nullptr; h->last_ms = 0; h->pending = false; h->device = -1; h->train = nullptr;
     h->n_cus = 0; h->pipe_rows = 0; h->h_utts_pinned = nullptr; h->h_utts_cap = 0; h->dec_side = nullptr; h->dec_fork = h->dec_join = nullptr;
+    {   // the environment is read HERE, once per handle: no decode or training call looks at it again
+        DecodeKnobs& k = h->dk;
+        k.generic = getenv("QPN_DECODE_GENERIC") != nullptr;
+        k.no_resl = getenv("QPN_DECODE_NO_RESL") != nullptr;
+        k.coop = 0; if (const char* e = getenv("QPN_DECODE_COOP")) k.coop = atoi(e) > 0 ? atoi(e) : 0;
+        k.pipe = 1; if (const char* e = getenv("QPN_DECODE_PIPE")) k.pipe = atoi(e) != 0 ? 1 : 0;
+        k.hybrid = getenv("QPN_DECODE_HYBRID") != nullptr;
+        k.stamps = getenv("QPN_STAMPS") != nullptr;
+        k.test_pipe_gives_up = false;
+#ifdef QPN_TESTING
+        k.test_pipe_gives_up = getenv("QPN_TEST_PIPE_GIVES_UP") != nullptr;
+#endif
+    }
     rc = build_program(h);
     h->decode_ok = rc == QPN_OK;
     if (rc != QPN_OK) h->decode_err = g_err;            // reported by the decode entry points; the training path has its own limits
@@ -939,13 +952,13 @@ static int grow(T** p, size_t* cap, size_t need) {
 // One launch of the one-CU kernels (one 1024-thread workgroup per utterance) over the descriptors p.utts[0 .. n)
 static int launch_one_cu(qpn_handle* h, DecodeParams& p, int n, hipStream_t stream) {
     const Geom& g = h->g;
-    const bool generic = getenv("QPN_DECODE_GENERIC") != nullptr;
+    const bool generic = h->dk.generic;
     const bool fast64 = !generic && g.C == 64 && g.S == 256 && g.Q == 256, fast32 = !generic && g.C == 32 && g.S == 32 && g.Q == 256;
     // the specialised kernel does not use the task table: the residual-1x1 tiles of layers 0..L-2 take its place (and more) when they fit
     const int stamp_floats = p.stamps ? 120 * QPN_NW : 0;
     const int nres_tiles = (g.C * g.C / 1024) * (g.L - 1);
     p.o_wres = (p.o_tasks + 3) & ~3;
-    const bool resl = (fast64 || fast32) && g.L >= 2 && !getenv("QPN_DECODE_NO_RESL") &&
+    const bool resl = (fast64 || fast32) && g.L >= 2 && !h->dk.no_resl &&
                       ((size_t)p.o_wres + (size_t)nres_tiles * 1024 + stamp_floats) * sizeof(float) <= 160 * 1024;
     const int use_floats = resl ? p.o_wres + nres_tiles * 1024 : p.lds_floats;
     p.o_stamp = use_floats;
@@ -965,12 +978,6 @@ static int launch_one_cu(qpn_handle* h, DecodeParams& p, int n, hipStream_t stre
     QPN_HIP(hipGetLastError());
     return QPN_OK;
 }
-
-// measured per-sample times of the two paper-size kernels, used to decide whether the rows beyond one pipelined launch's capacity run
-// beside it on one-CU kernels or as further pipelined launches: 8.3 us pipelined; one-CU rows BESIDE a full pipelined launch 14.8 us
-// for one row, 22.3 us for sixteen (they re-stream their tiles from an L2 the hand-off traffic of 240 busy CUs goes through:
-// profiles/r03_bench_line.json, larger_batches)
-static const double T_PIPE_US = 8.3, T_ONE_US = 14.3, T_ONE_PER_ROW_US = 0.5;
 
 // force_one_cu: the retry of qpn_decode_finish (a multi-workgroup launch gave up) -- one-CU kernels only
 static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t Td,
@@ -1004,8 +1011,7 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     }
     ring_floats = (ring_floats + 63) & ~(size_t)63;
     // several workgroups per utterance when one CU cannot hold the step state (or QPN_DECODE_COOP=<G> asks for it)
-    int coopG = 0;
-    if (const char* e = getenv("QPN_DECODE_COOP")) coopG = atoi(e) > 0 ? atoi(e) : 0;
+    int coopG = h->dk.coop;
     if (!h->single_cu_ok && coopG == 0) coopG = h->n_cus;
     if (force_one_cu && h->single_cu_ok) coopG = 0;
     if (coopG > 0) {
@@ -1019,12 +1025,11 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     std::vector<int> order(B);
     for (int b = 0; b < B; ++b) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return h_n_samples[a] > h_n_samples[b2]; });
-    const char* epipe = getenv("QPN_DECODE_PIPE");
-    const bool pipe_ok = !coopG && !force_one_cu && (epipe ? atoi(epipe) != 0 : true) && qpn_pipe_supported(g) && !getenv("QPN_DECODE_GENERIC") && h->pipe_rows >= 1;
+    const bool pipe_ok = !coopG && !force_one_cu && h->dk.pipe != 0 && qpn_pipe_supported(g) && !h->dk.generic && h->pipe_rows >= 1;
     int n_pipe = 0, n_waves = 0, wave_rows = 0;
     if (pipe_ok) {
         const int cap = h->pipe_rows;                    // five-role groups one launch holds resident
-        const bool hybrid_knob = getenv("QPN_DECODE_HYBRID") != nullptr;      // dev aid: rows beyond `cap` on one-CU kernels beside the launch (round-3 first form)
+        const bool hybrid_knob = h->dk.hybrid;      // dev aid: rows beyond `cap` on one-CU kernels beside the launch (round-3 first form)
         if (B <= cap) { n_pipe = B; n_waves = 1; wave_rows = B; }
         else if (hybrid_knob && B - cap <= h->n_cus - 5 * cap) { n_pipe = cap; n_waves = 1; wave_rows = cap; }
         else {
@@ -1075,7 +1080,7 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
                        h->aux_woff4, h->aux_tiles, h->logRa, g.A, g.Ap, g.C, g.L, h->d_pproj);
     p.wpk = (const float4*)h->d_wpk; p.flat = h->d_flat; p.qb = h->d_qb; p.tasks = h->d_tasks; p.utts = h->d_utts;
     p.status = h->d_status; p.mode = mode; p.seed = seed; p.bias_src = h->d_bias_src;
-    p.stamps = getenv("QPN_STAMPS") ? (long long*)(h->d_status + 16) : nullptr;
+    p.stamps = h->dk.stamps ? (long long*)(h->d_status + 16) : nullptr;
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
     char plan[160];
@@ -1166,7 +1171,7 @@ extern "C" int qpn_decode_finish(qpn_handle* h, void* stream_) {
             float ms2 = 0.f; QPN_HIP(hipEventElapsedTime(&ms2, h->ev0, h->ev1)); h->last_ms += ms2;
         }
     }
-    if (getenv("QPN_STAMPS")) {      // dev aid: stamp times (cycles, relative to the first stamp of wave 0) of step 3000
+    if (h->dk.stamps) {      // dev aid: stamp times (cycles, relative to the first stamp of wave 0) of step 3000
         std::vector<long long> st((size_t)120 * QPN_NW);
         QPN_HIP(hipMemcpy(st.data(), h->d_status + 16, st.size() * sizeof(long long), hipMemcpyDeviceToHost));
         for (int s = 0; s < 40; ++s) {

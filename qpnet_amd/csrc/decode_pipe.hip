@@ -655,13 +655,15 @@ int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, int groups, hi
     }
     pp.xch = h->d_xch + 16; pp.abort = (int*)h->d_xch;
     QPN_HIP(hipMemsetAsync(h->d_xch, 0, xwords * sizeof(unsigned long long), stream));
-    if (getenv("QPN_TEST_PIPE_GIVES_UP")) {
-        // test hook: the launch behaves as if a wait had timed out at once (abort flag raised, status bit 4): exercises the
+#ifdef QPN_TESTING
+    if (h->dk.test_pipe_gives_up) {
+        // test hook (a -DQPN_TESTING build only): the launch behaves as if a wait had timed out at once (abort flag raised, status bit 4): exercises the
         // re-run on the one-CU kernels without needing a CU-masked device (tests/test_decode_gpu.py)
         static const int one = 1, four = 4;
         QPN_HIP(hipMemcpyAsync(h->d_xch, &one, sizeof(int), hipMemcpyHostToDevice, stream));
         QPN_HIP(hipMemcpyAsync(h->d_status, &four, sizeof(int), hipMemcpyHostToDevice, stream));
     }
+#endif
     const size_t lds = pipe_lds_bytes(nu);
     const void* kfn = nu == 1 ? (const void*)k_decode_pipe : nu == 2 ? (const void*)k_decode_pipe_n<2> : (const void*)k_decode_pipe_n<3>;
     QPN_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    // per device: set at every launch

@@ -6,9 +6,21 @@ struct BiasDesc { int64_t auxb[2], convb[2], convPb[2]; int adaptive; int pad; }
 struct TrainState;
 void qpn_train_destroy(TrainState* t);
 
+// decode launch-plan knobs, parsed once in qpn_create (all optional; tests / tools build a fresh handle per setting)
+struct DecodeKnobs {
+    bool generic;          // QPN_DECODE_GENERIC: the interpreter kernel k_decode instead of the straight-line k_decode_fast
+    bool no_resl;          // QPN_DECODE_NO_RESL: no LDS-resident residual tiles in the one-CU kernel
+    int coop;              // QPN_DECODE_COOP=<G>: cooperative decode with up to G workgroups per utterance (0: only where one CU cannot hold the state)
+    int pipe;              // QPN_DECODE_PIPE: 0 = one-CU kernels, 1 / unset = the five-role pipelined kernel where it applies
+    bool hybrid;           // QPN_DECODE_HYBRID (dev): rows beyond the pipelined capacity on one-CU kernels beside the launch
+    bool stamps;           // QPN_STAMPS (dev, -DQPN_ENABLE_STAMPS builds)
+    bool test_pipe_gives_up;   // -DQPN_TESTING builds only (QPN_TEST_PIPE_GIVES_UP=1)
+};
+
 struct qpn_handle {
     Geom g;
     int device;
+    DecodeKnobs dk;
     // decode program
     std::vector<int> h_map;          // gather map of the packed tile buffer
     std::vector<Task> h_tasks;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm2<MT, QPN_PD2P>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
+            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.p2t_f4, NTS, nts, Q, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm2<MT, QPN_PD2P>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
+            wave_gemm<MT, 2>(acc, R, ldr, p.wp + p.p1t_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void k_post_bwd(TrainParams p, TrainBwd bw) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm2<MT, QPN_PD2P>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
+            wave_gemm<MT, 2>(acc, P, ldp, p.wp + p.wst_f4, NTL, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j && nt1 == nt0) break;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
     const int C = p.C, Ktp = p.Ktp, Ap = p.Ap;
     const int ldx = tr_lda(C), ldz = tr_lda(2 * C);
     float* Dx = sm; float* Dz = sm + TM * ldx;
-    const int b = blockIdx.y, n0 = ly.s_out + ((pp >> 4) + tr_xcd_tile(blockIdx.x, gridDim.x, pp & 1)) * TM;      // pp: bit 0 XCD swizzle, bits 4.. first tile
+    const int b = blockIdx.y, n0 = ly.s_out + tr_xcd_tile(blockIdx.x, gridDim.x, pp & 1) * TM;      // pp: bit 0 XCD swizzle
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t rb = (size_t)b * p.N1;
     const size_t nDX = (size_t)p.B * p.N1 * C;     // grads wrt X[j] live at DXA/DXB[0] + j*nDX
@@ -384,15 +384,9 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
 // gradient (+ residual path), the pitch-tap part as one 256-byte row per tap row -- a plain store for the fixed blocks (unique
 // writer), ONE full-row float-atomic instruction per row for the adaptive blocks (the accumulator layout gave 64-byte strips
 // of four different rows per instruction) -- and the aux columns as row-contiguous atomics.
-// dev aid (build with -DQPN_ENABLE_STAMPS, run with QPN_BWDP_STAMPS=1): s_memtime of wave 0 at the phase boundaries of a few workgroups
-#ifdef QPN_ENABLE_STAMPS
-#define BWDP_STAMP(i) do { if (stamps && lane == 0 && wave == 0 && (blockIdx.x & 63) == 5 && (i) < 64) stamps[(blockIdx.x >> 6) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define BWDP_STAMP(i) do { } while (0)
-#endif
 template <int NTK, bool LAST>      // NTK = Ktp / 16 column tiles of the input gradient (11 for n_resch 64, n_aux 39)
-__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles, float* dummy, long long* stamps) {     // flags: bit 1 XCD swizzle
-    constexpr int C = 64, C4 = C / 4;
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd bw, int l, int flags, int tiles, float* dummy) {     // flags: bit 1 XCD swizzle
+    constexpr int C = 64;
     constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     constexpr int NJ = (NTK + 3) / 4;                              // column tiles of the second contraction per wave
     extern __shared__ float sm[];
@@ -464,20 +458,16 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * wave + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
     };
-    BWDP_STAMP(0);
     load_rows(t_first);
     load_taps(t_first, tprow);
     store_rows(t_first, sm);
-    BWDP_STAMP(1);
     const int arow = lane & 15, ak = lane >> 4;
     const int c = 16 * wave + (lane & 15);
     for (int ti = 0; ti < t_count; ++ti) {
         const int t = t_first + ti, n0 = ly.s_out + t * 16;
         float* Dx = sm + (ti & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
         { const int tn = t + 1 < t_last ? t + 1 : t_last; load_rows(tn); load_taps(tn, tpnext); }      // (past the range: a harmless reload)
-        BWDP_STAMP(2 + 8 * ti);
         TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz / Os free (readers: previous trip)
-        BWDP_STAMP(3 + 8 * ti);
         // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
         float xa[4][4];
 #pragma unroll
@@ -501,9 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
             Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
             Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
         }
-        BWDP_STAMP(4 + 8 * ti);
         TR_LDS_BARRIER();
-        BWDP_STAMP(5 + 8 * ti);
         // ---- d[x_cur | x_past | aux] = dZ . W1
         float za[8][4];
 #pragma unroll
@@ -539,9 +527,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
             for (int i = 0; i < 4; ++i) Os[(size_t)(4 * (lane >> 4) + i) * ldo + 16 * nt + (lane & 15)] = acc[j][i];
         }
-        BWDP_STAMP(6 + 8 * ti);
         TR_LDS_BARRIER();
-        BWDP_STAMP(7 + 8 * ti);
         // ---- outputs as whole rows: wave w owns rows 4w .. 4w+3, lane = channel
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -560,9 +546,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
                 atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);               // unique writer per layer, layers in order
             }
         }
-        BWDP_STAMP(8 + 8 * ti);
         store_rows(t + 1 < t_last ? t + 1 : t_last, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
-        BWDP_STAMP(9 + 8 * ti);
 #pragma unroll
         for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
     }
@@ -588,7 +572,6 @@ struct Wg2 {
     int row0A[TR_MAXL], row0B[TR_MAXL], R[TR_MAXL];                         // window per layer
     int goff[TR_MAXL], gbias[TR_MAXL], tap_off[TR_MAXL], dil[TR_MAXL];
     int ldc, ncol_groups;                                                   // post: N split into column groups (blockIdx.z)
-    long long* stamps;                                                      // dev aid (QPN_ENABLE_STAMPS builds, QPN_WGRAD_STAMPS=<bmode>)
 };
 
 struct Wg2L {            // per-workgroup scalars hoisted out of the kernel-argument arrays
@@ -826,21 +809,11 @@ __device__ __forceinline__ void up_bwd_body(const UpArgs& p, int fx, int b, int 
     if (tid == 0) { float a = 0.f; for (int k = 0; k < nthr / 64; ++k) a += red[k]; atomicAdd(&p.gflat[p.up_b], a * p.gscale); }
 }
 
-// dev aid: s_memtime of thread 0 at the phase boundaries of four sampled workgroups (build -DQPN_ENABLE_STAMPS, run QPN_WGRAD_STAMPS=<bmode>)
-#ifdef QPN_ENABLE_STAMPS
-#define WG_STAMP(i) do { if (w.stamps && threadIdx.x == 0 && y == (w.nlayers > 3 ? 3 : 0) && zg == 0 && (ch & 15) == 5 && (i) < 128) \
-    w.stamps[(ch >> 4) * 128 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define WG_STAMP(i) do { } while (0)
-#endif
-// DB: 16-row stages in TWO LDS buffers (same footprint as one 32-row stage) and ONE LDS-only barrier per stage: stage s+1 goes from the
-// staging registers into the other buffer and stage s+2's rows are requested between the k-steps of stage s, so the staging instructions
-// issue in the shadow of the stage's own MFMAs instead of between two barriers with the matrix cores idle.
 // (ch, y, zg) = (time chunk, layer, column group) of this workgroup: blockIdx of the one-contraction launches, decoded from a flat index in k_wgrad_tail
-template <int BMODE, int MPW, int NT, bool TWO_A, bool DB>
+template <int BMODE, int MPW, int NT, bool TWO_A>
 __device__ __forceinline__ void wgrad3_body(const Wg2& w, const int nch, const int ch, const int y, const int zg) {
     extern __shared__ float sm[];
-    constexpr int RS = DB ? 16 : 32, Mp = 64 * MPW, Np = 16 * NT;
+    constexpr int RS = 32, Mp = 64 * MPW, Np = 16 * NT;
     constexpr int ldA = ((Mp + 15) / 32) * 32 + 16, ldB = ((Np + 15) / 32) * 32 + 16;       // tr_ldt
     constexpr int A4 = Mp / 4, ARS = 256 / A4, NA = RS / ARS;                               // A: every thread active, NA full passes
     constexpr int B4 = Np / 4, BRS = 256 / B4, NB = (RS + BRS - 1) / BRS;                   // B: threads < BRS*B4 active
@@ -988,7 +961,6 @@ __device__ __forceinline__ void wgrad3_body(const Wg2& w, const int nch, const i
         if (BMODE == 3 && rbeg + RS < rend) taps(rbeg + RS);
     }
     const int g = lane >> 4, cl = lane & 15;
-    WG_STAMP(0);
     // staging registers -> LDS buffer `buf`
     auto to_lds = [&](int buf) {
         float* Ab = As + buf * BUF; float* Bb = Bs + buf * BUF;
@@ -1031,53 +1003,17 @@ __device__ __forceinline__ void wgrad3_body(const Wg2& w, const int nch, const i
             }
         }
     };
-    if (DB) {
-        if (rbeg < rend) {
-            to_lds(0);
-            if (rbeg + RS < rend) {
-                fetch(rbeg + RS);
-                if (BMODE == 3 && rbeg + 2 * RS < rend) taps(rbeg + 2 * RS);
-            }
-            TR_LDS_BARRIER();
-        }
-        int buf = 0;
-        for (int rs = rbeg; rs < rend; rs += RS, buf ^= 1) {
-            WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
-            ksteps(buf, 0, 1);
-            WG_STAMP(2 + 6 * ((rs - rbeg) / RS));
-            if (rs + RS < rend) {
-                to_lds(buf ^ 1);                                                // (requested a whole stage ago)
-                WG_STAMP(3 + 6 * ((rs - rbeg) / RS));
-                if (rs + 2 * RS < rend) {
-                    fetch(rs + 2 * RS);
-                    if (BMODE == 3 && rs + 3 * RS < rend) taps(rs + 3 * RS);
-                }
-            }
-            WG_STAMP(4 + 6 * ((rs - rbeg) / RS));
-            ksteps(buf, 1, RS / 4);
-            WG_STAMP(5 + 6 * ((rs - rbeg) / RS));
-            TR_LDS_BARRIER();
-            WG_STAMP(6 + 6 * ((rs - rbeg) / RS));
-        }
-    } else
     for (int rs = rbeg; rs < rend; rs += RS) {
-        WG_STAMP(1 + 6 * ((rs - rbeg) / RS));
         to_lds(0);
-        WG_STAMP(2 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
-        WG_STAMP(3 + 6 * ((rs - rbeg) / RS));
         // next stage's rows fly while the matrix cores work on this one
         if (rs + RS < rend) {
             fetch(rs + RS);
             if (BMODE == 3 && rs + 2 * RS < rend) taps(rs + 2 * RS);       // gather rows of the stage after next
         }
-        WG_STAMP(4 + 6 * ((rs - rbeg) / RS));
         ksteps(0, 0, RS / 4);
-        WG_STAMP(5 + 6 * ((rs - rbeg) / RS));
         __syncthreads();
-        WG_STAMP(6 + 6 * ((rs - rbeg) / RS));
     }
-    WG_STAMP(120);
     float* out = w.slab + (size_t)ch * w.gstage;
 #pragma unroll
     for (int mi = 0; mi < MPW; ++mi) {
@@ -1091,16 +1027,15 @@ __device__ __forceinline__ void wgrad3_body(const Wg2& w, const int nch, const i
             }
         }
     }
-    WG_STAMP(121);
     if (gbias >= 0) {          // bias grads: column sums of A, reduced over the ARS row groups of the staging layout
         *(float4*)(sm + (size_t)a_row0 * Mp + a_col) = cs4;
         __syncthreads();
         if (tid < Mp) { float s = 0.f; for (int r = 0; r < ARS; ++r) s += sm[r * Mp + tid]; out[gbias + tid] = s; }
     }
 }
-template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1, bool DB = false>
+template <int BMODE, int MPW, int NT, bool TWO_A, int MINW = 1>
 __global__ __launch_bounds__(256, MINW) void k_wgrad3(Wg2 w, int nch) {          // MINW: waves per SIMD the register allocation must allow
-    wgrad3_body<BMODE, MPW, NT, TWO_A, DB>(w, nch, blockIdx.x, blockIdx.y, blockIdx.z);
+    wgrad3_body<BMODE, MPW, NT, TWO_A>(w, nch, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 #ifndef QPN_WGRAD_MINW
@@ -1111,14 +1046,8 @@ static void launch_wgrad3_k(const Wg2& w, int nch, size_t lds, hipStream_t strea
     // the 256 x 64 one-array launches (post-net pair, skip 1x1) are 512 workgroups = two per CU: the allocation may use half a SIMD's registers
     // (round 2 asked for a third of it -- three workgroups per CU; with the staging addresses hoisted that cap spills 80-150 B per lane)
     constexpr int MINW = (MPW == 4 && NT == 4 && !TWO_A) ? QPN_WGRAD_MINW : 1;
-    const int db = getenv("QPN_WGRAD_DB") ? atoi(getenv("QPN_WGRAD_DB")) : 0;                // bit mask by BMODE (dev knob; read per call: the tests flip it)
-    constexpr bool DB_OK = MPW * NT >= 16;         // (a 64 x 64 block has 4 MFMAs per k-step: nothing to hide the staging under)
-    if (lds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, DB_OK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (DB_OK && (db >> BMODE & 1)) hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, DB_OK>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
-    else hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW, false>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_wgrad3<BMODE, MPW, NT, TWO_A, MINW>), dim3(nch, w.nlayers, w.ncol_groups), dim3(256), lds, stream, w, nch);
 }
 template <int BMODE, int MPW, int NT>
 static bool wgrad3_fits(const Wg2& w) {
@@ -1139,34 +1068,9 @@ static bool launch_wgrad3(const Wg2& w, int nch, hipStream_t stream) {
     else launch_wgrad3_k<BMODE, MPW, NT, false>(w, nch, lds, stream);
     return true;
 }
-static bool wgrad3_any_(const Wg2& w, int nch, hipStream_t stream);
-static bool wgrad3_any(const Wg2& w0, int nch, hipStream_t stream) {
-#ifdef QPN_ENABLE_STAMPS
-    const char* e = getenv("QPN_WGRAD_STAMPS");
-    if (e && atoi(e) == w0.bmode && w0.M == (getenv("QPN_WGRAD_STAMPS_M") ? atoi(getenv("QPN_WGRAD_STAMPS_M")) : w0.M)) {
-        static long long* d = nullptr; static int calls = 0;
-        if (!d) (void)hipMalloc(&d, 4 * 128 * sizeof(long long));
-        (void)hipMemsetAsync(d, 0, 4 * 128 * sizeof(long long), stream);
-        Wg2 w = w0; w.stamps = d;
-        const bool ok = wgrad3_any_(w, nch, stream);
-        if (++calls == 8) {
-            long long h[4 * 128];
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-            for (int g = 0; g < 4; ++g) {
-                fprintf(stderr, "wgrad stamps bmode %d M %d wg %d: start 0", w0.bmode, w0.M, 16 * g + 5);
-                for (int i = 1; i < 128; ++i) if (h[g * 128 + i]) fprintf(stderr, " [%d]%lld", i, h[g * 128 + i] - h[g * 128]);
-                fprintf(stderr, "\n");
-            }
-        }
-        return ok;
-    }
-#endif
-    return wgrad3_any_(w0, nch, stream);
-}
-static bool wgrad3_any_(const Wg2& w, int nch, hipStream_t stream) {
+static bool wgrad3_any(const Wg2& w, int nch, bool generic, hipStream_t stream) {
     if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream) || launch_wgrad3<4, 1, 4>(w, nch, stream);      // causal table: C = 64, 128- or 64-class groups
-    if (getenv("QPN_WGRAD_GENERIC")) return false;
+    if (generic) return false;
     switch (w.bmode) {
     case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 / 32, n_aux 33..48
     case 2: return launch_wgrad3<2, 1, 4>(w, nch, stream) || launch_wgrad3<2, 4, 4>(w, nch, stream);       // res / skip 1x1 at C = 64
@@ -1183,8 +1087,8 @@ static int wgrad_col_groups(int M, int N) {
     return 1;
 }
 
-static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
-    if (wgrad3_any(w, nch, stream)) return true;
+static bool wgrad2_any(const Wg2& w, int nch, bool generic, hipStream_t stream) {
+    if (wgrad3_any(w, nch, generic, stream)) return true;
     switch (w.bmode) {
     case 4: return false;                       // one-hot operand: k_wgrad3 only (the launcher checks the geometry first)
     case 1: return wgrad2_mode<1>(w, nch, stream);
@@ -1195,19 +1099,8 @@ static bool wgrad2_any(const Wg2& w, int nch, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------ small backward kernels
-__global__ void k_reduce_grad(const float* __restrict__ slab, const int* __restrict__ gsrc, int nch, int gstage, int64_t n, float* __restrict__ g,
-                              float scale, int append_scale) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (append_scale && i >= n && i < n + 4) { g[i] = i == n ? scale : 0.f; return; }
-    if (i >= n) return;
-    const int s = gsrc[i];
-    float a = 0.f;
-    if (s >= 0) for (int c = 0; c < nch; ++c) a += slab[(size_t)c * gstage + s];
-    g[i] = a * scale;
-}
-
-// The same reduction walked in SLAB order: a wave reads 64 consecutive floats of each partial slab (the flat order is a
-// permutation of it -- transposed blocks, interleaved taps -- so the gather above touches scattered 4-byte words of 64 slabs),
+// Slabs -> flat gradient, walked in SLAB order: a wave reads 64 consecutive floats of each partial slab (the flat order is a
+// permutation of it -- transposed blocks, interleaved taps -- so a gather in flat order touches scattered 4-byte words of 64 slabs),
 // and the sum goes to the parameter(s) it feeds; entries nothing feeds are zeroed, the trailer appended.
 // [s0, s1): the slab elements this launch reduces (the early range runs on the side stream under the layer backward); `tail`: this launch
 // also zeroes the unfed entries and appends the trailer
@@ -1327,8 +1220,6 @@ __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
     zero_dx_slice(p, bw, blockIdx.y, blockIdx.z, blockIdx.x, gridDim.x, threadIdx.x, blockDim.x);
 }
 
-void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
-
 // ------------------------------------------------------------------------------------------ launchers
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     hipLaunchKernelGGL(k_zero_dx, dim3(64, p.L, p.B), dim3(256), 0, stream, p, bw);
@@ -1340,9 +1231,10 @@ void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t st
 // tail: this launch also zeroes the entries no slab feeds and appends the trailer (then the final reduction must not: the upsampling
 // kernel's gradient is added onto those zeros in between, see qpn_launch_bwd)
 static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail, int nch_side) {
-    const int64_t n = (int64_t)(bw.g_early1 - bw.g_early0) + (tail ? bw.n_gzero + 4 : 0);
+    const TrainSlabs& sl = *bw.sl;
+    const int64_t n = (int64_t)(sl.g_early1 - sl.g_early0) + (tail ? bw.n_gzero + 4 : 0);
     hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                       nch_side, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, bw.g_early0, bw.g_early1, 0, 0, tail);
+                       nch_side, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, sl.g_early0, sl.g_early1, 0, 0, tail);
 }
 static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t st) {
     const UpArgs u = up_args(p, bw);
@@ -1353,18 +1245,16 @@ static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t 
 // upsampling kernel's gradient
 int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done) {
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
-    if (bw.gdst && !getenv("QPN_REDUCE_FLAT_ORDER"))
-        hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + (up_done ? 0 : bw.n_gzero + 4) + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                           bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? bw.g_early0 : 0, early_done ? bw.g_early1 : 0, up_done ? 0 : 1);
-    else
-    hipLaunchKernelGGL(k_reduce_grad, dim3((unsigned)((bw.n_params + 4 + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gsrc, bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale);
+    const TrainSlabs& sl = *bw.sl;
+    hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + (up_done ? 0 : bw.n_gzero + 4) + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
+                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? sl.g_early0 : 0, early_done ? sl.g_early1 : 0, up_done ? 0 : 1);
     {
         const int64_t total = (int64_t)B * N1;
         const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
         const int CB = C < 64 ? C : 64;
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        if (bw.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
+        if (sl.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
         if (p.U > 0 && !up_done) launch_up_bwd(p, bw, stream);
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
@@ -1373,43 +1263,40 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
 }
 
 bool qpn_stack_bwd_fits(const TrainParams& p);
-int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, hipStream_t stream);
+int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, const StackQ* sq, hipStream_t stream) {
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
+    const TrainSlabs& sl = *bw.sl;
     const size_t nDX = (size_t)B * N1 * C;
-    constexpr int MT = TR_MT, TM = 16 * MT;
-    const size_t lds_post = (size_t)TM * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
-    const size_t lds_layer = (size_t)TM * (4 * tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
+    // 16-row tiles (measured 11-15 % faster than 32 rows: twice the workgroups, a shorter last round)
+    const size_t lds_post = (size_t)16 * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
+    const size_t lds_layer = (size_t)16 * (4 * tr_lda(C) + tr_lda(2 * C)) * sizeof(float);
     if (lds_post > 160 * 1024 || lds_layer > 160 * 1024) { qpn_set_error("backward tiles do not fit LDS"); return QPN_EINVAL; }
-    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
-    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_bwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
-    const bool overlap = side && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL");
-    const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
-    const bool zero_in_post = post_wide && !(getenv("QPN_ZERO_IN_POST") && atoi(getenv("QPN_ZERO_IN_POST")) == 0);
+    const bool overlap = side && !qpn_prof_active() && !k.serial;
+    const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && k.post_wide;
+    const bool zero_in_post = post_wide && k.zero_in_post;
     if (!zero_in_post) qpn_launch_zero_dx(p, bw, stream);
     if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
         constexpr int MTW = 5;
         const size_t ldsw = (size_t)16 * MTW * tr_lda(256) * sizeof(float);
         QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
         hipLaunchKernelGGL((k_post_bwd_w<MTW>), dim3((BL + 16 * MTW - 1) / (16 * MTW), B), dim3(512), ldsw, stream, p, bw, zero_in_post ? 1 : 0);
-    } else if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
-        const size_t lds1 = lds_post / MT;
-        if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipLaunchKernelGGL((k_post_bwd<1>), dim3((BL + 15) / 16, B), dim3(512), lds1, stream, p, bw);
-    } else
-    hipLaunchKernelGGL((k_post_bwd<MT>), dim3((BL + TM - 1) / TM, B), dim3(512), lds_post, stream, p, bw);
+    } else {
+        if (lds_post > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post);
+        hipLaunchKernelGGL((k_post_bwd<1>), dim3((BL + 15) / 16, B), dim3(512), lds_post, stream, p, bw);
+    }
     qpn_prof_mark(PG_POST_BWD, stream);
     // ---- the skip 1x1 and post-net weight gradients only need what k_post_bwd has just produced (dS0, dY0, dlogits) and
-    // saved activations: they run on a side stream UNDER the eight layer-backward launches (+2.5 % steps/s; the layer
-    // kernels are latency-bound but their workgroups still occupy every CU, so the overlap is partial).  Per-group
-    // profiling (bench roofline) and QPN_TRAIN_SERIAL=1 keep everything on the one stream.  [Per-layer dW1/dWr launches
-    // on a second side stream were tried too: 64 workgroups per launch are too few, 680 steps/s.]
+    // saved activations: they run on a side stream UNDER the layer backward (the layer kernels are latency-bound but their
+    // workgroups still occupy every CU, so the overlap is partial).  Per-group profiling (bench roofline) and QPN_TRAIN_SERIAL=1
+    // keep everything on the one stream.
     const int nch = bw.nch;
     int nch_side_ = nch;      // time chunks (= partial slabs) of the skip / post-net contractions, which run on the side stream under the layer backward and are reduced by a launch of their own
+    const bool gen = k.wgrad_generic;
     Wg2 wbase; memset(&wbase, 0, sizeof(wbase));
     wbase.slab = bw.slab; wbase.gstage = bw.gstage; wbase.nb = B; wbase.C = C; wbase.Ap = p.Ap; wbase.hup = p.HUP; wbase.tap = p.TAP; wbase.ncol_groups = 1;
     bool ok = true;
@@ -1420,198 +1307,122 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* s
             w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
             w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
             w.ncol_groups = wgrad_col_groups(w.M, w.N);
-            for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = bw.g_ws[l]; w.gbias[l] = l == 0 ? bw.g_bs : -1; w.tap_off[l] = -1; }
-            ok = ok && wgrad2_any(w, nch_side_, st);
+            for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = sl.g_ws[l]; w.gbias[l] = l == 0 ? sl.g_bs : -1; w.tap_off[l] = -1; }
+            ok = ok && wgrad2_any(w, nch_side_, gen, st);
         }
         {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
             w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
             w.row0A[0] = w.row0B[0] = 0; w.R[0] = BL; w.tap_off[0] = -1;
             w.ncol_groups = S % 64 == 0 ? S / 64 : 1;
-            if (getenv("QPN_POST_WGRAD_GEMM") && Q % 32 == 0 && S % 32 == 0) {
-                // the 128 x 128 x 32 LDS-tiled time contraction of train_gemm.hip on the two 256-row outputs: measured 34 us SLOWER per
-                // step than the tile kernel at paper size (64 partial slabs leave each workgroup 10 K-chunks); kept as a knob
-                qpn_launch_post_wgrad_gemm(p, bw, st);
-            } else {
-            w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = bw.g_p2; w.gbias[0] = bw.g_bp2;
-            if (Q == S && !(getenv("QPN_POST_WGRAD_PAIR") && atoi(getenv("QPN_POST_WGRAD_PAIR")) == 0)) {
+            w.A = bw.dlogits; w.lda = Q; w.M = Q; w.B1 = p.Y0; w.ldb = S; w.N = S; w.Nvalid = S; w.ldc = S; w.goff[0] = sl.g_p2; w.gbias[0] = sl.g_bp2;
+            if (Q == S && k.post_pair) {
                 // both contractions have the same shape: ONE launch with the second as "layer 1" (strides = the distance between the arrays,
                 // modulo 2^64), 2 x 256 workgroups = two per CU, so one's staging runs under the other's MFMAs (alone, each launch put one
                 // workgroup on a CU: 35 % of every stage with the matrix cores idle, in-kernel stamps)
                 w.nlayers = 2;
                 w.A_lstride = (size_t)(bw.DY0 - bw.dlogits); w.B_lstride = (size_t)(p.S0 - p.Y0);
-                w.row0A[1] = w.row0B[1] = 0; w.R[1] = BL; w.tap_off[1] = -1; w.goff[1] = bw.g_p1; w.gbias[1] = bw.g_bp1;
-                ok = ok && wgrad2_any(w, nch_side_, st);
+                w.row0A[1] = w.row0B[1] = 0; w.R[1] = BL; w.tap_off[1] = -1; w.goff[1] = sl.g_p1; w.gbias[1] = sl.g_bp1;
+                ok = ok && wgrad2_any(w, nch_side_, gen, st);
             } else {
-            ok = ok && wgrad2_any(w, nch_side_, st);
-            w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = bw.g_p1; w.gbias[0] = bw.g_bp1;
-            ok = ok && wgrad2_any(w, nch_side_, st);
-            }
+                ok = ok && wgrad2_any(w, nch_side_, gen, st);
+                w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = sl.g_p1; w.gbias[0] = sl.g_bp1;
+                ok = ok && wgrad2_any(w, nch_side_, gen, st);
             }
         }
-    };
-    // layers [lo, hi) of a per-layer weight-gradient launch (blockIdx.y counts from lo)
-    auto subset = [&](Wg2 w, int lo, int hi) {
-        w.A += (size_t)lo * w.A_lstride; if (w.A2) w.A2 += (size_t)lo * w.A_lstride;
-        w.B1 += (size_t)lo * w.B_lstride; if (w.B2) w.B2 += (size_t)lo * w.B_lstride;
-        for (int i = 0; i + lo < hi; ++i) {
-            w.row0A[i] = w.row0A[lo + i]; w.row0B[i] = w.row0B[lo + i]; w.R[i] = w.R[lo + i]; w.goff[i] = w.goff[lo + i];
-            w.gbias[i] = w.gbias[lo + i]; w.tap_off[i] = w.tap_off[lo + i]; w.dil[i] = w.dil[lo + i];
-        }
-        w.nlayers = hi - lo;
-        return w;
     };
     // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
     auto build_w1 = [&]() {     // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
         Wg2 w = wbase;
-            w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
-            w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
-            w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
-            for (int l = 0; l < L; ++l) {
-                const TrLayer& ly = p.layers[l];
-                w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = bw.g_w1[l]; w.gbias[l] = bw.g_b1[l];
-                w.tap_off[l] = ly.tap_off; w.dil[l] = ly.dilation;
-            }
+        w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
+        w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
+        w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
+        for (int l = 0; l < L; ++l) {
+            const TrLayer& ly = p.layers[l];
+            w.row0A[l] = w.row0B[l] = ly.s_out; w.R[l] = N1 - ly.s_out; w.goff[l] = sl.g_w1[l]; w.gbias[l] = sl.g_b1[l];
+            w.tap_off[l] = ly.tap_off; w.dil[l] = ly.dilation;
+        }
         return w;
     };
     auto build_wr = [&]() {     // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
         Wg2 w = wbase;
-            w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
-            w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
-            w.nlayers = L; w.ncol_groups = wgrad_col_groups(w.M, w.N);
-            for (int l = 0; l < L; ++l) {
-                w.row0A[l] = w.row0B[l] = p.layers[l].s_out;
-                w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = bw.g_wr[l]; w.gbias[l] = bw.g_br[l]; w.tap_off[l] = -1; w.dil[l] = 0;
-            }
+        w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
+        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+        w.nlayers = L; w.ncol_groups = wgrad_col_groups(w.M, w.N);
+        for (int l = 0; l < L; ++l) {
+            w.row0A[l] = w.row0B[l] = p.layers[l].s_out;
+            w.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out; w.goff[l] = sl.g_wr[l]; w.gbias[l] = sl.g_br[l]; w.tap_off[l] = -1; w.dil[l] = 0;
+        }
         return w;
-    };
-    auto launch_w1_wr = [&](int lo, int hi, hipStream_t st, int which = 3) {      // which: bit 0 dW1, bit 1 dWr
-        if (lo >= hi) return;
-        if (which & 1) ok = ok && wgrad2_any(subset(build_w1(), lo, hi), nch, st);
-        if (which & 2) ok = ok && wgrad2_any(subset(build_wr(), lo, hi), nch, st);
     };
     // the memory-bound reduction of the skip / post-net slabs (half of k_reduce_grad's 130 MB) runs on the side stream under the
     // matrix-bound layer backward instead of at the end of the step
-    const bool early_reduce = overlap && bw.gdst && bw.g_early1 > bw.g_early0 && !getenv("QPN_REDUCE_FLAT_ORDER") && !(getenv("QPN_REDUCE_EARLY") && atoi(getenv("QPN_REDUCE_EARLY")) == 0);
-    // the side stream carries, under the layer backward: the skip / post-net weight gradients (ready after k_post_bwd) and, once the
-    // upper half of the stack has been differentiated, that half's dW1 / dWr (QPN_WGRAD_SPLIT = first layer of that half; L = none)
+    const bool early_reduce = overlap && bw.gdst && sl.g_early1 > sl.g_early0 && k.reduce_early;
     // with the early reduction doing the zeroing / trailer too, the upsampling kernel's gradient (atomics onto those zeros, needs dH of every
     // layer) runs on the side stream next to dW1 instead of behind the final reduction
-    const bool up_side = early_reduce && p.U > 0 && !(getenv("QPN_UP_SIDE") && atoi(getenv("QPN_UP_SIDE")) == 0);
-    int mid = L;                       // measured: 975 steps/s with or without the split (the layer kernels already fill the chip)
-    if (const char* e = getenv("QPN_WGRAD_SPLIT")) { const int v = atoi(e); if (v >= 0 && v <= L) mid = v; }
-    if (!overlap) mid = L;
+    const bool up_side = early_reduce && p.U > 0 && k.up_side;
     // (only with the early reduction: otherwise ONE launch reduces every block with one slab count)
     if (early_reduce) {
-        nch_side_ = nch <= 48 ? nch : 48;       // measured on the overlapped step: 64 -> 48 chunks makes each of these launches slower alone and the step faster
-        if (const char* e = getenv("QPN_WGRAD_CHUNKS_SIDE")) { const int v = atoi(e); if (v >= 1 && v <= nch) nch_side_ = v; }
+        // measured on the overlapped step: 64 -> 48 chunks makes each of these launches slower alone and the step faster
+        nch_side_ = k.wgrad_chunks_side > 0 && k.wgrad_chunks_side <= nch ? k.wgrad_chunks_side : (nch <= 48 ? nch : 48);
     }
-    // experiment (QPN_REDUCE_LATE_SIDE=1): the memory-bound early reduction next to the matrix-bound dW1 instead of next to the latency-bound layer backward
-    const bool reduce_late = early_reduce && getenv("QPN_REDUCE_LATE_SIDE") && atoi(getenv("QPN_REDUCE_LATE_SIDE")) == 1;
     if (overlap) {
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
         launch_skip_post(side);
-        if (early_reduce && !reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
+        if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
         // the post-net block of the flat gradient (and, with up_side, the zeroing and the row-count trailer behind it) is final from here on:
         // a data-parallel caller exchanges that bucket while the layer backward still runs (qpn_train_early_bucket)
-        if (early_reduce && !reduce_late && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
+        if (early_reduce && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
     }
-    // two-part time split of the layer backward (see qpn_launch_fwd): the LATER part runs first here -- its chain needs nothing from
-    // the earlier rows -- on the main stream; the earlier part of layer l follows on the split stream once the later part of
-    // layer l+1 (whose pitch-tap scatter reaches back across the cut) is done
-    const bool lbmt1 = !getenv("QPN_LAYER_BWD_MT") || atoi(getenv("QPN_LAYER_BWD_MT")) == 1;
-    const bool split = sp && lbmt1 && L >= 2 && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL") &&
-                       (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) && getenv("QPN_TRAIN_SPLIT_BWD") && N1 - p.layers[L - 1].s_out >= 4096;
-    const int cut_row = split ? tr_split_cut(p) : 0;
-    const int swz = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 1;
-    if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
+    const int swz = k.xcd_swizzle ? 1 : 0;
     const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
-    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && off32 && !split && !(getenv("QPN_LAYER_BWD_PERSIST") && atoi(getenv("QPN_LAYER_BWD_PERSIST")) == 0);
-    const int wg_per_cu = getenv("QPN_LAYER_BWD_WGS") ? atoi(getenv("QPN_LAYER_BWD_WGS")) : 2;
+    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && off32 && k.persist_bwd;
     // the whole stack's backward as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE_BWD=0 (or
     // QPN_STACK_QUEUE=0) keeps a launch per layer
-    const bool stack_q = persist && sq && sq->flags && p.qctl && mid == L && qpn_stack_bwd_fits(p) && !getenv("QPN_BWDP_STAMPS");
-    if (stack_q) { const int rcq = qpn_launch_stack_bwd(p, bw, *sq, stream); if (rcq) return rcq; }
+    const bool stack_q = persist && k.stack_q_bwd && sq && sq->flags && p.qctl && qpn_stack_bwd_fits(p);
+    if (stack_q) { const int rcq = qpn_launch_stack_bwd(p, bw, *sq, k, stream); if (rcq) return rcq; }
     for (int l = L - 1; l >= 0 && !stack_q; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;
+        const int tiles = (rows + 15) / 16;
         if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)
-            const int tiles = (rows + 15) / 16;
-            int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+            int G = qpn_num_cus() * 2; if (G > tiles) G = tiles;
             if (G > 1024) G = 1024;                                // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
             const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(176)) * sizeof(float);
             (void)hipFuncSetAttribute(l == L - 1 ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-            long long* d_st = nullptr;
-#ifdef QPN_ENABLE_STAMPS
-            static long long* d_stamps = nullptr;
-            if (getenv("QPN_BWDP_STAMPS")) { if (!d_stamps) (void)hipMalloc(&d_stamps, 16 * 64 * sizeof(long long)); (void)hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream); d_st = d_stamps; }
-#endif
-            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows, d_st);
-            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows, d_st);
-#ifdef QPN_ENABLE_STAMPS
-            if (d_st && l == atoi(getenv("QPN_BWDP_STAMPS"))) {      // print one layer's launch (cycles relative to the first stamp of each sampled workgroup)
-                static int printed = 0;
-                long long hs[16 * 64];
-                (void)hipStreamSynchronize(stream);
-                (void)hipMemcpy(hs, d_st, sizeof(hs), hipMemcpyDeviceToHost);
-                if (printed++ == 8) for (int w = 0; w < 8; ++w) {
-                    fprintf(stderr, "bwdp stamps layer %d wg %d:", l, 64 * w + 5);
-                    for (int i = 0; i < 34; ++i) fprintf(stderr, " %lld", hs[w * 64 + i] ? hs[w * 64 + i] - hs[w * 64] : -1LL);
-                    fprintf(stderr, "\n");
-                }
-            }
-#endif
-        } else if (lbmt1) {      // 16-row tiles measured 11 % faster than 32
-            const size_t lds1 = lds_layer / MT;
-            if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-            const int tiles = (rows + 15) / 16, lastf = l == L - 1 ? 1 : 0;
-            const int t0 = split ? tr_split_tiles(p, l, cut_row, tiles) : 0;
-            hipLaunchKernelGGL((k_layer_bwd<1>), dim3(tiles - t0, B), dim3(256), lds1, stream, p, bw, l, lastf, swz | (t0 << 4));
-            if (split) {
-                QPN_HIP(hipEventRecord(sp->ev[l], stream));
-                if (l < L - 1) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l + 1], 0));
-                hipLaunchKernelGGL((k_layer_bwd<1>), dim3(t0, B), dim3(256), lds1, sp->side, p, bw, l, lastf, swz);
-            }
-        } else
-        hipLaunchKernelGGL((k_layer_bwd<MT>), dim3((rows + TM - 1) / TM, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, swz);
-        if (overlap && l == mid && mid < L) {
-            QPN_HIP(hipEventRecord(bw.ev_mid, stream));
-            QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-            launch_w1_wr(mid, L, side);
+            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+        } else {
+            if (lds_layer > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer);
+            hipLaunchKernelGGL((k_layer_bwd<1>), dim3(tiles, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, swz);
         }
     }
-    if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     // the residual-1x1 weight gradient is a memory-bound 64 x 64 contraction: on the side stream next to the matrix-heavy dW1 launch
     // (measured 1028 -> 1052 steps/s; the causal table's contraction there as well: 1028 again, the side chain becomes the longer one)
     auto build_causal = [&]() {      // causal conv table: dWc[tap][c][q] = (dX0)^T onehot(class of x[t-1+tap]); bias = colsum(dX0)
         Wg2 w = wbase;
-        w.nlayers = 2; w.ncol_groups = Q / ((Q % 64 == 0 && !getenv("QPN_CAUSAL_NG128")) ? 64 : 128);     /* 64-class groups: 512 workgroups, two per CU (29 -> 25 us) */ w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
+        w.nlayers = 2; w.ncol_groups = Q / (Q % 64 == 0 ? 64 : 128);     /* 64-class groups: 512 workgroups, two per CU (29 -> 25 us) */ w.bmode = 4; w.xc = p.XC; w.B1 = w.B2 = nullptr; w.B_lstride = 0;
         w.A = bw.DXA[0]; w.A2 = bw.DXB[0]; w.A_lstride = 0; w.lda = C; w.M = C; w.rowsA = N1;
         w.N = Q; w.Nvalid = Q; w.rowsB = N1 + 1; w.ldb = 0; w.ldc = Q;
-        for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = bw.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? bw.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
+        for (int tp = 0; tp < 2; ++tp) { w.row0A[tp] = 0; w.row0B[tp] = tp; w.R[tp] = N1; w.goff[tp] = sl.g_cw + tp * C * Q; w.gbias[tp] = tp == 0 ? sl.g_cb : -1; w.tap_off[tp] = -1; w.dil[tp] = 0; }
         return w;
     };
-    auto launch_causal = [&](hipStream_t st) { if (bw.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, st); };
     // [One launch for everything that waits for the whole layer backward (dW1 + dWr + causal table + upsampling kernel as roles of one kernel)
     //  was tried: 1146 steps/s against 1205.  dW1 is a 247-register kernel (159 VGPRs + 88 accumulators): two of its workgroups fill a CU's
-    //  register file, nothing runs beside them -- which is also why kernels launched next to it on the side stream start when it ends.  The
-    //  causal table as an LDS histogram (27 us, as long as the one-hot MFMA contraction it would replace) did not pay either.]
-    // the causal table's contraction (256 workgroups, latency-bound) next to dW1 as well: the side chain up_bwd + dWr + causal is as long as dW1
-    const bool causal_side = overlap && getenv("QPN_CAUSAL_SIDE") && atoi(getenv("QPN_CAUSAL_SIDE")) == 1;
-    const bool wr_side = overlap && !(getenv("QPN_WR_SIDE") && atoi(getenv("QPN_WR_SIDE")) == 0);
-    if (wr_side || up_side || causal_side) {
+    //  register file, nothing runs beside them -- which is also why kernels launched next to it on the side stream start when it ends.]
+    const bool wr_side = overlap && k.wr_side;
+    if (wr_side || up_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        if (reduce_late) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
         if (up_side) launch_up_bwd(p, bw, side);
-        if (wr_side) launch_w1_wr(0, mid, side, 2);
-        if (causal_side) launch_causal(side);
+        if (wr_side) ok = ok && wgrad2_any(build_wr(), nch, gen, side);
     }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
-    launch_w1_wr(0, mid, stream, wr_side ? 1 : 3);
+    ok = ok && wgrad2_any(build_w1(), nch, gen, stream);
+    if (!wr_side) ok = ok && wgrad2_any(build_wr(), nch, gen, stream);
     if (!overlap) launch_skip_post(stream);
-    if (!causal_side) launch_causal(stream);
+    if (sl.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, gen, stream);
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD, stream);

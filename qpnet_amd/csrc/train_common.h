@@ -11,8 +11,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define TR_MT 2            // 16-row MFMA m-tiles per workgroup tile (32 time rows: more workgroups per CU, smaller tail)
-#define TR_MAXL 32          // layers supported by the training kernels (kernel-argument budget)
+#define TR_MAXL QPN_MAX_LAYERS   // layers supported by the training kernels (the reference's deepest shipped stack, Rd10Rr3Ed4Er1, has 34: src/utils/param_model.py:66-72)
 
 // leading dimension for an LDS A-tile read "row = lane&15, k = lane>>4" with ds_read_b32:
 // ld == 2 (mod 32) makes the 32-lane groups conflict free (MI355X_MICROARCH.md §LDS).
@@ -66,6 +65,14 @@ struct TrainParams {
     TrLayer layers[TR_MAXL];
 };
 
+// slab offsets (floats) of every weight-grad block; host side only
+struct TrainSlabs {
+    int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
+    int g_p1, g_bp1, g_p2, g_bp2;
+    int g_early0, g_early1;           // slab range [g_early0, g_early1): skip 1x1 / skip bias / post-net blocks, complete before the layer backward ends
+    int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
+};
+
 struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     const float* dlogits; float* gflat;
     float* DXA[2]; float* DXB[2];     // [B][N1][C] grads w.r.t. a layer input: own-position part / scattered pitch-tap part
@@ -80,16 +87,32 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     const int* gzero; int n_gzero;    // flat-grad entries no slab element feeds (written by their own kernels afterwards): zeroed by the reduction
     int nch, gstage;
     int64_t n_params;
-    // slab offsets (floats) of every weight-grad block
-    int g_w1[TR_MAXL], g_b1[TR_MAXL], g_wr[TR_MAXL], g_br[TR_MAXL], g_ws[TR_MAXL], g_bs;
-    int g_p1, g_bp1, g_p2, g_bp2;
-    int g_early0, g_early1;           // slab range [g_early0, g_early1): skip 1x1 / skip bias / post-net blocks, complete before the layer backward ends
-    int g_cw, g_cb;                   // causal conv table [tap][C][Q] and bias, or -1: histogram kernel (k_causal_bwd)
+    const struct TrainSlabs* sl;      // HOST pointer (launchers only): slab offsets of every weight-grad block -- kept out of the kernel arguments (4 KB budget at 48 layers)
     float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
     int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
     hipEvent_t ev_early; int* early_recorded;                // recorded on the side stream behind the early reduction when it also wrote the trailer (qpn_train_early_bucket)
 };
+
+
+// Launch-plan knobs, parsed ONCE per handle from the environment (train_init): nothing in the per-step launch path calls getenv().
+// All optional; the defaults are the measured best.  tests/test_train_gpu.py builds a fresh model (= a fresh handle) per arrangement.
+struct TrainKnobs {
+    bool serial;                      // QPN_TRAIN_SERIAL=1: every launch of a step on the caller's stream (also forced while a profile is taken)
+    bool stack_q_fwd, stack_q_bwd;    // QPN_STACK_QUEUE=0 / QPN_STACK_QUEUE_BWD=0: a launch per layer instead of the work-queue launches (train_stack.hip)
+    int stack_wgs, stack_wgs_bwd;     // QPN_STACK_WGS / QPN_STACK_WGS_BWD: grid sizes of the queue launches (0: 2 / 1.5 workgroups per CU)
+    bool persist_fwd, persist_bwd;    // QPN_LAYER_PERSIST=0 / QPN_LAYER_BWD_PERSIST=0: the tile-per-workgroup layer kernels at n_resch 64
+    bool wgrad_generic;               // QPN_WGRAD_GENERIC=1: the run-time-tiled weight-gradient kernel (k_wgrad2)
+    int wgrad_chunks, wgrad_chunks_side;   // QPN_WGRAD_CHUNKS / QPN_WGRAD_CHUNKS_SIDE: time chunks (= partial slabs) of the weight gradients
+    bool up_side, reduce_early, wr_side;   // QPN_UP_SIDE=0 / QPN_REDUCE_EARLY=0 / QPN_WR_SIDE=0: where the backward's small launches run
+    bool post_pair, zero_in_post, post_wide;   // QPN_POST_WGRAD_PAIR=0 / QPN_ZERO_IN_POST=0 / QPN_POST_WIDE=0
+    bool xcd_swizzle;                 // QPN_NO_XCD_SWIZZLE=1 clears it
+    bool ce_separate;                 // QPN_CE_SEPARATE=1: cross entropy as its own kernel behind the forward
+    bool event_fence;                 // QPN_EVENT_FENCE=1: system-scope fence at the fork / join events
+    bool aux_hoist;                   // QPN_AUX_HOIST=0: the auxiliary 1x1 contracted at sample rate (K = 176) even where the frame-rate form applies
+    bool test_stack_gives_up;         // -DQPN_TESTING builds only (QPN_TEST_STACK_GIVES_UP=1): the queue launches' published flags are made unrecognisable
+};
+void qpn_train_knobs_parse(TrainKnobs& k);
 
 #define TR_QHEAD_STRIDE 1056   // words between sub-queue heads (4224 bytes: different memory channels)
 #define TR_QHDR_WORDS 17920    // control block: [1] abort, counters [4..6] forward, [8..10] backward, [1024 + (8 dir + q) * TR_QHEAD_STRIDE]: sub-queue heads
@@ -161,20 +184,6 @@ __device__ __forceinline__ void tr_queue_entry_bwd(const TrainParams& p, int pos
     }
     a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0) | (ly.adaptive ? 1 << 26 : 0), first, n);
     b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, bi * p.BL * p.LC + l * p.C);
-}
-
-// Host-side only: the second stream and events of the two-part time split of the layer kernels (owned by TrainState).
-// The stack is causal, so the EARLIER part of layer l needs nothing from the later part; launching the two parts of every
-// layer on two streams lets one part's load / store phases and launch gaps hide under the other part's matrix work.
-struct TrainSplit { hipStream_t side; hipEvent_t ev[TR_MAXL]; hipEvent_t fork, join; };
-// row where the later part of layer 0 starts, and the number of 16-row tiles of layer l below its cut: the cut moves 16 rows
-// earlier per layer, so cut(l) <= cut(l-1) whatever the layers' first valid rows are
-static inline int tr_split_cut(const TrainParams& p) { return p.layers[0].s_out + (p.N1 - p.layers[0].s_out) / 2; }
-static inline int tr_split_tiles(const TrainParams& p, int l, int cut_row, int tiles) {
-    int t0 = (cut_row - 16 * l - p.layers[l].s_out) / 16;
-    if (t0 < 1) t0 = 1;
-    if (t0 > tiles - 1) t0 = tiles - 1;
-    return t0;
 }
 
 // K-major, zero-padded weight blocks of the GEMM path (train_gemm.hip; n_resch > 128): float offsets into `wp`
@@ -271,37 +280,6 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[MT][NJ], const float* __r
     if (ks4 < nk) wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks4, arow, ak, b0);      // odd step count: the last fragments are already here
 }
 
-// Ring of PD fragment sets: slot d is refilled right behind the step that consumed it with the fragments of PD steps later, so a
-// request has PD - 1 steps of MFMAs to arrive under.  Full trips are one basic block without conditionals (see wave_gemm).
-template <int MT, int NJ, int PD>
-__device__ __forceinline__ void wave_gemm_ring(f32x4 (&acc)[MT][NJ], const float* __restrict__ A_lds, int lda,
-                                               const float4* __restrict__ Bp, int NT, const int (&nts)[NJ], int K, int lane) {
-    const int arow = lane & 15, ak = lane >> 4;
-    const int nk = K / 16;
-    float4 bq[PD][NJ];
-#pragma unroll
-    for (int d = 0; d < PD; ++d) {
-        const int kd = d < nk ? d : nk - 1;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kd * NT + nts[j]) * 64 + lane];
-    }
-    int ks0 = 0;
-    for (; ks0 + PD <= nk; ks0 += PD) {
-#pragma unroll
-        for (int d = 0; d < PD; ++d) {
-            __builtin_amdgcn_sched_barrier(0);
-            wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks0 + d, arow, ak, bq[d]);
-            __builtin_amdgcn_sched_barrier(0);
-            const int kn = ks0 + d + PD < nk ? ks0 + d + PD : nk - 1;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bq[d][j] = Bp[((size_t)kn * NT + nts[j]) * 64 + lane];
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < PD; ++d)
-        if (ks0 + d < nk) wave_gemm_step<MT, NJ>(acc, A_lds, lda, ks0 + d, arow, ak, bq[d]);      // the last partial trip: fragments already requested
-}
-
 // Variant for the narrow GEMMs (one n-tile per wave): the weight fragments come from L2 (~1 k cycles away) and are requested PD
 // 16-deep steps ahead through a ring of PD register sets.  [With one step of lookahead a 16-row tile's step has only 4-8 MFMAs (128-256 cycles) to hide that latency
 // behind: in-kernel stamps showed ~1.2 k cycles per step, 10 k cycles for a 32-MFMA GEMM.  For the two-n-tile GEMMs the
@@ -358,21 +336,6 @@ __device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float
     wave_gemm_run<MT, NJ, PD>(acc, A_lds, lda, bq, Bp, NT, nts, K, lane);
 }
 
-// The two-n-tile GEMMs (gate pre-activations, post-net): weight-fragment prefetch depth as a build-time knob (1 = one step of
-// lookahead, wave_gemm; > 1 = a ring of QPN_PD2 register sets, wave_gemm_deep).  QPN_PD2L for the layer kernels, QPN_PD2P for the post-net.
-#ifndef QPN_PD2L
-#define QPN_PD2L 1
-#endif
-#ifndef QPN_PD2P
-#define QPN_PD2P 1
-#endif
-template <int MT, int PD>
-__device__ __forceinline__ void wave_gemm2(f32x4 (&acc)[MT][2], const float* __restrict__ A_lds, int lda,
-                                           const float4* __restrict__ Bp, int NT, const int (&nts)[2], int K, int lane) {
-    if constexpr (PD <= 1) wave_gemm<MT, 2>(acc, A_lds, lda, Bp, NT, nts, K, lane);
-    else wave_gemm_ring<MT, 2, PD>(acc, A_lds, lda, Bp, NT, nts, K, lane);
-}
-
 // ---- wide post-net tiles (k_post_fwd_w / k_post_bwd_w): a wave owns two column tiles and 16 MT rows
 template <int MT>
 __device__ __forceinline__ void post_load_a(float (&x)[MT][4], const float* __restrict__ A, int lda, int ks, int arow, int ak) {
@@ -404,19 +367,13 @@ __device__ __forceinline__ void post_gemm(f32x4 (&acc)[MT][2], const float* __re
     float x0[MT][4], x1[MT][4];
     post_load_a<MT>(x0, A, lda, 0, arow, ak);
     for (int ks = 0; ks < nk; ks += 2) {                          // nk is even (K a multiple of 32)
-#ifdef POSTW_TEST_NOB      // timing experiment only (wrong results): no weight-fragment loads inside the contraction
-        float4 c0 = b[0], c1 = b[1];
-#else
         float4 c0 = Bp[((size_t)(ks + 1) * NT + nt0) * 64 + lane], c1 = Bp[((size_t)(ks + 1) * NT + nt0 + 1) * 64 + lane];
-#endif
         post_load_a<MT>(x1, A, lda, ks + 1, arow, ak);
         __builtin_amdgcn_sched_barrier(0);
         post_mfma<MT>(acc, x0, b[0], b[1]);
         __builtin_amdgcn_sched_barrier(0);
-#ifndef POSTW_TEST_NOB
         const float4* nx = ks + 2 < nk ? Bp + ((size_t)(ks + 2) * NT + nt0) * 64 + lane : next;
         b[0] = nx[0]; b[1] = nx[64];
-#endif
         post_load_a<MT>(x0, A, lda, ks + 2 < nk ? ks + 2 : ks, arow, ak);      // (past the end: a harmless re-read)
         __builtin_amdgcn_sched_barrier(0);
         post_mfma<MT>(acc, x1, c0, c1);

@@ -166,7 +166,7 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
         const int nts[2] = {cg, NCG + cg};
-        wave_gemm2<MT, QPN_PD2L>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
+        wave_gemm<MT, 2>(acc, As, lda, W1, 2 * NCG, nts, Ktp, lane);
         const int c = 16 * cg + (lane & 15);
         const float bs = cg == wave ? bs_pre : bias1[c], bt = cg == wave ? bt_pre : bias1[C + c];
 #pragma unroll
@@ -206,9 +206,9 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
 // one layer per launch.  [A persistent all-layers kernel with per-tile completion flags was tried: on this multi-XCD part
 // an agent-scope release is a whole-L2 write-back (buffer_wbl2 sc1) per tile, 4x slower than the eight launches.]
 template <int MT>
-__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {      // last: bit 0 last layer, bit 1 XCD swizzle, bits 4.. first tile
+__global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int last) {      // last: bit 0 last layer, bit 1 XCD swizzle
     extern __shared__ float sm[];
-    layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + ((last >> 4) + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2)) * 16 * MT, sm);
+    layer_fwd_tile<MT>(p, l, last & 1, blockIdx.y, p.layers[l].s_out + tr_xcd_tile(blockIdx.x, gridDim.x, last & 2) * 16 * MT, sm);
 }
 
 // ------------------------------------------------------------------------------------------------ persistent form, n_resch = 64
@@ -223,21 +223,14 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
 //    lines, one address per array and tile) instead of 64-byte column strips straight from the accumulator layout;
 //  * barriers order LDS only (TR_LDS_BARRIER): the prefetch and the stores stay in flight across them.
 // (reference: the fixed / adaptive gated block of src/nets/qpnet.py:626-670; same arithmetic as layer_fwd_tile above.)
-// dev aid (build with -DQPN_ENABLE_STAMPS, run with QPN_FWDP_STAMPS=1): s_memtime of wave 0 at the phase boundaries of a few workgroups
-#ifdef QPN_ENABLE_STAMPS
-#define FWDP_STAMP(i) do { if (stamps && lane == 0 && wave == 0 && (blockIdx.x & 63) == 5 && (i) < 64) stamps[(blockIdx.x >> 6) * 64 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FWDP_STAMP(i) do { } while (0)
-#endif
 template <int KS, bool LAST>
-__global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy, long long* stamps, int tile0) {     // flags: bit 1 XCD swizzle; tile0: first tile of this launch (two-part time split)
+__global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy) {     // flags: bit 1 XCD swizzle
     constexpr int C = 64, Ktp = 16 * KS;
     constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;     // tr_lda: conflict-free fragment reads, 8-byte aligned rows
     extern __shared__ float sm[];
     float* Gs = sm + 32 * lda;                                   // As buffers: sm, sm + 16 * lda
     float* SGs = Gs + 16 * ldg; float* THs = SGs + 16 * ldg; float* Xs = THs + 16 * ldg;
-    TrLayer ly = p.layers[l];
-    ly.s_out += 16 * tile0;                                       // (tiles are counted from the launch's first one)
+    const TrLayer ly = p.layers[l];
     const int Ap = p.Ap, N1 = p.N1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
@@ -268,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
     const int srow = tid >> 4, sc4 = tid & 15;
     const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
     const int orow = tid >> 5, oc2 = (tid & 31) * 2;
-    float* const dmy = dummy + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) + (tile0 ? 512 : 0)) * 2 * C + oc2;       // two scratch rows per workgroup (second half of the table: the split's other launch)
+    float* const dmy = dummy + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + oc2;       // two scratch rows per workgroup
     int tp; float4 rc, rp, rx;
     auto load_tap = [&](int t) { const int n = ly.s_out + t * 16 + srow; tp = taps[n < N1 ? n : N1 - 1]; };
     auto load_rows = [&](int t) {
@@ -296,22 +289,17 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
         *(float2*)d0 = v0; *(float2*)d1 = v1;
     };
     // ---- prologue: rows of the first tile, tap of the second
-    FWDP_STAMP(0);
     load_tap(t_first);
     load_rows(t_first);
     store_rows(t_first, sm);
     load_tap(t_first + 1 < t_last ? t_first + 1 : t_last);
-    FWDP_STAMP(1);
     const int arow = lane & 15, ak = lane >> 4;
     for (int ti = 0; ti < t_count; ++ti) {
         const int t = t_first + ti, n0 = ly.s_out + t * 16;
         float* As = sm + (ti & 1) * 16 * lda;
-        FWDP_STAMP(2 + 8 * ti);
         load_rows(t + 1 < t_last ? t + 1 : t_last);              // in flight under this tile's contractions (past the range: a harmless reload)
         load_tap(t + 2 < t_last ? t + 2 : t_last);
-        FWDP_STAMP(3 + 8 * ti);
         TR_LDS_BARRIER();                                          // As[ti & 1] complete (written at the end of the previous trip); Xs of the previous tile complete
-        FWDP_STAMP(4 + 8 * ti);
         if (!LAST) store_out(Xs, Xout, n0 - 16, ti > 0);
         float xa[KS][4];
 #pragma unroll
@@ -329,16 +317,13 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][0].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][1].z, a1, 0, 0, 0);
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][0].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][1].w, a1, 0, 0, 0);
         }
-        FWDP_STAMP(5 + 8 * ti);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int o = (4 * (lane >> 4) + i) * ldg + c;
             const float sg = sigmoidf_(a0[i] + bs), th = tanhf_(a1[i] + bt);
             Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
         }
-        FWDP_STAMP(6 + 8 * ti);
         TR_LDS_BARRIER();
-        FWDP_STAMP(7 + 8 * ti);
         if (!LAST) {                                              // the last block's residual output is never used (qpnet.py:306-309)
             float ga[4][4];
 #pragma unroll
@@ -366,15 +351,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
             store_out(SGs, SG, n0, true);
             store_out(THs, TH, n0, true);
         }
-        FWDP_STAMP(8 + 8 * ti);
-#ifdef QPN_ENABLE_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // stamped build only: how long until every load / store in flight has landed
-        FWDP_STAMP(40 + ti);
-#endif
         // the next tile's rows have had a whole tile of matrix work to arrive: into the OTHER buffer (its last readers were
         // the previous trip's contractions, two barriers ago)
         store_rows(t + 1, sm + ((ti + 1) & 1) * 16 * lda);
-        FWDP_STAMP(9 + 8 * ti);
     }
     if (!LAST) {
         TR_LDS_BARRIER();
@@ -435,7 +414,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
         POST_PIN_BIAS;
-        if (active) { const int nts[2] = {nt0, nt1}; wave_gemm2<MT, QPN_PD2P>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
+        if (active) { const int nts[2] = {nt0, nt1}; wave_gemm<MT, 2>(acc, Gall, ldall, p.wp + p.ws_f4, NTS, nts, LC, lane); }
         __syncthreads();                                         // every wave is done reading Gall before St overwrites it
         if (active) {
 #pragma unroll
@@ -510,7 +489,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
             if (fits && l + 1 < L) gfetch(l + 1);
             if (active) {
                 const int nts[2] = {nt0, nt1};
-                wave_gemm2<MT, QPN_PD2P>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
+                wave_gemm<MT, 2>(acc, G, ldg, p.wp + p.ws_f4 + (size_t)l * NCG * NTS * 64, NTS, nts, C, lane);
             }
         }
         if (active) {
@@ -542,7 +521,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm2<MT, QPN_PD2P>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
+            wave_gemm<MT, 2>(acc, St, lds, p.wp + p.p1_f4, NTS, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
@@ -572,7 +551,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
             const int nts[2] = {nt0, nt1};
-            wave_gemm2<MT, QPN_PD2P>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
+            wave_gemm<MT, 2>(acc, Yt, lds, p.wp + p.p2_f4, NTQ, nts, S, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nt = j ? nt1 : nt0;
@@ -692,9 +671,6 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
     };
     // ... and from there to a [BL][256] array as whole 1 KB rows
     auto rows_out = [&](float* dst) {
-#ifdef POSTW_TEST_NOOUT     // timing experiment only
-        if (p.BL > 0) return;
-#endif
         for (int idx = tid; idx < TM * (S / 2); idx += 512) {
             const int r = idx / (S / 2), kk = (idx - r * (S / 2)) * 2;
             if (t0 + r < p.BL) *(float2*)(dst + ((size_t)b * p.BL + t0 + r) * S + kk) = *(const float2*)(T + (size_t)r * lds + kk);
@@ -735,9 +711,6 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
             const int r = idx / (Q / 2), kk = (idx - r * (Q / 2)) * 2;
             if (t0 + r < p.BL) *(float2*)(p.logits + ((size_t)b * p.BL + t0 + r) * Q + kk) = *(const float2*)(T + (size_t)r * lds + kk);
         }
-#ifdef POSTW_TEST_NOOUT
-    if (p.BL > 0) return;
-#endif
     if (!p.ce_tgt) return;
     // ---------- fused torch.nn.CrossEntropyLoss() (mean) and its gradient while the logits are in LDS (same arithmetic as k_ce)
     {
@@ -828,112 +801,53 @@ void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
 }
 
 bool qpn_stack_fwd_fits(const TrainParams& p);
-int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stream);
+int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq, hipStream_t stream) {
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S;
     qpn_launch_prep(p, stream);
     qpn_prof_mark(PG_PREP, stream);
-    constexpr int MT = TR_MT, TM = 16 * MT;
-    const size_t lds_layer = (size_t)TM * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
-    const size_t lds_post = (size_t)TM * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
+    // 16-row tiles everywhere (twice the workgroups of 32-row tiles, all co-resident: measured 8-15 % faster for the layer and post-net kernels)
+    const size_t lds_layer = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
+    const size_t lds_post = (size_t)16 * (tr_lda(S) + (tr_lda(S) > 2 * tr_lda(C) ? tr_lda(S) : 2 * tr_lda(C))) * sizeof(float);
     if (lds_layer > 160 * 1024 || lds_post > 160 * 1024) {
         qpn_set_error("training kernels: tiles do not fit the 160 KiB LDS for n_resch=%d n_skipch=%d (n_resch <= 128 supported)", C, S);
         return QPN_EINVAL;
     }
-    if (lds_layer > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer));
-    if (lds_post > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post));
     {
-        const char* e1 = getenv("QPN_LAYER_MT"); const char* e2 = getenv("QPN_LAYER_LDS");
-        // 16-row tiles (twice the workgroups, all co-resident) measured 8 % faster than 32-row tiles for the layer forward;
-        // QPN_LAYER_MT / QPN_LAYER_LDS (occupancy cap) are tuning knobs (tools/sweep_layer.sh)
-        const int lmt = e1 ? atoi(e1) : 1; const size_t pad = e2 ? (size_t)atoi(e2) : 0;
-        // two-part time split (TrainSplit): part 0 = tiles below the cut, part 1 = the rest, on a second stream.  The cut moves 16 rows
-        // earlier per layer so that part 0 of layer l only reads rows part 0 of layer l-1 wrote; part 1 of layer l waits for
-        // part 0 of layer l-1 (its pitch taps reach back across the cut).  Opt-in (QPN_TRAIN_SPLIT=1): measured 981 vs 1014 steps/s at paper size -- the
-        // layer kernels are not limited by launch gaps or phase separation, and the 34 extra event calls cost more than the overlap gives.
-        const int split_min_rows = 4096;
-        const bool split = sp && lmt == 1 && p.L >= 2 && !qpn_prof_active() && !getenv("QPN_TRAIN_SERIAL") &&
-                           (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) &&
-                           p.N1 - p.layers[p.L - 1].s_out >= split_min_rows;
-        const int flags0 = getenv("QPN_NO_XCD_SWIZZLE") ? 0 : 2;
-        const int cut_row = split ? tr_split_cut(p) : 0;
-        if (split) { QPN_HIP(hipEventRecord(sp->fork, stream)); QPN_HIP(hipStreamWaitEvent(sp->side, sp->fork, 0)); }
+        const int flags0 = k.xcd_swizzle ? 2 : 0;
         // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
-        const bool persist = C == 64 && p.Ktp == 176 && p.N1 < (1 << 24) && !(getenv("QPN_LAYER_PERSIST") && atoi(getenv("QPN_LAYER_PERSIST")) == 0);      // (N1 < 2^24: 32-bit element offsets of one batch item)
-        const int wg_per_cu = getenv("QPN_LAYER_WGS") ? atoi(getenv("QPN_LAYER_WGS")) : 2;
+        const bool persist = C == 64 && p.Ktp == 176 && p.N1 < (1 << 24) && k.persist_fwd;      // (N1 < 2^24: 32-bit element offsets of one batch item)
         // the whole stack as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE=0 keeps a launch per layer
-        const bool stack_q = persist && !split && sq && sq->flags && p.qctl && qpn_stack_fwd_fits(p) && !getenv("QPN_FWDP_STAMPS");
-        if (stack_q) { const int rcq = qpn_launch_stack_fwd(p, *sq, stream); if (rcq) return rcq; }
+        const bool stack_q = persist && k.stack_q_fwd && sq && sq->flags && p.qctl && qpn_stack_fwd_fits(p);
+        if (stack_q) { const int rcq = qpn_launch_stack_fwd(p, *sq, k, stream); if (rcq) return rcq; }
         for (int l = 0; l < p.L && !stack_q; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
+            const int tiles = (rows + 15) / 16;
             if (persist) {
-                const int tiles = (rows + 15) / 16;
-                int G = qpn_num_cus() * wg_per_cu; if (G > tiles) G = tiles;
+                int G = qpn_num_cus() * 2; if (G > tiles) G = tiles;
                 if (G > 1024) G = 1024;                            // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
                 const size_t ldsp = (size_t)(32 * tr_lda(176) + 4 * 16 * tr_lda(64)) * sizeof(float);
-                static long long* d_stamps = nullptr;
-                const bool stamp = getenv("QPN_FWDP_STAMPS") != nullptr;
-                if (stamp && !d_stamps) { QPN_HIP(hipMalloc(&d_stamps, 16 * 64 * sizeof(long long))); }
-                if (stamp) QPN_HIP(hipMemsetAsync(d_stamps, 0, 16 * 64 * sizeof(long long), stream));
-                if (split) {      // two launches of one workgroup per CU each: the earlier tiles on the main stream, the later ones on the side stream
-                    const int t0 = tr_split_tiles(p, l, cut_row, tiles), ncu = qpn_num_cus();
-                    const int ncap = ncu < 512 ? ncu : 512;             // (the split's second launch uses the upper half of the scratch rows)
-                    const int G0 = t0 < ncap ? t0 : ncap, G1 = tiles - t0 < ncap ? tiles - t0 : ncap;
-                    if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
-                    else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G0, p.B), dim3(256), ldsp, stream, p, l, flags0, t0, p.scratch_rows, nullptr, 0);
-                    QPN_HIP(hipEventRecord(sp->ev[l], stream));
-                    if (l > 0) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l - 1], 0));
-                    if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G1, p.B), dim3(256), ldsp, sp->side, p, l, flags0, tiles - t0, p.scratch_rows, nullptr, t0);
-                    else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G1, p.B), dim3(256), ldsp, sp->side, p, l, flags0, tiles - t0, p.scratch_rows, nullptr, t0);
-                    continue;
-                }
-                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr, 0);
-                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows, stamp ? d_stamps : nullptr, 0);
-                if (stamp && l == 5) {      // dev aid: print the stamps of one adaptive layer's launch (cycles relative to the first stamp of each sampled workgroup)
-                    static int printed = 0;
-                    long long hs[16 * 64];
-                    QPN_HIP(hipStreamSynchronize(stream));
-                    QPN_HIP(hipMemcpy(hs, d_stamps, sizeof(hs), hipMemcpyDeviceToHost));
-                    if (printed++ == 30) for (int w = 0; w < 8; ++w) {
-                        fprintf(stderr, "fwdp stamps wg %d:", 64 * w + 5);
-                        for (int i = 0; i < 46; ++i) fprintf(stderr, " %lld", hs[w * 64 + i] ? hs[w * 64 + i] - hs[w * 64] : -1LL);
-                        fprintf(stderr, "\n");
-                    }
-                }
-            } else if (lmt == 1) {
-                size_t lds1 = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float); if (pad > lds1) lds1 = pad;
-                if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-                const int tiles = (rows + 15) / 16, fl = (l == p.L - 1 ? 1 : 0) | flags0;
-                const int t0 = split ? tr_split_tiles(p, l, cut_row, tiles) : tiles;
-                hipLaunchKernelGGL((k_layer_fwd<1>), dim3(t0, p.B), dim3(256), lds1, stream, p, l, fl);
-                if (split) {
-                    QPN_HIP(hipEventRecord(sp->ev[l], stream));
-                    if (l > 0) QPN_HIP(hipStreamWaitEvent(sp->side, sp->ev[l - 1], 0));
-                    hipLaunchKernelGGL((k_layer_fwd<1>), dim3(tiles - t0, p.B), dim3(256), lds1, sp->side, p, l, fl | (t0 << 4));
-                }
+                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
             } else {
-                size_t lds2 = lds_layer; if (pad > lds2) lds2 = pad;
-                if (lds2 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                hipLaunchKernelGGL((k_layer_fwd<MT>), dim3((rows + TM - 1) / TM, p.B), dim3(256), lds2, stream, p, l, (l == p.L - 1 ? 1 : 0) | flags0);
+                if (lds_layer > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer);
+                hipLaunchKernelGGL((k_layer_fwd<1>), dim3(tiles, p.B), dim3(256), lds_layer, stream, p, l, (l == p.L - 1 ? 1 : 0) | flags0);
             }
         }
-        if (split) { QPN_HIP(hipEventRecord(sp->join, sp->side)); QPN_HIP(hipStreamWaitEvent(stream, sp->join, 0)); }
     }
     qpn_prof_mark(PG_LAYER_FWD, stream);
     // wide post-net tiles (S = Q = 256, n_resch 64): 16 * MT rows per workgroup, MT chosen so that the chunk is one round of workgroups
-    const bool post_wide = S == 256 && p.Q == 256 && C == 64 && !(getenv("QPN_POST_WIDE") && atoi(getenv("QPN_POST_WIDE")) == 0);
+    const bool post_wide = S == 256 && p.Q == 256 && C == 64 && k.post_wide;
     if (post_wide) {
         constexpr int MTW = 5;
         const size_t ldsw = (size_t)16 * MTW * (tr_lda(256) + 2 * tr_lda(64)) * sizeof(float);
         QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));
         hipLaunchKernelGGL((k_post_fwd_w<MTW>), dim3((p.BL + 16 * MTW - 1) / (16 * MTW), p.B), dim3(512), ldsw, stream, p);
-    } else if (!getenv("QPN_POST_MT") || atoi(getenv("QPN_POST_MT")) == 1) {     // 16-row tiles: twice the workgroups, shorter last round (measured 15 % faster than 32 rows)
-        const size_t lds1 = lds_post / MT;
-        if (lds1 > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-        hipLaunchKernelGGL((k_post_fwd<1>), dim3((p.BL + 15) / 16, p.B), dim3(512), lds1, stream, p);
-    } else
-    hipLaunchKernelGGL((k_post_fwd<MT>), dim3((p.BL + TM - 1) / TM, p.B), dim3(512), lds_post, stream, p);
+    } else {
+        if (lds_post > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_post_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_post);
+        hipLaunchKernelGGL((k_post_fwd<1>), dim3((p.BL + 15) / 16, p.B), dim3(512), lds_post, stream, p);
+    }
     qpn_prof_mark(PG_POST_FWD, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;
@@ -943,7 +857,7 @@ int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, i
     const int64_t rows = (int64_t)B * BL;
     // (the loss accumulator was cleared by this step's k_refresh; a CE call without a forward in front clears it itself)
     if (!loss_cleared) QPN_HIP(hipMemsetAsync(loss, 0, 64 * sizeof(double), stream));
-    const int rpw = getenv("QPN_CE_RPW") ? atoi(getenv("QPN_CE_RPW")) : 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
+    const int rpw = 4;                // 16 rows per workgroup: ~1250 workgroups for a 20 k-row chunk (64 rows per workgroup left most CUs with one)
     hipLaunchKernelGGL(k_ce, dim3((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), dim3(256), 0, stream, logits, tgt, tgt_stride, BL, Q, rows, dlogits, loss, rpw, status);
     qpn_prof_mark(PG_CE, stream);
     QPN_HIP(hipGetLastError());

@@ -526,15 +526,14 @@ int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t st
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
 int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done);
 
-// post-net weight gradients dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0) (+ bias column sums) into the `nch` partial slabs;
-// also used by the tile path of the narrow geometries (train_bwd.hip), where these two are the only 256-row outputs
-void qpn_launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+// post-net weight gradients dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0) (+ bias column sums) into the `nch` partial slabs
+static void launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     TArgs a; memset(&a, 0, sizeof(a));
     a.nb = p.B; a.nsplit = bw.nch; a.slab = bw.slab; a.gstage = bw.gstage; a.C = p.C; a.Ap = p.Ap;
     a.M = p.Q; a.N = p.S; a.a = bw.dlogits; a.lda = p.Q; a.rowsA = p.BL; a.b1 = p.Y0; a.ldb = p.S; a.rowsB = p.BL; a.ldc = p.S;
-    a.R[0] = p.BL; a.goff[0] = bw.g_p2; a.gbias[0] = bw.g_bp2; a.tap_off[0] = -1;
+    a.R[0] = p.BL; a.goff[0] = bw.sl->g_p2; a.gbias[0] = bw.sl->g_bp2; a.tap_off[0] = -1;
     launch_tn<BM_RELU>(a, 1, stream);
-    a.M = p.S; a.a = bw.DY0; a.lda = p.S; a.b1 = p.S0; a.goff[0] = bw.g_p1; a.gbias[0] = bw.g_bp1;
+    a.M = p.S; a.a = bw.DY0; a.lda = p.S; a.b1 = p.S0; a.goff[0] = bw.sl->g_p1; a.gbias[0] = bw.sl->g_bp1;
     launch_tn<BM_RELU>(a, 1, stream);
 }
 
@@ -597,7 +596,7 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
         a.b1 = p.X; a.b_ls = (long)nDX; a.ldb = C; a.rowsB = N1; a.ldc = p.Ktp;
         for (int l = 0; l < L; ++l) {
             const TrLayer& ly = p.layers[l];
-            a.row0A[l] = a.row0B[l] = ly.s_out; a.R[l] = N1 - ly.s_out; a.goff[l] = bw.g_w1[l]; a.gbias[l] = bw.g_b1[l];
+            a.row0A[l] = a.row0B[l] = ly.s_out; a.R[l] = N1 - ly.s_out; a.goff[l] = bw.sl->g_w1[l]; a.gbias[l] = bw.sl->g_b1[l];
             a.tap_off[l] = ly.adaptive ? ly.tap_off : -1; a.dil[l] = ly.dilation;
         }
         launch_tn<BM_GATHER>(a, L, stream);
@@ -608,7 +607,7 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
         a.b1 = w.G; a.b_ls = (long)nDX; a.ldb = C; a.rowsB = N1; a.ldc = C;
         for (int l = 0; l < L; ++l) {
             a.row0A[l] = a.row0B[l] = p.layers[l].s_out; a.R[l] = l == L - 1 ? 0 : N1 - p.layers[l].s_out;
-            a.goff[l] = bw.g_wr[l]; a.gbias[l] = bw.g_br[l]; a.tap_off[l] = -1;
+            a.goff[l] = bw.sl->g_wr[l]; a.gbias[l] = bw.sl->g_br[l]; a.tap_off[l] = -1;
         }
         launch_tn<BM_PLAIN>(a, L, stream);
     }
@@ -616,10 +615,10 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
         TArgs a = t;
         a.M = S; a.N = C; a.a = bw.DS0; a.a_ls = 0; a.lda = S; a.rowsA = BL;
         a.b1 = w.G; a.b_ls = (long)nDX; a.ldb = C; a.rowsB = N1; a.ldc = C;
-        for (int l = 0; l < L; ++l) { a.row0A[l] = 0; a.row0B[l] = N1 - BL; a.R[l] = BL; a.goff[l] = bw.g_ws[l]; a.gbias[l] = l == 0 ? bw.g_bs : -1; a.tap_off[l] = -1; }
+        for (int l = 0; l < L; ++l) { a.row0A[l] = 0; a.row0B[l] = N1 - BL; a.R[l] = BL; a.goff[l] = bw.sl->g_ws[l]; a.gbias[l] = l == 0 ? bw.sl->g_bs : -1; a.tap_off[l] = -1; }
         launch_tn<BM_PLAIN>(a, L, stream);
     }
-    qpn_launch_post_wgrad_gemm(p, bw, stream);
+    launch_post_wgrad_gemm(p, bw, stream);
     qpn_prof_mark(PG_WGRAD, stream);
     return qpn_launch_grad_tail(p, bw, stream, false, false);
 }

@@ -7,10 +7,10 @@
 #include <algorithm>
 #include <string.h>
 
-int qpn_launch_fwd(const TrainParams& p, const TrainSplit* sp, const StackQ* sq, hipStream_t stream);
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, hipStream_t stream);
 void qpn_stack_fill(TrainParams& p);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainSplit* sp, const StackQ* sq, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const StackQ* sq, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
@@ -24,6 +24,8 @@ struct TrainState {
     int* d_gsrc; int* d_gsrc2; int* d_gdst; int* d_gdst_list; int* d_gzero; int n_gzero;
     TrainParams tp;                           // template with block offsets filled in
     TrainBwd bw;
+    TrainSlabs slabs;                         // slab offsets of the weight-gradient blocks (bw.sl points here)
+    TrainKnobs knobs;                         // launch-plan knobs, parsed once (qpn_train_knobs_parse)
     // workspaces (grow only)
     float* d_ws; size_t ws_cap;               // one arena, carved per call
     int* d_tap; size_t tap_cap;
@@ -39,12 +41,40 @@ struct TrainState {
     int64_t generation;                       // bumped by every qpn_train_forward: identifies whose activations the workspace holds
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
     hipEvent_t ev_early; int early_recorded; int64_t early_first;   // qpn_train_early_bucket: the flat-gradient tail that is final before the layer backward ends
-    TrainSplit split; bool have_split;                       // second stream of the two-part time split of the layer kernels
     int64_t bwd_generation;                                  // generation of the forward the last backward belonged to
     bool stack_disabled;                                     // a stack-queue launch gave up once (status bit 4): this handle keeps to a launch per layer
     unsigned* d_sq; size_t sq_pos_cap, sq_per_dir;                           // stack work queues (train_stack.hip): [16 control words | forward flags | backward flags]
     StackQ sqf, sqb;
 };
+
+// The environment is read HERE, once per handle: the launch path of a step never calls getenv().
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && *e) ? atoi(e) : dflt; }
+void qpn_train_knobs_parse(TrainKnobs& k) {
+    k.serial = env_int("QPN_TRAIN_SERIAL", 0) != 0;
+    k.stack_q_fwd = env_int("QPN_STACK_QUEUE", 1) != 0;
+    k.stack_q_bwd = k.stack_q_fwd && env_int("QPN_STACK_QUEUE_BWD", 1) != 0;
+    k.stack_wgs = env_int("QPN_STACK_WGS", 0); if (k.stack_wgs < 0 || k.stack_wgs > 4096) k.stack_wgs = 0;
+    k.stack_wgs_bwd = env_int("QPN_STACK_WGS_BWD", 0); if (k.stack_wgs_bwd < 0 || k.stack_wgs_bwd > 4096) k.stack_wgs_bwd = 0;
+    k.persist_fwd = env_int("QPN_LAYER_PERSIST", 1) != 0;
+    k.persist_bwd = env_int("QPN_LAYER_BWD_PERSIST", 1) != 0;
+    k.wgrad_generic = getenv("QPN_WGRAD_GENERIC") != nullptr;
+    k.wgrad_chunks = env_int("QPN_WGRAD_CHUNKS", 0); if (k.wgrad_chunks < 1 || k.wgrad_chunks > 512) k.wgrad_chunks = 0;
+    k.wgrad_chunks_side = env_int("QPN_WGRAD_CHUNKS_SIDE", 0); if (k.wgrad_chunks_side < 1 || k.wgrad_chunks_side > 512) k.wgrad_chunks_side = 0;
+    k.up_side = env_int("QPN_UP_SIDE", 1) != 0;
+    k.reduce_early = env_int("QPN_REDUCE_EARLY", 1) != 0;
+    k.wr_side = env_int("QPN_WR_SIDE", 1) != 0;
+    k.post_pair = env_int("QPN_POST_WGRAD_PAIR", 1) != 0;
+    k.zero_in_post = env_int("QPN_ZERO_IN_POST", 1) != 0;
+    k.post_wide = env_int("QPN_POST_WIDE", 1) != 0;
+    k.xcd_swizzle = getenv("QPN_NO_XCD_SWIZZLE") == nullptr;
+    k.ce_separate = getenv("QPN_CE_SEPARATE") != nullptr;
+    k.event_fence = env_int("QPN_EVENT_FENCE", 0) == 1;
+    k.aux_hoist = env_int("QPN_AUX_HOIST", 1) != 0;
+    k.test_stack_gives_up = false;
+#ifdef QPN_TESTING
+    k.test_stack_gives_up = env_int("QPN_TEST_STACK_GIVES_UP", 0) == 1;
+#endif
+}
 
 int qpn_num_cus() {
     static int cached[64] = {0};
@@ -154,8 +184,9 @@ static int train_init(qpn_handle* h) {
     t->d_gdst = t->d_gdst_list = t->d_gzero = nullptr; t->n_gzero = 0;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr; t->ev_early = nullptr; t->early_recorded = 0; t->early_first = -1;
-    memset(&t->split, 0, sizeof(t->split)); t->have_split = false;
     t->d_sq = nullptr; t->sq_pos_cap = 0; t->sq_per_dir = 0; t->bwd_generation = -1; t->stack_disabled = false; memset(&t->sqf, 0, sizeof(t->sqf)); memset(&t->sqb, 0, sizeof(t->sqb));
+    qpn_train_knobs_parse(t->knobs);
+    memset(&t->slabs, 0, sizeof(t->slabs));
     t->use_gemm = (C > 128 || getenv("QPN_TRAIN_GEMM")) && !getenv("QPN_TRAIN_TILES");
     t->d_gmap = nullptr; t->d_gwp = nullptr; t->d_ctmap = nullptr; t->d_ct = nullptr; memset(&t->gm, 0, sizeof(t->gm));
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
@@ -237,18 +268,20 @@ static int train_init(qpn_handle* h) {
 
     // ---- weight-grad staging space ("slab") and the flat-grad gather map
     TrainBwd& bw = t->bw;
+    TrainSlabs& sl = t->slabs;
+    bw.sl = &t->slabs;
     int go = 0;
     auto gtake = [&](int n) { int r = go; go += (n + 63) & ~63; return r; };
     std::vector<int>& gs = t->h_gsrc; std::vector<int>& gs2 = t->h_gsrc2;
     gs.assign(g.n_params, -1); gs2.assign(g.n_params, -1);
     for (int l = 0; l < L; ++l) {
-        bw.g_w1[l] = gtake(2 * C * Ktp);   // dW1[n][k] (n = z row, k = A-tile column), row-major [2C][Ktp]
-        bw.g_b1[l] = gtake(2 * C);
-        bw.g_wr[l] = gtake(C * C);         // dWr[o][c]
-        bw.g_br[l] = gtake(C);
+        sl.g_w1[l] = gtake(2 * C * Ktp);   // dW1[n][k] (n = z row, k = A-tile column), row-major [2C][Ktp]
+        sl.g_b1[l] = gtake(2 * C);
+        sl.g_wr[l] = gtake(C * C);         // dWr[o][c]
+        sl.g_br[l] = gtake(C);
     }
-    bw.g_early0 = go;
-    for (int l = 0; l < L; ++l) bw.g_ws[l] = gtake(S * C);         // dWs_l[s][c]
+    sl.g_early0 = go;
+    for (int l = 0; l < L; ++l) sl.g_ws[l] = gtake(S * C);         // dWs_l[s][c]
     for (int l = 0; l < L; ++l) {
         const LayerGeom y = g.layers[l];
         // (slab order: first the blocks that need the layer backward -- dW1, dWr of every layer -- then, contiguous, the ones the side
@@ -260,35 +293,35 @@ static int train_init(qpn_handle* h) {
                 if (k < C) dst = y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
                 else if (k < 2 * C) { const int kk = k - C; dst = y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2; }
                 else dst = (half ? y.auxT : y.auxS) + (int64_t)r * A + (k - 2 * C);
-                gs[dst] = bw.g_w1[l] + n * Ktp + k;
+                gs[dst] = sl.g_w1[l] + n * Ktp + k;
             }
-            gs[(half ? y.bT : y.bS) + r] = bw.g_b1[l] + n;
-            gs[(half ? y.auxTb : y.auxSb) + r] = bw.g_b1[l] + n;
-            if (y.adaptive) gs[(half ? y.bTP : y.bSP) + r] = bw.g_b1[l] + n;
+            gs[(half ? y.bT : y.bS) + r] = sl.g_b1[l] + n;
+            gs[(half ? y.auxTb : y.auxSb) + r] = sl.g_b1[l] + n;
+            if (y.adaptive) gs[(half ? y.bTP : y.bSP) + r] = sl.g_b1[l] + n;
         }
-        for (int o = 0; o < C; ++o) { for (int c = 0; c < C; ++c) gs[y.res + (int64_t)o * C + c] = bw.g_wr[l] + o * C + c; gs[y.resb + o] = bw.g_br[l] + o; }
-        for (int s = 0; s < S; ++s) for (int c = 0; c < C; ++c) gs[y.skip + (int64_t)s * C + c] = bw.g_ws[l] + s * C + c;
+        for (int o = 0; o < C; ++o) { for (int c = 0; c < C; ++c) gs[y.res + (int64_t)o * C + c] = sl.g_wr[l] + o * C + c; gs[y.resb + o] = sl.g_br[l] + o; }
+        for (int s = 0; s < S; ++s) for (int c = 0; c < C; ++c) gs[y.skip + (int64_t)s * C + c] = sl.g_ws[l] + s * C + c;
     }
-    bw.g_bs = gtake(S);
-    for (int l = 0; l < L; ++l) for (int s = 0; s < S; ++s) gs[g.layers[l].skipb + s] = bw.g_bs + s;
-    bw.g_p1 = gtake(S * S); bw.g_bp1 = gtake(S); bw.g_p2 = gtake(Q * S); bw.g_bp2 = gtake(Q);
-    bw.g_early1 = go;
+    sl.g_bs = gtake(S);
+    for (int l = 0; l < L; ++l) for (int s = 0; s < S; ++s) gs[g.layers[l].skipb + s] = sl.g_bs + s;
+    sl.g_p1 = gtake(S * S); sl.g_bp1 = gtake(S); sl.g_p2 = gtake(Q * S); sl.g_bp2 = gtake(Q);
+    sl.g_early1 = go;
     // the post-net blocks close the flat parameter order (state_dict order, qpnet.py): with the trailer behind them one contiguous early bucket
     t->early_first = (g.post1_b == g.post1_w + (int64_t)S * S && g.post2_w == g.post1_b + S && g.post2_b == g.post2_w + (int64_t)Q * S && g.post2_b + Q == g.n_params) ? g.post1_w : -1;
-    for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = bw.g_p1 + o * S + s; gs[g.post1_b + o] = bw.g_bp1 + o; }
-    for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = bw.g_p2 + q * S + s; gs[g.post2_b + q] = bw.g_bp2 + q; }
+    for (int o = 0; o < S; ++o) { for (int s = 0; s < S; ++s) gs[g.post1_w + (int64_t)o * S + s] = sl.g_p1 + o * S + s; gs[g.post1_b + o] = sl.g_bp1 + o; }
+    for (int q = 0; q < Q; ++q) { for (int s = 0; s < S; ++s) gs[g.post2_w + (int64_t)q * S + s] = sl.g_p2 + q * S + s; gs[g.post2_b + q] = sl.g_bp2 + q; }
     // causal conv table: dW[c][q][tap] = sum_t dX0[t][c] * onehot(x[t-1+tap])[q] is one more time contraction (k_wgrad3 mode 4)
     // when its tiles fit (C = 64, Q a multiple of 128); otherwise the LDS-histogram kernel owns it (gs stays -1)
-    bw.g_cw = bw.g_cb = -1;
+    sl.g_cw = sl.g_cb = -1;
     if (C == 64 && Q % 128 == 0 && !t->use_gemm) {
-        bw.g_cw = gtake(2 * C * Q); bw.g_cb = gtake(C);
+        sl.g_cw = gtake(2 * C * Q); sl.g_cb = gtake(C);
         for (int c = 0; c < C; ++c) {
-            for (int q = 0; q < Q; ++q) for (int tp = 0; tp < 2; ++tp) gs[g.causal_w + ((int64_t)c * Q + q) * 2 + tp] = bw.g_cw + tp * C * Q + c * Q + q;
-            gs[g.causal_b + c] = bw.g_cb + c;
+            for (int q = 0; q < Q; ++q) for (int tp = 0; tp < 2; ++tp) gs[g.causal_w + ((int64_t)c * Q + q) * 2 + tp] = sl.g_cw + tp * C * Q + c * Q + q;
+            gs[g.causal_b + c] = sl.g_cb + c;
         }
     }
     bw.gstage = go; bw.nch = t->use_gemm ? 4 : 64; bw.n_params = g.n_params;
-    if (const char* e = getenv("QPN_WGRAD_CHUNKS")) { const int v = atoi(e); if (v >= 1 && v <= 512) bw.nch = v; }   // tuning knob: time chunks (= partial slabs)
+    if (t->knobs.wgrad_chunks > 0) bw.nch = t->knobs.wgrad_chunks;      // tuning knob: time chunks (= partial slabs)
     // the upsampling kernel's gradient is written by a dedicated kernel (gs stays -1)
 
     const size_t nmap = t->use_gemm ? 4 : map.size();      // (the GEMM path keeps its own K-major blocks)
@@ -349,18 +382,11 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));          // on the handle's device (current at this call)
     // the fork / join events only order kernels of THIS device's streams: no system-scope fence (cache write-back for the host) at each record
     // (QPN_EVENT_FENCE=1 restores it)
-    const unsigned evf = hipEventDisableTiming | ((getenv("QPN_EVENT_FENCE") && atoi(getenv("QPN_EVENT_FENCE")) == 1) ? 0u : (unsigned)hipEventDisableSystemFence);
+    const unsigned evf = hipEventDisableTiming | (t->knobs.event_fence ? 0u : (unsigned)hipEventDisableSystemFence);
     QPN_HIP(hipEventCreateWithFlags(&t->ev_fork, evf));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_join, evf));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_mid, evf));
     QPN_HIP(hipEventCreateWithFlags(&t->ev_early, evf));
-    if (getenv("QPN_TRAIN_SPLIT") && atoi(getenv("QPN_TRAIN_SPLIT")) == 1) {     // opt-in experiment: no extra hardware queue otherwise
-        QPN_HIP(hipStreamCreateWithFlags(&t->split.side, hipStreamNonBlocking));
-        for (int l = 0; l < TR_MAXL; ++l) QPN_HIP(hipEventCreateWithFlags(&t->split.ev[l], hipEventDisableTiming));
-        QPN_HIP(hipEventCreateWithFlags(&t->split.fork, hipEventDisableTiming));
-        QPN_HIP(hipEventCreateWithFlags(&t->split.join, hipEventDisableTiming));
-        t->have_split = true;
-    }
     h->train = t;
     return QPN_OK;
 }
@@ -378,10 +404,6 @@ void qpn_train_destroy(TrainState* t) {
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->ev_mid) (void)hipEventDestroy(t->ev_mid);
     if (t->ev_early) (void)hipEventDestroy(t->ev_early);
-    if (t->split.side) (void)hipStreamDestroy(t->split.side);
-    for (int l = 0; l < TR_MAXL; ++l) if (t->split.ev[l]) (void)hipEventDestroy(t->split.ev[l]);
-    if (t->split.fork) (void)hipEventDestroy(t->split.fork);
-    if (t->split.join) (void)hipEventDestroy(t->split.join);
     delete t;
 }
 
@@ -493,10 +515,10 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     qpn_prof_mark(PG_PREP, stream);
     t->fwd_valid = false; t->loss_clear = true;
     ++t->generation;
-    const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !getenv("QPN_CE_SEPARATE");
+    const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !t->knobs.ce_separate;
     p.ce_tgt = fuse_ce ? d_targets : nullptr; p.ce_stride = tgt_stride; p.ce_dlogits = d_dlogits; p.ce_loss = t->d_loss;
     if (fuse_ce && !want_logits) p.logits = nullptr;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->have_split ? &t->split : nullptr, &t->sqf, stream);
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->knobs, &t->sqf, stream);
     p.ce_tgt = nullptr; p.logits = d_logits;
     if (rc) return rc;
     t->fwd_valid = true;
@@ -676,7 +698,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     const bool first_bwd = t->bwd_generation != t->generation;
     t->bwd_generation = t->generation;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_)
-                       : qpn_launch_bwd(t->tp, bw, t->have_split ? &t->split : nullptr, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
+                       : qpn_launch_bwd(t->tp, bw, t->knobs, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream_) {

@@ -398,280 +398,6 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
     if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
 }
 
-// ------------------------------------------------------------------------------------------------ forward, one workgroup per CU
-// The same queue, tile body and arithmetic as k_stack_fwd, for ONE workgroup per CU (a wave per SIMD, the whole register file): with 256 tiles
-// in flight a producer is ~5 rounds ahead of its consumer and no look ever misses, but a lone workgroup has no partner to run its matrix
-// work under its memory / LDS / epilogue phases -- so the tile loop is software-pipelined inside the wave: while the gate contraction of
-// tile k issues, the epilogue of tile k-1 (sigma, tanh: VALU + LDS) and then its residual contraction, block output and stores run between the
-// MFMAs; the rows of tile k+1 are requested a whole tile ahead.  Per trip (three barriers, as before):
-//   a   As(k) staged                     | gate(k) first half  +  epilogue(k-1) -> Gs, SGs, THs           + flags / rows of tile k+1 requested
-//   b   Gs(k-1) complete                 | residual(k-1), gate(k) second half  +  Xs(k-1), sigma / tanh(k-1) out, publish point of tile k-2
-//   c   Xs(k-1) complete                 | block output of k-1 leaves (write-through); rows of k+1 -> As(k+1)   (three As buffers)
-// A look that misses (small problems: fewer tiles per layer than workgroups) FLUSHES the pipeline: tile k is finished without overlap, tiles
-// k-1 and k are published, and only then does the workgroup wait (the rule of k_stack_fwd: no wait while it holds finished, unpublished tiles).
-template <int KS>
-__global__ __launch_bounds__(256, 1) void k_stack_fwd1(TrainParams p, StackQ q) {
-    constexpr int C = 64, Ktp = 16 * KS;
-    constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;
-    extern __shared__ float sm[];
-    float* Gs = sm + 48 * lda;                                    // As buffers: sm + {0, 16, 32} * lda
-    float* SGs = Gs + 16 * ldg; float* THs = SGs + 16 * ldg; float* Xs = THs + 16 * ldg;
-    int* ctl = (int*)(Xs + 16 * ldg);          // [0..3] position ring, [4..7] per wave: the next tile's rows were NOT requested early, [8] arrivals at the publish point
-    const int Ap = p.Ap, N1 = p.N1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = sq_rfl(tid >> 6);
-    const int srow = tid >> 4, sc4 = tid & 15;
-    const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
-    const int orow = tid >> 5, oc2 = (tid & 31) * 2;
-    const int c = 16 * wave + (lane & 15);
-    const int arow = lane & 15, ak = lane >> 4;
-    float* const dmy = p.scratch_rows + (size_t)blockIdx.x * 2 * C + oc2;
-    const unsigned xbytes = (unsigned)N1 * C * 4u;
-    const size_t xlayer = (size_t)p.B * N1 * C;
-
-    // weights: the gate fragments of the layer of tile k; residual fragments and biases of the layers of tile k (_c) and of tile k-1 (_p)
-    float4 w1[KS][2], wr_c[4], wr_p[4];
-    float bs_c = 0.f, bt_c = 0.f, bb_c = 0.f, bs_p = 0.f, bt_p = 0.f, bb_p = 0.f;
-    auto load_weights = [&](int l) {
-        const TrLayer ly = p.layers[l];
-        const float4* W1 = p.wp + ly.w1_f4; const float4* Wr = p.wp + ly.wr_f4;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { w1[ks][0] = W1[((size_t)ks * 8 + wave) * 64 + lane]; w1[ks][1] = W1[((size_t)ks * 8 + 4 + wave) * 64 + lane]; }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wr_c[ks] = Wr[((size_t)ks * 4 + wave) * 64 + lane];
-        bs_c = p.bp[ly.bias1 + c]; bt_c = p.bp[ly.bias1 + C + c]; bb_c = p.bp[ly.biasr + c];
-    };
-    auto xrsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
-    int tp = 0; float4 rc, rp, ec, ep, ex;
-    auto load_tap = [&](const SqTile& d, int& out) { const int n = d.n0 + srow; out = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1]; };
-    auto load_x = [&](const SqTile& d, bool go, float4& oc_, float4& op_) {
-        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
-        const auto rs = xrsrc(p.X + (size_t)d.xrow * C);
-        const unsigned oc = go ? (__umul24((unsigned)nn, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
-        const unsigned op = go ? (__umul24((unsigned)tp, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)oc, 0, SQ_SC1);
-        const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)op, 0, SQ_SC1);
-        oc_ = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-        op_ = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
-    };
-    auto load_aux = [&](const SqTile& d) {
-        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
-        ex = *(const float4*)(p.HUP + (size_t)d.hrow * Ap + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
-    };
-    auto store_rows = [&](const SqTile& d, float* As, bool early) {
-        const bool in = d.n0 + srow < N1;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 vc = in ? (early ? ec : rc) : z, vp = in ? (early ? ep : rp) : z, vx = (in && aux_real) ? ex : z;
-        float* dd = As + (size_t)srow * lda + 4 * sc4;
-        *(float2*)dd = make_float2(vc.x, vc.y); *(float2*)(dd + 2) = make_float2(vc.z, vc.w);
-        *(float2*)(dd + C) = make_float2(vp.x, vp.y); *(float2*)(dd + C + 2) = make_float2(vp.z, vp.w);
-        if (aux_thread) { *(float2*)(dd + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(dd + 2 * C + 2) = make_float2(vx.z, vx.w); }
-    };
-    auto store_out = [&](const float* T, float* dst, int n0, bool go) {
-        const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
-        float* d0 = dst + (__umul24((unsigned)(n0 + orow), (unsigned)C) + oc2);
-        float* d1 = d0 + 8 * C;
-        d0 = (go && n0 + orow < N1) ? d0 : dmy;
-        d1 = (go && n0 + orow + 8 < N1) ? d1 : dmy + C;
-        *(float2*)d0 = v0; *(float2*)d1 = v1;
-    };
-    auto store_x = [&](const SqTile& d, bool go) {
-        const float2 v0 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4), v1 = *(const float2*)(Xs + (size_t)srow * ldg + 4 * sc4 + 2);
-        const int n = d.n0 + srow;
-        const unsigned o = (go && n < N1) ? (__umul24((unsigned)n, (unsigned)C) + 4u * sc4) * 4u : SQ_OOB;
-        const u32x4 v = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v1.x), __float_as_uint(v1.y)};
-        __builtin_amdgcn_raw_buffer_store_b128(v, xrsrc(p.X + (size_t)d.xrow * C + xlayer), (int)o, 0, SQ_SC1);
-    };
-    auto publishes = [&](const SqTile& d) { return sq_valid(d) && !sq_last(d); };
-#define SQ1_GATE(ks) \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][0].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][1].x, a1, 0, 0, 0); \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][0].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][1], w1[ks][1].y, a1, 0, 0, 0); \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][0].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][2], w1[ks][1].z, a1, 0, 0, 0); \
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][0].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], w1[ks][1].w, a1, 0, 0, 0);
-    // epilogue of a gate tile: sigma * tanh -> Gs (the residual contraction's operand), sigma and tanh -> SGs / THs (stored for the backward)
-    auto epilogue = [&](const f32x4& g0, const f32x4& g1, float bs, float bt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = (4 * (lane >> 4) + i) * ldg + c;
-            const float sg = sq_sigmoid(g0[i] + bs), th = sq_tanh(g1[i] + bt);
-            Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
-        }
-    };
-    // residual contraction of the tile whose gate is in Gs and whose rows are in Ab: block output -> Xs.  In three pieces, so that every LDS read
-    // of a block can be issued ahead of its MFMAs (left alone hipcc sinks each read to its use: an LDS round trip in front of every fourth MFMA)
-    float ga[4][4], xres[4];
-    f32x4 ar0, ar1;
-    auto residual_reads = [&](const float* Ab) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { const float* gp = Gs + (size_t)arow * ldg + 16 * ks + ak; ga[ks][0] = gp[0]; ga[ks][1] = gp[4]; ga[ks][2] = gp[8]; ga[ks][3] = gp[12]; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xres[i] = Ab[(size_t)(4 * (lane >> 4) + i) * lda + c];
-    };
-    auto residual_mfma = [&](const float4 (&wr)[4]) {
-        ar0 = (f32x4){0, 0, 0, 0}; ar1 = (f32x4){0, 0, 0, 0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ks += 2) {
-            ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][0], wr[ks].x, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][0], wr[ks + 1].x, ar1, 0, 0, 0);
-            ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][1], wr[ks].y, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][1], wr[ks + 1].y, ar1, 0, 0, 0);
-            ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][2], wr[ks].z, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][2], wr[ks + 1].z, ar1, 0, 0, 0);
-            ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
-        }
-    };
-    auto residual_write = [&](float bb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int r = 4 * (lane >> 4) + i; Xs[r * ldg + c] = ((ar0[i] + ar1[i]) + bb) + xres[i]; }
-    };
-    auto residual = [&](const float* Ab, const float4 (&wr)[4], float bb) { residual_reads(Ab); residual_mfma(wr); residual_write(bb); };
-    float2 so0, so1, so2, so3;
-    auto out_reads = [&]() {
-        so0 = *(const float2*)(SGs + (size_t)orow * ldg + oc2); so1 = *(const float2*)(SGs + (size_t)(orow + 8) * ldg + oc2);
-        so2 = *(const float2*)(THs + (size_t)orow * ldg + oc2); so3 = *(const float2*)(THs + (size_t)(orow + 8) * ldg + oc2);
-    };
-    auto out_stores = [&](const SqTile& d, bool go) {
-        float* sg0 = p.SG + (size_t)d.xrow * C + (__umul24((unsigned)(d.n0 + orow), (unsigned)C) + oc2);
-        float* th0 = p.TH + (size_t)d.xrow * C + (__umul24((unsigned)(d.n0 + orow), (unsigned)C) + oc2);
-        const bool in0 = go && d.n0 + orow < N1, in1 = go && d.n0 + orow + 8 < N1;
-        *(float2*)(in0 ? sg0 : dmy) = so0; *(float2*)(in1 ? sg0 + 8 * C : dmy + C) = so1;
-        *(float2*)(in0 ? th0 : dmy) = so2; *(float2*)(in1 ? th0 + 8 * C : dmy + C) = so3;
-    };
-
-    int zero_v; asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
-    const int NQ = q.nq, sub = (blockIdx.x / 8) % NQ;
-    unsigned* const head = q.head + sub * TR_QHEAD_STRIDE + zero_v;
-    if (tid == 0) {
-        ctl[8] = 0;
-        const unsigned k0 = atomicAdd(head, 1u); ctl[0] = (int)(k0 * NQ + sub);
-        asm volatile("" ::: "memory");
-        const unsigned k1 = atomicAdd(head, 1u); ctl[1] = (int)(k1 * NQ + sub);
-        asm volatile("" ::: "memory");
-        const unsigned k2 = atomicAdd(head, 1u); ctl[2] = (int)(k2 * NQ + sub);
-    }
-    __syncthreads();
-    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1]))), nn = sq_take(sq_fetch(q, sq_rfl(ctl[2])));
-    if (!sq_valid(cur)) return;
-    SqTile prev = cur; prev.meta = 0;        // tile k-1: in the pipeline (epilogue, residual, output pending)
-    SqTile pp = prev;                        // tile k-2: its block output has left, not yet published
-    int lw = sq_layer(cur);
-    load_weights(lw);
-    load_tap(cur, tp);
-    sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
-    load_x(cur, true, rc, rp); load_aux(cur);
-    store_rows(cur, sm, false);
-    load_tap(next, tp);
-    f32x4 g0 = (f32x4){0, 0, 0, 0}, g1 = (f32x4){0, 0, 0, 0};        // gate accumulators of tile k-1
-    int bufc = 0;                                                     // As buffer of tile k (k-1: bufc - 1, k+1: bufc + 1, mod 3)
-    for (int it = 0;; ++it) {
-        float* Ac = sm + bufc * 16 * lda;
-        float* Ap_ = sm + (bufc == 0 ? 2 : bufc - 1) * 16 * lda;
-        float* An = sm + (bufc == 2 ? 0 : bufc + 1) * 16 * lda;
-        SQ_STAMP(0);
-        unsigned rtk = 0;
-        if (tid == 0) rtk = atomicAdd(head, 1u);
-        int tpn; load_tap(nn, tpn);
-        TR_LDS_BARRIER();                                          // a: As(k) complete; Gs / SGs / THs free
-        SQ_STAMP(1);
-        // ---- block 1: first look for tile k+1, gate(k) first half, epilogue(k-1)
-        const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;
-        unsigned fe0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fe1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
-        asm volatile("" ::: "memory");
-        float xa[KS][4];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { const float* ap = Ac + (size_t)arow * lda + 16 * ks + ak; xa[ks][0] = ap[0]; xa[ks][1] = ap[4]; xa[ks][2] = ap[8]; xa[ks][3] = ap[12]; }
-        __builtin_amdgcn_sched_barrier(0);                        // every fragment read of the tile issued ahead of its MFMAs
-        f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
-        SQ1_GATE(0) SQ1_GATE(1) SQ1_GATE(2)
-        epilogue(g0, g1, bs_p, bt_p);
-        SQ1_GATE(3) SQ1_GATE(4) SQ1_GATE(5)
-        __builtin_amdgcn_sched_barrier(0);                        // (the look waits for every request of the wave: behind the block's MFMAs)
-        SQ_STAMP(2);
-        asm volatile("" : "+v"(fe0), "+v"(fe1));
-        const bool early = fn == 0 || (fn <= 128 && __all(fe0 == q.epoch && fe1 == q.epoch));
-        load_x(next, early, ec, ep); load_aux(next);             // the rows of tile k+1: a whole tile ahead of their use
-        if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
-        if (lane == 0) ctl[4 + wave] = early ? 0 : 1;
-        SQ_STAMP(3);
-        TR_LDS_BARRIER();                                          // b: Gs(k-1) complete
-        SQ_STAMP(4);
-        // ---- block 2: residual(k-1), gate(k) second half, publish point of tile k-2, outputs of tile k-1
-        // publish point: younger than the block output of tile k-2 (it left at the end of the previous trip) are the tap, the two flag words and
-        // the three early row requests (and, in wave 0, the ticket): counted wait for everything older than the six youngest
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        if (lane == 0) {
-            const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old & 3) == 3 && publishes(pp)) sq_st(q.flags + sq_fidx((unsigned)pp.pos), q.epoch_pub);
-        }
-        const SqRaw raw3 = sq_fetch(q, sq_rfl(ctl[(it + 3) & 3]));
-        residual_reads(Ap_); out_reads();
-        __builtin_amdgcn_sched_barrier(0);
-        residual_mfma(wr_p);
-        SQ1_GATE(6) SQ1_GATE(7)
-        residual_write(bb_p);
-        SQ1_GATE(8)
-        out_stores(prev, sq_valid(prev));
-        SQ1_GATE(9) SQ1_GATE(10)
-        __builtin_amdgcn_sched_barrier(0);
-        const int any_late = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
-        SQ_STAMP(5);
-        TR_LDS_BARRIER();                                          // c: Xs(k-1) complete
-        SQ_STAMP(6);
-        // ---- block 3: the block output of tile k-1 leaves; the rows of tile k+1 are staged
-        bool flushed = false;
-        if (any_late) {
-            store_x(prev, publishes(prev));
-            // some wave's look missed: flush the pipeline (finish tile k without overlap), publish tiles k-1 and k, THEN wait
-            if (tid == 0) atomicAdd(q.stats, 1u);
-            epilogue(a0, a1, bs_c, bt_c);
-            TR_LDS_BARRIER();
-            residual(Ac, wr_c, bb_c);
-            out_reads(); out_stores(cur, true);
-            TR_LDS_BARRIER();
-            store_x(cur, publishes(cur));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TR_LDS_BARRIER();
-            if (tid == 0) {
-                if (publishes(pp)) sq_st(q.flags + sq_fidx((unsigned)pp.pos), q.epoch_pub);      // (idempotent: the publish point may have stored it already)
-                if (publishes(prev)) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
-                if (publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch_pub);
-            }
-            if (!early) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
-            flushed = true;
-        }
-        load_x(next, !early, rc, rp);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!any_late) store_x(prev, publishes(prev));           // (behind the row requests: vmcnt counts in order)
-        store_rows(next, An, early);
-        SQ_STAMP(7);
-        // ---- rotate: tile k becomes tile k-1 of the next trip (an invalid one after a flush: its work is done and published)
-        tp = tpn;
-        pp = prev; prev = cur; cur = next; next = nn; nn = sq_take(raw3);
-        if (flushed) { pp.meta = 0; prev.meta = 0; }
-        g0 = a0; g1 = a1;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) wr_p[ks] = wr_c[ks];
-        bs_p = bs_c; bt_p = bt_c; bb_p = bb_c;
-        bufc = bufc == 2 ? 0 : bufc + 1;
-        if (!sq_valid(cur)) break;
-        if (sq_layer(cur) != lw) { lw = sq_layer(cur); load_weights(lw); }
-    }
-    // ---- drain: tile k-1 (if any) still has its epilogue, residual and output to do; tile k-2 is unpublished
-    {
-        float* Ap_ = sm + (bufc == 0 ? 2 : bufc - 1) * 16 * lda;
-        TR_LDS_BARRIER();
-        epilogue(g0, g1, bs_p, bt_p);
-        TR_LDS_BARRIER();
-        residual(Ap_, wr_p, bb_p);
-        out_reads(); out_stores(prev, sq_valid(prev));
-        TR_LDS_BARRIER();
-        store_x(prev, publishes(prev));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TR_LDS_BARRIER();
-        if (tid == 0) {
-            if (publishes(pp)) sq_st(q.flags + sq_fidx((unsigned)pp.pos), q.epoch_pub);
-            if (publishes(prev)) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
-        }
-    }
-#undef SQ1_GATE
-}
-
 // ------------------------------------------------------------------------------------------------ backward
 // The layer backward of k_layer_bwd_p (train_bwd.hip: dg = dXout . Wr^T + skip-path grads, dz = dg * gate', d[x_cur | x_past | aux] = dZ . W1^T,
 // the pitch-tap part scattered to its tap rows) over the same kind of queue, layers from the last to the first.  What is handed between
@@ -998,14 +724,17 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// tests/test_train_gpu.py::test_stack_queue_that_gives_up_...: QPN_TEST_STACK_GIVES_UP=1 makes the published flags carry another value than the
-// consumers expect and shortens the waits, so the first dependent tile runs out, raises the abort word and the launch drains
-static void sq_test_hook(StackQ& q) {
+// tests/test_train_gpu.py::test_stack_queue_that_gives_up_... (a -DQPN_TESTING build, QPN_TEST_STACK_GIVES_UP=1): the published flags carry another
+// value than the consumers expect and the waits are short, so the first dependent tile runs out, raises the abort word and the launch drains
+static void sq_arm(StackQ& q, const TrainKnobs& k) {
     q.epoch_pub = q.epoch; q.spin_limit = SQ_SPIN_LIMIT;
-    if (const char* e = getenv("QPN_TEST_STACK_GIVES_UP")) if (atoi(e) == 1) { q.epoch_pub = q.epoch ^ 0x55555555u; q.spin_limit = 2000u; }
+#ifdef QPN_TESTING
+    if (k.test_stack_gives_up) { q.epoch_pub = q.epoch ^ 0x55555555u; q.spin_limit = 2000u; }
+#else
+    (void)k;
+#endif
 }
 bool qpn_stack_fwd_fits(const TrainParams& p) {
-    if (getenv("QPN_STACK_QUEUE") && atoi(getenv("QPN_STACK_QUEUE")) == 0) return false;
     return p.C == 64 && p.Ktp == 176 && p.L >= 1 && p.L <= TR_MAXL && p.B < 65536 && (int64_t)p.N1 * p.C * 4 <= (1ll << 30) &&
            (int64_t)(p.L + 1) * p.B * p.N1 < (1ll << 31);
 }
@@ -1021,50 +750,43 @@ void qpn_stack_fill(TrainParams& p) {
     p.qtotal = pos;
 }
 
-int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, hipStream_t stream) {
-    constexpr int lda = ((176 + 29) / 32) * 32 + 2, ldg = ((64 + 29) / 32) * 32 + 2;
+template <int KS>
+static int launch_stack_fwd_k(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
+    constexpr int lda = ((16 * KS + 29) / 32) * 32 + 2, ldg = ((64 + 29) / 32) * 32 + 2;
     const size_t lds = (size_t)(32 * lda + 4 * 16 * ldg) * sizeof(float) + 64;
-    int G = qpn_num_cus() * 2;
-    if (const char* e = getenv("QPN_STACK_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 4096) G = v; }
+    int G = k.stack_wgs > 0 ? k.stack_wgs : qpn_num_cus() * 2;
     if (G > q.total) G = q.total;
     if (G > 1024) G = 1024;                                      // (scratch rows: one pair per workgroup)
-    const bool one_per_cu = getenv("QPN_STACK_FWD1") && atoi(getenv("QPN_STACK_FWD1")) == 1;
-    if (one_per_cu) {      // the software-pipelined form: one workgroup per CU
-        const size_t lds1 = (size_t)(48 * lda + 4 * 16 * ldg) * sizeof(float) + 64;
-        int G1 = qpn_num_cus();
-        if (const char* e = getenv("QPN_STACK_WGS")) { const int v = atoi(e); if (v >= 1 && v <= 1024) G1 = v; }
-        if (G1 > q.total) G1 = q.total;
-        QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd1<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        StackQ q1 = q; q1.nq = G1 / 8 < 1 ? 1 : (G1 / 8 < SQ_NQ ? G1 / 8 : SQ_NQ);
-        sq_test_hook(q1);
-        hipLaunchKernelGGL((k_stack_fwd1<11>), dim3(G1), dim3(256), lds1, stream, p, q1);
-        return QPN_OK;
-    }
-    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_fwd<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);      // every sub-queue needs a puller (a workgroup's home: (blockIdx / 8) % nq)
-    sq_test_hook(qq);
-    hipLaunchKernelGGL((k_stack_fwd<11>), dim3(G), dim3(256), lds, stream, p, qq);
+    sq_arm(qq, k);
+    hipLaunchKernelGGL((k_stack_fwd<KS>), dim3(G), dim3(256), lds, stream, p, qq);
     return QPN_OK;
+}
+int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
+    return launch_stack_fwd_k<11>(p, q, k, stream);
 }
 
 bool qpn_stack_bwd_fits(const TrainParams& p) {
-    if (getenv("QPN_STACK_QUEUE_BWD") && atoi(getenv("QPN_STACK_QUEUE_BWD")) == 0) return false;
     return qpn_stack_fwd_fits(p) && p.Ap <= 64 && (int64_t)p.B * p.BL * p.LC < (1ll << 31) && (int64_t)p.N1 * (p.LC > 2 * p.C ? p.LC : 2 * p.C) < (1ll << 32);
 }
 
-int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, hipStream_t stream) {
-    constexpr int ldx = ((64 + 29) / 32) * 32 + 2, ldz = ((128 + 29) / 32) * 32 + 2, ldo = ((176 + 29) / 32) * 32 + 2;
+template <int NTK>
+static int launch_stack_bwd_k(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
+    constexpr int ldx = ((64 + 29) / 32) * 32 + 2, ldz = ((128 + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 128;
     // 1.5 workgroups per CU: the skip / post-net weight gradients run on the side stream while this launch is resident (qpn_launch_bwd), and a
     // launch that fills every CU twice over leaves them no room -- measured on the overlapped step: 0.846 ms with 2 per CU, 0.776 with 1.5,
     // 0.778 with 1, 0.790 for the eight per-layer launches
-    int G = qpn_num_cus() * 3 / 2;
-    if (const char* e = getenv("QPN_STACK_WGS_BWD")) { const int v = atoi(e); if (v >= 1 && v <= 4096) G = v; }
+    int G = k.stack_wgs_bwd > 0 ? k.stack_wgs_bwd : qpn_num_cus() * 3 / 2;
     if (G > q.total) G = q.total;
     if (G > 1024) G = 1024;
-    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_bwd<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QPN_HIP(hipFuncSetAttribute((const void*)k_stack_bwd<NTK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     StackQ qq = q; qq.nq = G / 8 < 1 ? 1 : (G / 8 < SQ_NQ ? G / 8 : SQ_NQ);
-    sq_test_hook(qq);
-    hipLaunchKernelGGL((k_stack_bwd<11>), dim3(G), dim3(256), lds, stream, p, bw, qq);
+    sq_arm(qq, k);
+    hipLaunchKernelGGL((k_stack_bwd<NTK>), dim3(G), dim3(256), lds, stream, p, bw, qq);
     return QPN_OK;
+}
+int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
+    return launch_stack_bwd_k<11>(p, bw, q, k, stream);
 }
