@@ -85,12 +85,24 @@ def max_over_ranks(v, world, dev):
 
 def measured_traffic():
     """HBM traffic measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (committed under profiles/)."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
             d["_file"] = "profiles/" + name
             return d
+        except Exception:
+            continue
+    return None
+
+
+def measured_pmc():
+    """matrix-core busy fraction per kernel (SQ_VALU_MFMA_BUSY_CYCLES pass, committed under profiles/): {rocprof kernel name: fraction}."""
+    for name in ("r05_pmc_by_kernel.json",):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return {k: v.get("mfma_busy") for k, v in d.get("train", d).items() if isinstance(v, dict)}
         except Exception:
             continue
     return None
@@ -217,24 +229,50 @@ def run_decode(args, rank, local, world):
     return out
 
 
-PG_NAMES = ["prep+pack", "k_layer_fwd", "k_post_fwd", "k_ce", "k_post_bwd", "k_wgrad", "k_layer_bwd", "grad_tail", "k_adam", "allreduce"]
+# profile groups of libqpnet_hip (include/qpnet_hip.h, QPN_PG_*): one per LAUNCH of the heavy kernels
+PG_NAMES = ["prep+pack", "k_layer_fwd", "k_post_fwd", "k_ce", "k_post_bwd", "k_wgrad_w1", "k_layer_bwd", "grad_tail", "k_adam", "allreduce",
+            "k_wgrad_wr", "k_wgrad_skip", "k_wgrad_post", "k_wgrad_causal"]
+PG_WGRAD = (5, 10, 11, 12, 13)          # the five weight-gradient launches (the "k_wgrad" group of earlier rounds)
 
 
-def train_flops(cfg, N1, BL, starts_out):
-    """Algorithmic FLOPs (2 x MACs, padding excluded) of one training step per kernel group
-    (per-row MACs x exact per-layer row counts)."""
+def pg_kernel_names(hoist):
+    """rocprofv3's kernel names of the launches behind each profile group (paper-size geometry; profiles/r05_train_kernel_stats.csv)."""
+    ks = 8 if hoist else 11
+    return {1: "k_stack_fwd<%d>" % ks, 2: "k_post_fwd_w<5>", 4: "k_post_bwd_w<5>", 5: "k_wgrad3<3, 2, %d, false, 1>" % ks, 6: "k_stack_bwd<%d>" % ks,
+            10: "k_wgrad3<2, 1, 4, true, 1>", 11: "k_wgrad3<2, 4, 4, false, 2>", 12: "k_wgrad3<1, 4, 4, false, 2>", 13: "k_wgrad3<4, 1, 4, true, 1>"}
+
+
+def train_flops(cfg, N1, BL, starts_out, hoist):
+    """FLOPs (2 x MACs) of one training step per profile group, two ways:
+      algorithmic -- SURVEY.md section 8d: per-row MACs of the reference's layers x exact per-layer row counts, padding excluded (the aux 1x1 at
+                     SAMPLE rate, as the reference computes it);
+      executed    -- what the matrix cores are asked to do here: with the auxiliary 1x1 hoisted to frame rate the gate contraction is
+                     K = 2C plus one 4-deep step, its backward has no aux columns (+ eight 16x16x4 MFMAs per wave and tile for the frame-rate
+                     accumulators), dW1 is 2C x 2C; without the hoist the aux columns are padded from 39 to 48.
+    roofline fractions use the EXECUTED count (a kernel is not credited with work it no longer does)."""
     C, S, Q, A = cfg.n_resch, cfg.n_skipch, cfg.n_quantize, cfg.n_aux
     L = len(starts_out)
-    Kt = 2 * C + A
     rows = [N1 - s for s in starts_out]
-    lf = sum(r * (Kt * 2 * C + (C * C if i < L - 1 else 0)) for i, r in enumerate(rows))
-    pf = BL * (L * C * S + S * S + S * Q)
-    pb = BL * (Q * S + S * S + S * L * C)
-    wg = BL * (Q * S + S * S + L * S * C) + sum(r * (2 * C * Kt + (C * C if i < L - 1 else 0)) for i, r in enumerate(rows))
-    lb = sum(r * ((C * C if i < L - 1 else 0) + 2 * C * Kt) for i, r in enumerate(rows))
-    g = [0.0] * len(PG_NAMES)
-    g[1], g[2], g[4], g[5], g[6] = 2.0 * lf, 2.0 * pf, 2.0 * pb, 2.0 * wg, 2.0 * lb
-    return g
+    res = [C * C if i < L - 1 else 0 for i in range(L)]
+
+    def groups(kf, kb, kw, extra_b):
+        g = [0.0] * len(PG_NAMES)
+        g[1] = 2.0 * sum(r * (kf * 2 * C + res[i]) for i, r in enumerate(rows))
+        g[2] = 2.0 * BL * (L * C * S + S * S + S * Q)
+        g[4] = 2.0 * BL * (Q * S + S * S + S * L * C)
+        g[5] = 2.0 * sum(r * 2 * C * kw for r in rows)
+        g[6] = 2.0 * sum(r * (res[i] + 2 * C * kb + extra_b) for i, r in enumerate(rows))
+        g[10] = 2.0 * sum(r * res[i] for i, r in enumerate(rows))
+        g[11] = 2.0 * BL * L * S * C
+        g[12] = 2.0 * BL * (Q * S + S * S)
+        return g
+    algo = groups(2 * C + A, 2 * C + A, 2 * C + A, 0)
+    if hoist:
+        execd = groups(2 * C + 4, 2 * C, 2 * C, 32 * 16 * 16 * 4 // 16)      # (32 MFMAs of 16x16x4 per 16-row tile)
+    else:
+        ap = (A + 15) // 16 * 16
+        execd = groups(2 * C + ap, 2 * C + ap, 2 * C + ap, 0)
+    return algo, execd
 
 
 def cpu_baseline_train(cfg, flat, batch):
@@ -399,10 +437,23 @@ def run_train(args, rank, local, world):
         s_ += dil; starts.append(s_)
     for dil in cfg.dilationsA:
         s_ += dil * maxd; starts.append(s_)
-    fl = train_flops(cfg, N1, BL, starts)
-    dom = int(np.argmax(ms[:9]))                  # dominant COMPUTE group (the all-reduce is reported beside it)
-    achieved = fl[dom] / (ms[dom] * 1e-3) / 1e12 if ms[dom] > 0 else 0.0
-    total_flops = sum(fl)
+    hoist = os.environ.get("QPN_AUX_HOIST", "1") != "0"
+    fl_algo, fl = train_flops(cfg, N1, BL, starts, hoist)
+    knames = pg_kernel_names(hoist)
+    tr_meas = measured_traffic() or {}
+    pmc = measured_pmc() or {}
+    kernels = []
+    for gidx, kname in knames.items():
+        if ms[gidx] <= 0:
+            continue
+        tfl = fl[gidx] / (ms[gidx] * 1e-3) / 1e12
+        kernels.append({"name": kname, "group": PG_NAMES[gidx], "us": round(ms[gidx] * 1e3, 1), "gflop": round(fl[gidx] / 1e9, 3),
+                        "gflop_algorithmic": round(fl_algo[gidx] / 1e9, 3), "tflops": round(tfl, 1), "frac": round(tfl / F32_MFMA_PEAK_TFLOPS, 3),
+                        "mfma_busy": pmc.get(kname), "hbm_bytes": tr_meas.get("train", {}).get("hbm_bytes_by_kernel", {}).get(kname)})
+    kernels.sort(key=lambda k: -k["us"])
+    dom = kernels[0]                               # the single longest kernel of the step (per-launch HIP events on the launch stream)
+    wg_ms = sum(ms[i] for i in PG_WGRAD); wg_fl = sum(fl[i] for i in PG_WGRAD)
+    total_flops, total_algo = sum(fl), sum(fl_algo)
     value = args.steps * world / dt
     out = {
         "metric": "train steps/sec (batch-1 chunk-steps of RF+20000 samples, aggregate over GPUs)",
@@ -412,26 +463,30 @@ def run_train(args, rank, local, world):
         "config": {"workload": "config[1]: paper-size SI-QPNet (C=64,S=256,4F+4A) training step, forward+CE+backward+Adam on one chunk "
                                "of %d samples (RF %d + batch_length %d), batch 1 per GPU" % (x0.shape[1], N1 + 1 - BL, BL),
                    "global_batch": world, "parallelism": "dp%d (utterance-sharded chunks, one flat-gradient all-reduce per step)" % world,
-                   "backend": BACKEND, "world_size": (dist.get_world_size() if dist.is_initialized() else 1)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / F32_MFMA_PEAK_TFLOPS,
-                     "traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_by_group", {}).get(PG_NAMES[dom],
-                                    (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step") if PG_NAMES[dom] == "k_wgrad" else None),
-                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this command, the launches of the named group in one step; commit %s)"
-                                       % ((measured_traffic() or {}).get("_file"), (measured_traffic() or {}).get("commit", "?")),
-                     "step_traffic": (measured_traffic() or {}).get("train", {}).get("hbm_bytes_per_step_all_kernels"),
-                     "kernel": PG_NAMES[dom],
-                     "kernel_ms": ms[dom], "flops_per_launch_group": fl[dom],
+                   "backend": BACKEND, "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+                   "aux_1x1": "frame rate (hoisted: K = 128 + one 4-deep step)" if hoist else "sample rate (K = 176)"},
+        "roofline": {"bound": "mfma", "achieved": dom["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": dom["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                     "traffic": dom["hbm_bytes"],
+                     "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per kernel and launch; commit %s)"
+                                       % (tr_meas.get("_file"), tr_meas.get("commit", "?")),
+                     "step_traffic": tr_meas.get("train", {}).get("hbm_bytes_per_step_all_kernels"),
+                     "kernel": dom["name"], "kernel_ms": dom["us"] / 1e3, "flops_per_launch": dom["gflop"] * 1e9,
+                     # every heavy kernel of the step, longest first: us from HIP events around the launch (one stream), gflop = EXECUTED FLOPs,
+                     # mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES fraction from the committed PMC pass (profiles/), hbm_bytes per launch likewise
+                     "kernels": kernels[:8],
+                     "wgrad_group": {"launches": 5, "ms": round(wg_ms, 4), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms > 0 else None,
+                                     "frac": round(wg_fl / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3) if wg_ms > 0 else None},
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
-                     # the whole step against the same peak: algorithmic FLOPs of every group / the timed loop's ms_per_step
-                     "step_flops": total_flops, "step_achieved": total_flops / (dt / args.steps) / 1e12,
+                     # the whole step against the same peak: executed FLOPs of every group / the timed loop's ms_per_step
+                     "step_flops": total_flops, "step_flops_algorithmic": total_algo, "step_achieved": total_flops / (dt / args.steps) / 1e12,
                      "step_frac": total_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                     "step_frac_algorithmic": total_algo / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
-                     "note": "achieved = algorithmic FLOPs of the dominant kernel group (all its launches in one step) / its summed "
-                             "device time from HIP events on the launch stream; step_tflops = whole step.  Groups are timed on ONE stream; "
-                             "the timed steps run the skip / post-net weight gradients and the early slab reduction on a side stream under the layer "
-                             "backward, and there those two launches use 48 time chunks instead of the one-stream 64 (each slower alone -- 70 vs 59 us -- "
-                             "the overlapped step faster: 0.760 vs 0.772 ms)"},
+                     "note": "roofline.kernel = the single longest kernel of the step; achieved = its EXECUTED FLOPs / its device time from HIP events "
+                             "around the launch (the profile step runs on ONE stream; the timed steps run the skip / post-net weight gradients, the early "
+                             "slab reduction and the aux-gradient tail on a side stream under the layer backward).  step_frac counts executed FLOPs over the "
+                             "timed loop's ms_per_step; step_frac_algorithmic credits the reference's sample-rate aux 1x1 (SURVEY 8d) instead."},
     }
     if world == 1 and not args.no_cpu:
         # the drop-in path north_star describes: the reference's own loop on this module (weights keep training; timing only)
@@ -490,13 +545,16 @@ def run_default_geometry(local):
         s_ += dil; starts.append(s_)
     for dil in cfg.dilationsA:
         s_ += dil * maxd; starts.append(s_)
-    fl = train_flops(cfg, N1, BL, starts)
+    fl, _ = train_flops(cfg, N1, BL, starts, False)          # algorithmic FLOPs; the GEMM path marks all its weight gradients as one group
+    fl[5] = sum(fl[i] for i in PG_WGRAD)
+    for i in PG_WGRAD[1:]:
+        fl[i] = 0.0
     out = {"geometry": "repo default: C=512, S=256, F=[1,2,4,8]x3, A=[1,2,4,8], 24151151 parameters",
            "train": {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "tflop_per_step": sum(fl) / 1e12,
                      "roofline": {"bound": "mfma", "achieved": sum(fl) / dt / 1e12, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": sum(fl) / dt / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                   "groups_ms": dict(zip(PG_NAMES, [round(v, 3) for v in ms])),
-                                  "groups_tflops": {k: round(f / (v * 1e-3) / 1e12, 1) for k, v, f in zip(PG_NAMES, ms, fl + [0.0]) if f > 0 and v > 0}},
+                                  "groups_tflops": {k: round(f / (v * 1e-3) / 1e12, 1) for k, v, f in zip(PG_NAMES, ms, fl) if f > 0 and v > 0}},
                      "reference_cpu_s_per_step": 17.9}}
     del tr, bt
     m = m.eval()

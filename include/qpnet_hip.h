@@ -193,8 +193,11 @@ int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d
                      int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                      const float* d_grad_denominator, void* stream);
 
-/* Per-kernel-group device timings of the training calls issued between begin and end (HIP events on
- * `stream`; used by bench.py for the roofline).  h_ms[QPN_PG_*] receives milliseconds. */
+/* Per-launch-group device timings of the training calls issued between begin and end (HIP events on `stream`; used by bench.py for
+ * the roofline).  h_ms[QPN_PG_*] receives milliseconds.  While a profile is being taken a step runs on ONE stream, and every heavy
+ * kernel is a group of its own: LAYER_FWD / LAYER_BWD = the residual stack (one work-queue launch each at n_resch 64), WGRAD = the
+ * gate contraction's weight gradient, WGRAD_WR / _SKIP / _POST / _CAUSAL = the residual 1x1's, the skip 1x1's, the post-net pair's and
+ * the causal table's. */
 #define QPN_PG_PREP 0
 #define QPN_PG_LAYER_FWD 1
 #define QPN_PG_POST_FWD 2
@@ -205,7 +208,11 @@ int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d
 #define QPN_PG_GRAD_TAIL 7
 #define QPN_PG_ADAM 8
 #define QPN_PG_ALLREDUCE 9     /* marked by the caller after its gradient all-reduce (qpn_train_profile_mark) */
-#define QPN_PG_COUNT 10
+#define QPN_PG_WGRAD_WR 10
+#define QPN_PG_WGRAD_SKIP 11
+#define QPN_PG_WGRAD_POST 12
+#define QPN_PG_WGRAD_CAUSAL 13
+#define QPN_PG_COUNT 14
 /* Diagnostics of the one-launch residual stack (csrc/train_stack.hip; no reference counterpart): the first n <= 1024 control words of
  * the work queues as the last step left them -- [1] abort raised; forward [4..6] / backward [8..10]: escalations (a workgroup published
  * everything it held before waiting without a bound), polls spent waiting, waves that did not find their producers' flags at first look.  Synchronises the stream. */

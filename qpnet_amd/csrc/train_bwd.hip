@@ -389,10 +389,12 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     constexpr int C = 64;
     constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     constexpr int NJ = (NTK + 3) / 4;                              // column tiles of the second contraction per wave
+    constexpr bool HOIST = NTK == 8;                               // the auxiliary 1x1 at frame rate (TrainParams::hoist): D / G instead of the aux columns (train_common.h, tr_aux_bwd)
     extern __shared__ float sm[];
-    // two staging buffers {Dx | Sg | Th | Dg}, [16][ldx] each; Dz [16][ldz]; Os [16][ldo] (the second contraction's outputs)
+    // two staging buffers {Dx | Sg | Th | Dg}, [16][ldx] each; Dz [16][ldz]; Os [16][ldo] (the second contraction's outputs); hoist: Gp [4][16]
     float* Dz = sm + 8 * 16 * ldx;
     float* Os = Dz + 16 * ldz;
+    float* Gp = Os + 16 * ldo;
     const TrLayer ly = p.layers[l];
     const int Ap = p.Ap, N1 = p.N1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -410,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     const int win0 = N1 - p.BL;
     const float* DGS = bw.DGS + (size_t)b * p.BL * p.LC + (size_t)l * C;
     float* DZg = bw.DZ + ((size_t)l * p.B * N1 + rb) * 2 * C;
-    float* DH = bw.DHUP + rb * Ap;
+    float* DH = HOIST ? nullptr : bw.DHUP + rb * Ap;
+    float* GWl = HOIST ? bw.GW + (size_t)(l * p.B + b) * N1 : nullptr;
     const int* taps = p.TAP + ly.tap_off + rb;
     // ---- resident weight fragments
     const float4* Wrt = p.wp + ly.wrt_f4; const float4* W1t = p.wp + ly.w1t_f4;
@@ -458,7 +461,19 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int n = ly.s_out + t * 16 + 4 * wave + i; tp[i] = taps[n < N1 ? n : N1 - 1]; }
     };
+    // aux hoist: the WJ entries of this lane's four dZ rows and its four PA values -- c*: the tile in hand, n*: the next tile's, in flight
+    float2 cwj[4], nwj[4]; float cpa[4], npa[4]; int cpoff = 0, npoff = 0;
+    auto load_aux = [&](int t, float2 (&wj)[4], float (&pa)[4], int& poff) {
+        const int n0 = ly.s_out + t * 16;
+        poff = tr_pa_off(p, l, b, n0);
+        const float2* w = p.WJ + n0 + 4 * (lane >> 4);             // (16 rows of padding behind row N1 - 1)
+        const float* q4 = p.PA + poff + 16 * wave + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wj[i] = w[i];
+        pa[0] = q4[0]; pa[1] = q4[C]; pa[2] = q4[2 * C]; pa[3] = q4[3 * C];
+    };
     load_rows(t_first);
+    if constexpr (HOIST) load_aux(t_first, cwj, cpa, cpoff);
     load_taps(t_first, tprow);
     store_rows(t_first, sm);
     const int arow = lane & 15, ak = lane >> 4;
@@ -466,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
     for (int ti = 0; ti < t_count; ++ti) {
         const int t = t_first + ti, n0 = ly.s_out + t * 16;
         float* Dx = sm + (ti & 1) * 4 * 16 * ldx; float* Sg = Dx + 16 * ldx; float* Th = Sg + 16 * ldx; float* Dg = Th + 16 * ldx;
-        { const int tn = t + 1 < t_last ? t + 1 : t_last; load_rows(tn); load_taps(tn, tpnext); }      // (past the range: a harmless reload)
+        { const int tn = t + 1 < t_last ? t + 1 : t_last; load_rows(tn); load_taps(tn, tpnext); if constexpr (HOIST) load_aux(tn, nwj, npa, npoff); }      // (past the range: a harmless reload)
         TR_LDS_BARRIER();                                          // this tile's staged rows complete; Dz / Os free (readers: previous trip)
         // ---- dg = dXout . Wr + DGS ; dz = dg * gate'
         float xa[4][4];
@@ -483,13 +498,23 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
                 a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][3], wr[ks].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks + 1][3], wr[ks + 1].w, a1, 0, 0, 0);
             }
         }
+        float dzs[4], dzt[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * (lane >> 4) + i;
             const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
             const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-            Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
-            Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
+            dzs[i] = dg * th * sg * (1.0f - sg); dzt[i] = dg * sg * (1.0f - th * th);
+            Dz[(size_t)r * ldz + c] = dzs[i];
+            Dz[(size_t)r * ldz + C + c] = dzt[i];
+        }
+        float dacc[4] = {0.f, 0.f, 0.f, 0.f}, eacc[2] = {0.f, 0.f};
+        if constexpr (HOIST) {      // the frame-rate aux term's backward (same arithmetic as k_stack_bwd)
+            const TrAuxBwd ab = tr_aux_bwd(cwj, cpa, dzs, dzt, lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dacc[k] = ab.d[k];
+            eacc[0] = ab.e[0]; eacc[1] = ab.e[1];
+            if ((lane & 15) == 0) { float* gq = Gp + 16 * wave + 4 * (lane >> 4); gq[0] = ab.gp[0]; gq[1] = ab.gp[1]; gq[2] = ab.gp[2]; gq[3] = ab.gp[3]; }
         }
         TR_LDS_BARRIER();
         // ---- d[x_cur | x_past | aux] = dZ . W1
@@ -541,14 +566,28 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
             db = in ? db : dmy + 128 + lane;
             if (ly.adaptive) atomicAdd(db, past);                                                       // gather backward (collisions)
             else *db = past;                                                                            // unique writer
-            if (lane < Ap) {                                                                            // (Ap <= 64)
+            if constexpr (!HOIST) if (lane < Ap) {                                                      // (Ap <= 64)
                 float* dh = DH + (__umul24((unsigned)n, (unsigned)Ap) + lane);
                 atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);               // unique writer per layer, layers in order
             }
         }
+        if constexpr (HOIST) {      // D_l[frame][gate row] += this tile's share; the tile's 16 G values
+            if (lane < 16) {
+                float* dp = bw.DPA + cpoff + 16 * wave + lane;
+                atomicAdd(dp, dacc[0]); atomicAdd(dp + C, dacc[1]); atomicAdd(dp + 2 * C, dacc[2]); atomicAdd(dp + 3 * C, dacc[3]);
+                float* ep = bw.EB + (size_t)(l * TR_EB_SLOTS + (blockIdx.x & (TR_EB_SLOTS - 1))) * 2 * C + 16 * wave + lane;
+                atomicAdd(ep, eacc[0]); atomicAdd(ep + C, eacc[1]);
+            }
+            if (tid < 16 && n0 + tid < N1) GWl[n0 + tid] = (Gp[tid] + Gp[16 + tid]) + (Gp[32 + tid] + Gp[48 + tid]);
+        }
         store_rows(t + 1 < t_last ? t + 1 : t_last, sm + ((ti + 1) & 1) * 4 * 16 * ldx);
 #pragma unroll
         for (int i = 0; i < 4; ++i) tprow[i] = tpnext[i];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cwj[i] = nwj[i]; cpa[i] = npa[i]; }
+            cpoff = npoff;
+        }
     }
 }
 
@@ -1072,7 +1111,7 @@ static bool wgrad3_any(const Wg2& w, int nch, bool generic, hipStream_t stream) 
     if (w.bmode == 4) return launch_wgrad3<4, 1, 8>(w, nch, stream) || launch_wgrad3<4, 1, 4>(w, nch, stream);      // causal table: C = 64, 128- or 64-class groups
     if (generic) return false;
     switch (w.bmode) {
-    case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 / 32, n_aux 33..48
+    case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 2, 8>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 (K = 176 / 128: aux at sample / frame rate), C = 32, n_aux 33..48
     case 2: return launch_wgrad3<2, 1, 4>(w, nch, stream) || launch_wgrad3<2, 4, 4>(w, nch, stream);       // res / skip 1x1 at C = 64
     case 1: return launch_wgrad3<1, 4, 4>(w, nch, stream);                                                  // post-net, 64-column groups
     default: return false;
@@ -1176,6 +1215,81 @@ __global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, 
 
 __global__ __launch_bounds__(128) void k_up_bwd(UpArgs u) { up_bwd_body(u, blockIdx.x, blockIdx.y, threadIdx.x, 128); }
 
+// Aux hoist: the gradients the frame-rate form leaves to a kernel of its own, from what the layer backward accumulated: D (DPA), G (GW) and
+// the gate-bias gradient E_l[n] = colsum(dZ_l) (EB).  With h_up[a][U f + j] = h[a][f] w_up[j] + b_up (reference src/nets/qpnet.py:134-158) and
+// z_l[t] += Va_l . h_up[:, t] + ba_l (qpnet.py:215-216, 663-664):
+//   role A, blocks [0, L A):        dVa_l[n][a] = sum_{b, f} D_l[b][f][n] h[b][a][f] + b_up E_l[n]          (D_l[b][f][n] = sum_{t in f} w_up[j(t)] dZ_l[t][n])
+//                                   db_up      += sum_n Va_l[n][a] E_l[n]                                    (one atomic per block onto the entry the reduction zeroed)
+//   role B, blocks [L A, L A + U):  dw_up[j]    = sum_{l, b, t: j(t) = j, t >= s_out(l)} G_l[b][t]          (G_l[b][t] = sum_n dZ_l[t][n] (Va_l . h[b][:, f(t)])[n])
+// It needs nothing of the weight-gradient launches: it runs on the side stream next to them.
+__global__ __launch_bounds__(128) void k_aux_tail(AuxArgs p) {
+    __shared__ float hrow[1024];
+    __shared__ float red[2];
+    const AuxGeom& ag = p.g;
+    const int C = p.C, A = p.A, L = p.L, tid = threadIdx.x;
+    const int bx = blockIdx.x;
+    float v = 0.f;
+    const bool role_a = bx < L * A;
+    if (role_a) {
+        const int l = bx / A, a = bx - l * A, n = tid;    // (128 threads = 2C gate rows)
+        const size_t wi = (n < C ? ag.auxS[l] + (size_t)n * A : ag.auxT[l] + (size_t)(n - C) * A) + a;
+        const float va = p.flat[wi];
+        float e = 0.f;
+        {
+            float ev[TR_EB_SLOTS];
+#pragma unroll
+            for (int k = 0; k < TR_EB_SLOTS; ++k) ev[k] = p.EB[(size_t)(l * TR_EB_SLOTS + k) * 2 * C + n];
+#pragma unroll
+            for (int k = 0; k < TR_EB_SLOTS; ++k) e += ev[k];
+        }
+        float acc = 0.f;
+        for (int b = 0; b < p.B; ++b) {
+            const float* hb = p.h + ((size_t)b * A + a) * p.F + p.ffirst;
+            const float* D = p.DPA + (size_t)(l * p.B + b) * (p.nfr + 1) * 2 * C + n;
+            for (int f0 = 0; f0 < p.nfr; f0 += 1024) {
+                const int nf = p.nfr - f0 < 1024 ? p.nfr - f0 : 1024;
+                __syncthreads();
+                for (int i = tid; i < nf; i += 128) hrow[i] = hb[f0 + i];
+                __syncthreads();
+                int f = 0;
+                for (; f + 64 <= nf; f += 64) {           // 64 rows requested together (the loop is a chain of memory round trips otherwise)
+                    float d[64];
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) d[k] = D[(size_t)(f0 + f + k) * 2 * C];
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) acc += d[k] * hrow[f + k];
+                }
+                for (; f + 16 <= nf; f += 16) {
+                    float d[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) d[k] = D[(size_t)(f0 + f + k) * 2 * C];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc += d[k] * hrow[f + k];
+                }
+                for (; f < nf; ++f) acc += D[(size_t)(f0 + f) * 2 * C] * hrow[f];
+            }
+        }
+        p.gflat[wi] = (acc + p.flat[p.up_b] * e) * p.gscale;
+        v = va * e;
+    } else {
+        const int j = bx - L * A;
+        const int q0 = p.F * p.U - p.N1;                 // h_up sample index of row 0
+        const int items = L * p.B * p.nfr;
+        for (int it = tid; it < items; it += 128) {
+            const int fx = it % p.nfr, lb = it / p.nfr, l = lb / p.B;
+            const int n = (p.ffirst + fx) * p.U + j - q0;
+            if (n >= ag.s_out[l] && n < p.N1) v += p.GW[(size_t)lb * p.N1 + n];
+        }
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        if (role_a) atomicAdd(p.gflat + p.up_b, (red[0] + red[1]) * p.gscale);
+        else p.gflat[p.up_w + (bx - L * A)] = (red[0] + red[1]) * p.gscale;
+    }
+}
+
 // torch.optim.Adam (single tensor semantics, fp32)
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                        float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den) {
@@ -1208,12 +1322,16 @@ __device__ __forceinline__ void zero_dx_slice(const TrainParams& p, const TrainB
     const int b0 = ly.adaptive ? 0 : p.N1 - ly.dilation, b1 = p.N1;
     const size_t na = (size_t)(a1 - a0) * C / 4, nb = (size_t)(b1 > b0 ? b1 - b0 : 0) * C / 4;      // C % 16 == 0
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    // layer 0's blocks also clear the aux-feature gradient [N1][Ap] of this batch item (every layer adds to it)
-    const size_t nh = j == 0 ? (size_t)p.N1 * p.Ap / 4 : 0;
-    for (size_t i = part * nthr + t; i < na + nb + nh; i += nparts * nthr) {
+    // layer 0's blocks also clear the aux-feature gradient [N1][Ap] of this batch item (every layer adds to it); aux hoist: every layer's
+    // blocks clear the layer's frame-rate accumulators D_l[b] instead
+    const size_t nh = p.hoist ? (size_t)(p.nfr + 1) * 2 * C / 4 : (j == 0 ? (size_t)p.N1 * p.Ap / 4 : 0);
+    const size_t ne = (p.hoist && b == 0) ? (size_t)TR_EB_SLOTS * 2 * C / 4 : 0;            // ... and (batch item 0's blocks) the layer's gate-bias accumulators E_l
+    float* H = p.hoist ? bw.DPA + (size_t)(j * p.B + b) * (p.nfr + 1) * 2 * C : bw.DHUP + (size_t)b * p.N1 * p.Ap;
+    for (size_t i = part * nthr + t; i < na + nb + nh + ne; i += nparts * nthr) {
         if (i < na) ((float4*)(A + (size_t)a0 * C))[i] = z;
         else if (i < na + nb) ((float4*)(Bq + (size_t)(b0 > 0 ? b0 : 0) * C))[i - na] = z;
-        else ((float4*)(bw.DHUP + (size_t)b * p.N1 * p.Ap))[i - na - nb] = z;
+        else if (i < na + nb + nh) ((float4*)H)[i - na - nb] = z;
+        else ((float4*)(bw.EB + (size_t)j * TR_EB_SLOTS * 2 * C))[i - na - nb - nh] = z;
     }
 }
 __global__ void k_zero_dx(TrainParams p, TrainBwd bw) {
@@ -1243,7 +1361,11 @@ static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t 
 
 // early_done: the [g_early0, g_early1) slab range has been reduced already; up_done: so have the zeroing / trailer and, on top of the zeros, the
 // upsampling kernel's gradient
-int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done) {
+static void launch_aux_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom& ag, hipStream_t st) {
+    hipLaunchKernelGGL(k_aux_tail, dim3(p.L * p.A + p.U), dim3(128), 0, st, tr_aux_args(p, &bw, ag));
+}
+
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom* ag, hipStream_t stream, bool early_done, bool up_done) {
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
     const TrainSlabs& sl = *bw.sl;
     hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + (up_done ? 0 : bw.n_gzero + 4) + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
@@ -1255,7 +1377,8 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
         const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
         if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
         if (sl.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
-        if (p.U > 0 && !up_done) launch_up_bwd(p, bw, stream);
+        if (p.U > 0 && !up_done && !p.hoist) launch_up_bwd(p, bw, stream);
+        if (p.hoist && ag && !up_done) launch_aux_tail(p, bw, *ag, stream);      // (behind the reduction's zeroing: it adds onto the upsampling-bias entry; up_done: it ran on the side stream)
     }
     qpn_prof_mark(PG_GRAD_TAIL, stream);
     QPN_HIP(hipGetLastError());
@@ -1265,7 +1388,7 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t s
 bool qpn_stack_bwd_fits(const TrainParams& p);
 int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const StackQ* sq, hipStream_t stream) {
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const TrainSlabs& sl = *bw.sl;
     const size_t nDX = (size_t)B * N1 * C;
@@ -1309,6 +1432,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
             w.ncol_groups = wgrad_col_groups(w.M, w.N);
             for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = sl.g_ws[l]; w.gbias[l] = l == 0 ? sl.g_bs : -1; w.tap_off[l] = -1; }
             ok = ok && wgrad2_any(w, nch_side_, gen, st);
+            qpn_prof_mark(PG_WGRAD_SKIP, st);
         }
         {   // post-net: dW2[q][s] = dlogits^T relu(Y0), dW1[o][s] = dY0^T relu(S0); N split into 64-column groups
             w.nlayers = 1; w.A_lstride = w.B_lstride = 0; w.B2 = nullptr; w.bmode = 1; w.rowsA = w.rowsB = BL;
@@ -1328,13 +1452,14 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
                 w.A = bw.DY0; w.lda = S; w.M = S; w.B1 = p.S0; w.goff[0] = sl.g_p1; w.gbias[0] = sl.g_bp1;
                 ok = ok && wgrad2_any(w, nch_side_, gen, st);
             }
+            qpn_prof_mark(PG_WGRAD_POST, st);
         }
     };
     // ---- weight gradients that need the layer backward: dW1 (needs dZ_l), the residual 1x1 (needs dX_{l+1}), the causal table
     auto build_w1 = [&]() {     // dW1_l = dZ_l^T [x_cur | x_past | aux],  bias1 grads = colsum(dZ_l)
         Wg2 w = wbase;
         w.A = bw.DZ; w.A2 = nullptr; w.A_lstride = (size_t)B * N1 * 2 * C; w.lda = 2 * C; w.M = 2 * C; w.rowsA = N1;
-        w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = 2 * C + p.Ap; w.rowsB = N1;
+        w.bmode = 3; w.B1 = p.X; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = p.Ktp; w.Nvalid = p.hoist ? 2 * C : 2 * C + p.Ap; w.rowsB = N1;      // (aux hoist: no aux columns -- k_aux_tail)
         w.nlayers = L; w.ldc = p.Ktp; w.ncol_groups = wgrad_col_groups(w.M, w.N);
         for (int l = 0; l < L; ++l) {
             const TrLayer& ly = p.layers[l];
@@ -1359,6 +1484,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     const bool early_reduce = overlap && bw.gdst && sl.g_early1 > sl.g_early0 && k.reduce_early;
     // with the early reduction doing the zeroing / trailer too, the upsampling kernel's gradient (atomics onto those zeros, needs dH of every
     // layer) runs on the side stream next to dW1 instead of behind the final reduction
+    // (aux hoist: k_aux_tail takes k_up_bwd's place: it needs the layer backward's D / G / E and the zeroed upsampling-bias entry)
     const bool up_side = early_reduce && p.U > 0 && k.up_side;
     // (only with the early reduction: otherwise ONE launch reduces every block with one slab count)
     if (early_reduce) {
@@ -1376,7 +1502,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     }
     const int swz = k.xcd_swizzle ? 1 : 0;
     const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
-    const bool persist = C == 64 && p.Ktp == 176 && p.Ap <= 64 && off32 && k.persist_bwd;
+    const bool persist = C == 64 && (p.Ktp == 176 || p.hoist) && p.Ap <= 64 && off32 && k.persist_bwd;
+    if (p.hoist && !persist) { qpn_set_error("internal: the frame-rate aux term needs the register-resident layer kernels"); return QPN_EINVAL; }
     // the whole stack's backward as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE_BWD=0 (or
     // QPN_STACK_QUEUE=0) keeps a launch per layer
     const bool stack_q = persist && k.stack_q_bwd && sq && sq->flags && p.qctl && qpn_stack_bwd_fits(p);
@@ -1388,10 +1515,18 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
         if (persist) {      // register-resident weights, 2 workgroups per CU over contiguous tile ranges (k_layer_bwd_p)
             int G = qpn_num_cus() * 2; if (G > tiles) G = tiles;
             if (G > 1024) G = 1024;                                // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
-            const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(176)) * sizeof(float);
-            (void)hipFuncSetAttribute(l == L - 1 ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-            if (l == L - 1) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
-            else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            const size_t ldsp = (size_t)(8 * 16 * tr_lda(C) + 16 * tr_lda(2 * C) + 16 * tr_lda(p.Ktp) + 64) * sizeof(float);
+            const bool last = l == L - 1;
+            const void* kf = p.hoist ? (last ? (const void*)k_layer_bwd_p<8, true> : (const void*)k_layer_bwd_p<8, false>)
+                                     : (last ? (const void*)k_layer_bwd_p<11, true> : (const void*)k_layer_bwd_p<11, false>);
+            (void)hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+            if (p.hoist) {
+                if (last) hipLaunchKernelGGL((k_layer_bwd_p<8, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+                else hipLaunchKernelGGL((k_layer_bwd_p<8, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            } else {
+                if (last) hipLaunchKernelGGL((k_layer_bwd_p<11, true>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+                else hipLaunchKernelGGL((k_layer_bwd_p<11, false>), dim3(G, B), dim3(256), ldsp, stream, p, bw, l, swz ? 2 : 0, tiles, p.scratch_rows);
+            }
         } else {
             if (lds_layer > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_bwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer);
             hipLaunchKernelGGL((k_layer_bwd<1>), dim3(tiles, B), dim3(256), lds_layer, stream, p, bw, l, l == L - 1 ? 1 : 0, swz);
@@ -1414,19 +1549,20 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     if (wr_side || up_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        if (up_side) launch_up_bwd(p, bw, side);
+        if (up_side) { if (p.hoist) launch_aux_tail(p, bw, ag, side); else launch_up_bwd(p, bw, side); }      // (behind the early reduction's zeroing, on the same stream)
         if (wr_side) ok = ok && wgrad2_any(build_wr(), nch, gen, side);
     }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
     ok = ok && wgrad2_any(build_w1(), nch, gen, stream);
-    if (!wr_side) ok = ok && wgrad2_any(build_wr(), nch, gen, stream);
+    qpn_prof_mark(PG_WGRAD, stream);
+    if (!wr_side) { ok = ok && wgrad2_any(build_wr(), nch, gen, stream); qpn_prof_mark(PG_WGRAD_WR, stream); }
     if (!overlap) launch_skip_post(stream);
     if (sl.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, gen, stream);
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
     if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
-    qpn_prof_mark(PG_WGRAD, stream);
-    return qpn_launch_grad_tail(p, bw, stream, early_reduce, up_side);
+    qpn_prof_mark(PG_WGRAD_CAUSAL, stream);
+    return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }
 
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {

@@ -38,11 +38,20 @@ struct TrainParams {
     const float* flat;        // parameters (state_dict order)
     const float4* wp;         // fragment-ordered weights
     const float* ct;          // causal conv table transposed to [tap][class][C] (a row per looked-up class: coalesced)
-    const float* bp;          // packed biases
+    float* bp;                // packed biases (hoist: k_aux_proj adds b_up * sum_a Va[n][a] to the gate biases)
     const int64_t* x; const float* h; const float* d;
     float* X;                 // [L+1][B][N1][C]
     float* SG; float* TH;     // [L][B][N1][C]
     float* HUP;               // [B][N1][Ap]
+    // Auxiliary 1x1 at FRAME rate (hoist != 0; n_resch 64, upsampling_factor >= 16).  The upsampling deconvolution is rank 1
+    // (h_up[a][U f + j] = h[a][f] w_up[j] + b_up, reference src/nets/qpnet.py:134-158), so the aux 1x1 of a gated block (qpnet.py:215-216,
+    // 663-664) commutes with it:  Va . h_up[:, t] + ba = w_up[j(t)] * (Va . h[:, f(t)]) + (b_up * Va . 1 + ba).  The second term rides in
+    // the packed bias; the first is a rank-<=2 update of a 16-row tile (U >= 16: at most two frames per tile) -- ONE extra 16x16x4 MFMA per
+    // accumulator instead of the 48 padded aux columns of the K = 176 contraction (the decode kernels have always done this).
+    int hoist;                // Ktp = 2C (no aux columns in the A tile), PA / WJ valid, HUP not written
+    int nfr, ffirst;          // frames the N1 rows touch, first of them: row n -> q = F U - N1 + n, f = q / U, j = q - f U
+    float* PA;                // [L][B][nfr + 1][2C]: PA_l[b][f - ffirst][n] = sum_a Va_l[n][a] h[b][a][f]; row nfr: padding (finite, never used by a real row)
+    float2* WJ;               // [N1 + 16]: {w_up[j(n)], j(n) as int bits} (same for every batch item); tail = row N1 - 1
     int* TAP;                 // [LA][B][N1]
     int* XC;                  // [B][N1+1] sample classes of the rows (x % Q), for the causal conv's weight gradient
     float* S0; float* Y0;     // [B][BL][S] pre-relu skip sum / post1
@@ -79,10 +88,11 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     float* DZ;                        // [B][N1][2C] gate pre-activation grads of the current layer
     float* DS0; float* DY0;           // [B][BL][S]
     float* DGS;                       // [B][BL][L*C]
-    float* DHUP;                      // [B][N1][Ap]
+    float* DHUP;                      // [B][N1][Ap]  (hoist == 0)
+    float* DPA;                       // hoist: [L][B][nfr + 1][2C], D_l[b][fx][n] = sum_{t in frame} w_up[j(t)] dZ_l[t][n] (float atomics; zeroed per backward)
+    float* GW;                        // hoist: [L][B][N1], G_l[b][t] = sum_n dZ_l[t][n] PA_l[b][fx(t)][n]  (the upsampling kernel's gradient, per row)
+    float* EB;                        // hoist: [L][TR_EB_SLOTS][2C] directly behind DPA, zeroed with it; sum over the slots = E_l[n] = sum_{b, t} dZ_l[t][n] (the gate-bias gradient, accumulated by the layer backward itself)
     float* slab;                      // [NCH][gstage] split-time partial weight grads
-    const int* gsrc;                  // [n_params] gather map flat-grad <- slab space (-1: owned by a special kernel)
-    const int* gsrc2;                 // second source (adaptive conv biases share one gradient), -1 if none
     const int* gdst; const int* gdst_list;   // inverse map in CSR form: slab element s feeds flat-grad entries gdst_list[gdst[s] .. gdst[s+1])
     const int* gzero; int n_gzero;    // flat-grad entries no slab element feeds (written by their own kernels afterwards): zeroed by the reduction
     int nch, gstage;
@@ -95,6 +105,20 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
 };
 
 
+// aux hoist: what k_aux_proj / k_aux_tail need of every layer (flat offsets of the aux 1x1 weights, offset of the packed gate bias, first valid row of the call) ...
+struct AuxGeom { int auxS[TR_MAXL], auxT[TR_MAXL], bias1[TR_MAXL], s_out[TR_MAXL]; };
+// ... and their (compact) kernel arguments
+struct AuxArgs {
+    const float* flat; const float* h; float* PA; float* bp; const float* DPA; const float* EB; const float* GW; float* gflat;
+    float gscale; int C, A, L, B, F, U, N1, nfr, ffirst; int64_t up_w, up_b;
+    AuxGeom g;
+};
+static inline AuxArgs tr_aux_args(const TrainParams& p, const TrainBwd* bw, const AuxGeom& ag) {
+    AuxArgs a; a.flat = p.flat; a.h = p.h; a.PA = p.PA; a.bp = p.bp; a.DPA = bw ? bw->DPA : nullptr; a.EB = bw ? bw->EB : nullptr; a.GW = bw ? bw->GW : nullptr;
+    a.gflat = bw ? bw->gflat : nullptr; a.gscale = bw ? bw->gscale : 1.f;
+    a.C = p.C; a.A = p.A; a.L = p.L; a.B = p.B; a.F = p.F; a.U = p.U; a.N1 = p.N1; a.nfr = p.nfr; a.ffirst = p.ffirst; a.up_w = p.up_w; a.up_b = p.up_b; a.g = ag;
+    return a;
+}
 // Launch-plan knobs, parsed ONCE per handle from the environment (train_init): nothing in the per-step launch path calls getenv().
 // All optional; the defaults are the measured best.  tests/test_train_gpu.py builds a fresh model (= a fresh handle) per arrangement.
 struct TrainKnobs {
@@ -129,9 +153,15 @@ struct StackQ {
     int total, nq;            // positions; sub-queues in use
 };
 
+// float offset in PA / DPA of the frame that holds row n0 (layer l, batch item b)
+__host__ __device__ __forceinline__ int tr_pa_off(const TrainParams& p, int l, int b, int n0) {
+    const int q = p.F * p.U - p.N1 + n0;                       // (F U < 2^31: checked by the host)
+    return ((l * p.B + b) * (p.nfr + 1) + (q / p.U - p.ffirst)) * 2 * p.C;
+}
+
 // One entry of the forward tile table (device side of k_train_prep; read by k_stack_fwd):
 //   a = {first row n0, layer | batch item << 8 | last layer << 24 | valid << 25, first producer position, producer positions}
-//   b = {row offset of the layer's input in X (= of its sigma / tanh rows), tap table offset, row offset of the aux features, 0}
+//   b = {row offset of the layer's input in X (= of its sigma / tanh rows), tap table offset, row offset of the aux features (hoist: float offset of the tile's first frame in PA), 0}
 // producers of tile (l, t): the tiles of layer l - 1 that hold the rows n0 - reach .. n0 + 15 (own rows and every row a tap can touch;
 // reach = dilation (fixed) or dilation * maxd (adaptive), reference src/nets/qpnet.py:271-306)
 __device__ __forceinline__ void tr_queue_entry_fwd(const TrainParams& p, int pos, int4& a, int4& b) {
@@ -152,7 +182,7 @@ __device__ __forceinline__ void tr_queue_entry_fwd(const TrainParams& p, int pos
         first = p.qP[l - 1] + bi * p.qT[l - 1] + t_lo; n = t_hi - t_lo + 1;
     }
     a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0), first, n);
-    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, 0);
+    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, p.hoist ? tr_pa_off(p, l, bi, n0) : bi * p.N1, 0);
 }
 
 // The backward queue runs the layers from the last to the first (position blocks in that order, tiles by ascending rows).  Entry of tile
@@ -183,7 +213,7 @@ __device__ __forceinline__ void tr_queue_entry_bwd(const TrainParams& p, int pos
         first = pbase + bi * p.qT[l + 1] + t_lo; n = t_hi - t_lo + 1;
     }
     a = make_int4(n0, l | (bi << 8) | (l == p.L - 1 ? 1 << 24 : 0) | (valid ? 1 << 25 : 0) | (ly.adaptive ? 1 << 26 : 0), first, n);
-    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, bi * p.N1, bi * p.BL * p.LC + l * p.C);
+    b = make_int4((l * p.B + bi) * p.N1, ly.tap_off + bi * p.N1, p.hoist ? tr_pa_off(p, l, bi, n0) : bi * p.N1, bi * p.BL * p.LC + l * p.C);
 }
 
 // K-major, zero-padded weight blocks of the GEMM path (train_gemm.hip; n_resch > 128): float offsets into `wp`
@@ -205,7 +235,10 @@ struct TrainGemm {
 int qpn_num_cus();                                   // compute units of the current device (cached per device)
 
 // optional per-kernel-group timing (HIP events on the launch stream; bench.py roofline)
-enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE, PG_COUNT };
+// (one group per LAUNCH of the heavy kernels, so that bench.py can name the single longest kernel: PG_WGRAD = the gate contraction's weight
+//  gradient dW1, then the residual 1x1's, the skip 1x1's, the post-net pair's and the causal table's)
+enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE,
+       PG_WGRAD_WR, PG_WGRAD_SKIP, PG_WGRAD_POST, PG_WGRAD_CAUSAL, PG_COUNT };
 void qpn_prof_mark(int group, hipStream_t stream);
 bool qpn_prof_active();                              // per-group timing in progress (keeps a step on one stream)   // attributes the work enqueued since the previous mark to `group`
 
@@ -232,6 +265,46 @@ __device__ __forceinline__ void tr_tile_range(int orig, int G, int tiles, int sw
     before += j < mine ? j : mine;
     t_first = g * base + before; t_count = base + (orig < rem ? 1 : 0);
 }
+
+// ---- auxiliary 1x1 at frame rate (TrainParams::hoist): pieces shared by the per-layer and the work-queue kernels
+// frame slot (0: the tile's first frame, 1: the next one) of tile row `row` whose within-frame offset is j: the rows of a tile are consecutive
+// samples and U >= 16, so the offset has wrapped exactly when it is smaller than the row index
+__device__ __forceinline__ int tr_aux_slot(float2 wj, int row) { return __float_as_int(wj.y) < row ? 1 : 0; }
+// forward, A operand of the extra MFMA step: lane (row = lane & 15, k = lane >> 4) holds w_up[j(row)] in the k-slot of its frame, 0 elsewhere
+__device__ __forceinline__ float tr_aux_a(float2 wj, int lane) { return tr_aux_slot(wj, lane & 15) == (lane >> 4) ? wj.x : 0.f; }
+__device__ __forceinline__ float tr_dpp_row_sum(float a) {   // sum over the 16 lanes of a row, in every lane of it
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x128, 0xf, 0xf, true));      // row_ror:8
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x124, 0xf, 0xf, true));      // row_ror:4
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xf, 0xf, true));       // quad_perm [2,3,0,1]
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
+    return a;
+}
+// backward of the frame-rate aux term for one wave's share of a 16-row tile.  The lane holds dZ of rows 4 (lane >> 4) + i, i = 0..3, gate
+// columns c (sigma) and C + c (tanh), c = 16 wave + (lane & 15); wj[i] = the WJ entries of those rows, pa = {PA[f0][c], PA[f0][C + c],
+// PA[f0 + 1][c], PA[f0 + 1][C + c]}.
+//   d[0..3]  D contributions {frame 0 sigma, frame 0 tanh, frame 1 sigma, frame 1 tanh} for column lane & 15 -- valid in lanes 0..15 --:
+//            sum over the tile's rows of w_up[j(row)] dZ[row][col] per frame, as 8 MFMAs (A' = the [frame][row] weights, B' = the lane's dZ)
+//   gp[0..3] partial row sums of dZ[row][.] * PA[frame(row)][.] over this wave's 32 columns (the same value in all 16 lanes of a row group)
+//   e[0..1]  the tile's column sums of dZ (sigma, tanh) for column lane & 15 -- valid in lanes 0..15 --: a third row of A' holds ones
+struct TrAuxBwd { float d[4]; float gp[4]; float e[2]; };
+#define TR_EB_SLOTS 32       // the gate-bias accumulators E are spread over this many slabs per layer (workgroup index mod): ~40 float atomics per address and layer
+__device__ __forceinline__ TrAuxBwd tr_aux_bwd(const float2 (&wj)[4], const float (&pa)[4], const float (&dzs)[4], const float (&dzt)[4], int lane) {
+    TrAuxBwd o;
+    f32x4 as = (f32x4){0, 0, 0, 0}, at = (f32x4){0, 0, 0, 0};
+    const int m = lane & 15, g4 = 4 * (lane >> 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = tr_aux_slot(wj[i], g4 + i);
+        const float a = m == 2 ? 1.f : (k == m ? wj[i].x : 0.f);       // A'[m][kk = lane >> 4] of step i (row 4 kk + i): m = 0 / 1 the frame slots, m = 2 ones
+        as = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dzs[i], as, 0, 0, 0);
+        at = __builtin_amdgcn_mfma_f32_16x16x4f32(a, dzt[i], at, 0, 0, 0);
+        o.gp[i] = tr_dpp_row_sum(dzs[i] * (k ? pa[2] : pa[0]) + dzt[i] * (k ? pa[3] : pa[1]));
+    }
+    o.d[0] = as[0]; o.d[1] = at[0]; o.d[2] = as[1]; o.d[3] = at[1];        // rows 0 / 1 of the result = frame slots 0 / 1 (lanes 0..15)
+    o.e[0] = as[2]; o.e[1] = at[2];
+    return o;
+}
+
 // ---- one wave: acc[mt][j] += A_lds[16*mt.., :K] * Bfrag[:, nt_j]   (K multiple of 16)
 // A_lds row-major with leading dim lda (floats); Bp fragment order: [(ks4*NT + nt)*64 + lane] float4,
 // element e of the float4 = B[4*(4*ks4+e) + (lane>>4)][16*nt + (lane&15)].

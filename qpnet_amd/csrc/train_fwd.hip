@@ -20,25 +20,75 @@
 __device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 __device__ __forceinline__ float tanhf_(float z) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * z)) - 1.0f; }
 
+// Aux hoist: PA_l[b][fx][n] = sum_a Va_l[n][a] h[b][a][ffirst + fx] for every layer, gate row n (sigma rows, then tanh rows) and frame the
+// chunk's rows touch -- the auxiliary 1x1 (reference src/nets/qpnet.py:215-216, 663-664) applied BEFORE the rank-1 upsampling it commutes with
+// (qpnet.py:134-158): L x nfr x 2C x n_aux MACs per batch item instead of L x N1 x 2C x 48.  A role of k_train_prep's launch: one workgroup per
+// (AUXP_FPB frames, layer, batch item); thread = (gate row n, half of the frames).
+#define AUXP_FPB 8                                    // frames per workgroup
+__device__ __forceinline__ void aux_proj_block(const TrainParams& p, const AuxGeom& ag, int fxb, int l, int b, float* sm) {
+    // sm: Va_l [2C][A] (A odd: conflict-free column reads; even A: two-way), h tile [A][AUXP_FPB]
+    const int fx0 = fxb * AUXP_FPB, tid = threadIdx.x, n = tid & 127, fh = tid >> 7, C = p.C, A = p.A, CA = C * A;
+    float* Va = sm; float* hs = sm + 2 * CA;
+    {   // the sigma rows' and the tanh rows' weights are two contiguous [C][A] blocks of the flat parameters: a linear copy, 16 words in flight per thread
+        const float* s0 = p.flat + ag.auxS[l]; const float* s1 = p.flat + ag.auxT[l];
+        for (int base = 0; base < 2 * CA; base += 256 * 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int i = base + 256 * k + tid, ic = i < 2 * CA ? i : 0; v[k] = ic < CA ? s0[ic] : s1[ic - CA]; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int i = base + 256 * k + tid; if (i < 2 * CA) Va[i] = v[k]; }
+        }
+    }
+    for (int i = tid; i < A * AUXP_FPB; i += 256) {
+        const int a = i / AUXP_FPB, f = i - a * AUXP_FPB, fx = fx0 + f;
+        hs[i] = fx < p.nfr ? p.h[((size_t)b * A + a) * p.F + p.ffirst + fx] : 0.f;       // (the padding row behind the last frame: zeros)
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, vs = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float v = Va[n * A + a];
+        const float4 h4 = *(const float4*)(hs + a * AUXP_FPB + 4 * fh);
+        acc[0] += v * h4.x; acc[1] += v * h4.y; acc[2] += v * h4.z; acc[3] += v * h4.w;
+        vs += v;
+    }
+    float* out = p.PA + ((size_t)(l * p.B + b) * (p.nfr + 1) + fx0 + 4 * fh) * 2 * C + n;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) if (fx0 + 4 * fh + f <= p.nfr) out[(size_t)f * 2 * C] = acc[f];
+    // the constant part of the upsampled features, b_up * sum_a Va[n][a], joins the packed gate bias (written by k_refresh, earlier on this stream): one writer per (layer, gate row)
+    if (fxb == 0 && b == 0 && fh == 0) p.bp[ag.bias1[l] + n] += p.flat[p.up_b] * vs;
+}
+
 // Elementwise over (row, 4 channels): every access is a coalesced 16-byte load / store, no per-row serialisation.
 //   items [0, N1*C/4)                : X0[n][c..c+3] = tap-0 row of class x[n] + tap-1 row of class x[n+1] + bias  (transposed table p.ct)
 //   items [.., + N1*Ap/4)            : upsampled aux features HUP[n][a..a+3]
 //   items [.., + N1*L)               : tap row of layer l at row n: pitch-dependent (adaptive) or n - dilation (fixed) -- a table for
 //                                      every layer lets the consumers load taps without a branch (+ the class ids XC for the table gradient)
-__global__ __launch_bounds__(256) void k_train_prep(TrainParams p) {
+//   aux hoist: the workgroups behind the first `nprep` are aux_proj_block's
+__global__ __launch_bounds__(256) void k_train_prep(TrainParams p, AuxGeom ag, int nprep) {
     const int b = blockIdx.y;
+    if ((int)blockIdx.x >= nprep) {
+        extern __shared__ float sm[];
+        const int idx = blockIdx.x - nprep, nfxb = (p.nfr + 1 + AUXP_FPB - 1) / AUXP_FPB;
+        aux_proj_block(p, ag, idx % nfxb, idx / nfxb, b, sm);
+        return;
+    }
     const int C = p.C, Q = p.Q, N1 = p.N1, Ap = p.Ap;
     const int C4 = C / 4, A4 = Ap / 4;
-    const int nX = N1 * C4, nH = N1 * A4;
+    const int nX = N1 * C4, nH = p.hoist ? 0 : N1 * A4;          // (aux hoist: no sample-rate aux rows; the frame-rate projections are k_aux_proj's)
     const int total = nX + nH + N1 * p.L;
+    if (p.hoist && b == 0)         // row -> {w_up[j], j}: the upsampling weight and within-frame offset of every row (and of 16 rows past the end: the pattern continues)
+        for (int n = blockIdx.x * 256 + threadIdx.x; n < N1 + 16; n += nprep * 256) {
+            const int q = p.F * p.U - N1 + n, j = q - (q / p.U) * p.U;
+            p.WJ[n] = make_float2(p.flat[p.up_w + j], __int_as_float(j));
+        }
     if (p.qctl && blockIdx.x == 0 && b == 0 && threadIdx.x < 32) p.qctl[threadIdx.x < 16 ? threadIdx.x : 1024 + (threadIdx.x - 16) * TR_QHEAD_STRIDE] = 0u;      // abort word / counters / sub-queue heads of this step's stack queues (train_stack.hip)
     if (p.qtab && b == 0)          // tile table of the one-launch residual stack (train_stack.hip)
-        for (int pos = blockIdx.x * 256 + threadIdx.x; pos <= p.qtotal; pos += gridDim.x * 256) {
+        for (int pos = blockIdx.x * 256 + threadIdx.x; pos <= p.qtotal; pos += nprep * 256) {
             int4 ea, eb; tr_queue_entry_fwd(p, pos, ea, eb);
             p.qtab[2 * pos] = ea; p.qtab[2 * pos + 1] = eb;
             if (p.qtab_b) { tr_queue_entry_bwd(p, pos, ea, eb); p.qtab_b[2 * pos] = ea; p.qtab_b[2 * pos + 1] = eb; }
         }
-    for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += gridDim.x * 256) {
+    for (int it = blockIdx.x * 256 + threadIdx.x; it < total; it += nprep * 256) {
         if (it < nX) {
             const int n = it / C4, c = (it - n * C4) * 4;
             const int64_t xo = (int64_t)p.T - p.N0 + n;
@@ -226,6 +276,7 @@ __global__ __launch_bounds__(256) void k_layer_fwd(TrainParams p, int l, int las
 template <int KS, bool LAST>
 __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, int flags, int tiles, float* dummy) {     // flags: bit 1 XCD swizzle
     constexpr int C = 64, Ktp = 16 * KS;
+    constexpr bool HOIST = KS == 8;                              // K = 2C: the auxiliary 1x1 at frame rate (TrainParams::hoist; one extra MFMA step per accumulator)
     constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;     // tr_lda: conflict-free fragment reads, 8-byte aligned rows
     extern __shared__ float sm[];
     float* Gs = sm + 32 * lda;                                   // As buffers: sm, sm + 16 * lda
@@ -262,14 +313,21 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
     const bool aux_thread = sc4 < (Ktp - 2 * C) / 4, aux_real = 4 * sc4 < Ap;
     const int orow = tid >> 5, oc2 = (tid & 31) * 2;
     float* const dmy = dummy + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + oc2;       // two scratch rows per workgroup
-    int tp; float4 rc, rp, rx;
+    int tp; float4 rc, rp, rx = make_float4(0.f, 0.f, 0.f, 0.f);
+    // aux hoist: the extra step's operands of the tile in flight (rwj / rpb*: requested with its rows) and of the tile in hand (xaux_*)
+    float2 rwj = make_float2(0.f, 0.f); float rpb0 = 0.f, rpb1 = 0.f, xaux_a = 0.f, xaux_b0 = 0.f, xaux_b1 = 0.f;
     auto load_tap = [&](int t) { const int n = ly.s_out + t * 16 + srow; tp = taps[n < N1 ? n : N1 - 1]; };
     auto load_rows = [&](int t) {
         const int n = ly.s_out + t * 16 + srow, nn = n < N1 ? n : N1 - 1;
         // (32-bit element offsets behind uniform bases: see k_layer_bwd_p)
         rc = *(const float4*)(Xin + (__umul24((unsigned)nn, (unsigned)C) + 4u * sc4));
         rp = *(const float4*)(Xin + (__umul24((unsigned)tp, (unsigned)C) + 4u * sc4));
-        rx = *(const float4*)(hup + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
+        if constexpr (HOIST) {
+            const int n0 = ly.s_out + t * 16;
+            const float* pa = p.PA + tr_pa_off(p, l, b, n0) + ((lane >> 4) & 1) * 2 * C + 16 * wave + (lane & 15);
+            rwj = p.WJ[n0 + (lane & 15)];                        // (16 rows of padding behind row N1 - 1)
+            rpb0 = pa[0]; rpb1 = pa[C];
+        } else rx = *(const float4*)(hup + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
     };
     auto store_rows = [&](int t, float* As) {
         const bool in = ly.s_out + t * 16 + srow < N1;
@@ -278,7 +336,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
         float* d = As + (size_t)srow * lda + 4 * sc4;
         *(float2*)d = make_float2(vc.x, vc.y); *(float2*)(d + 2) = make_float2(vc.z, vc.w);
         *(float2*)(d + C) = make_float2(vp.x, vp.y); *(float2*)(d + C + 2) = make_float2(vp.z, vp.w);
-        if (aux_thread) { *(float2*)(d + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(d + 2 * C + 2) = make_float2(vx.z, vx.w); }
+        if constexpr (HOIST) {      // B operand: lane (k = lane >> 4, column lane & 15) = PA[first frame + k][...] for k < 2, 0 for the unused k-slots
+            xaux_a = tr_aux_a(rwj, lane); xaux_b0 = lane < 32 ? rpb0 : 0.f; xaux_b1 = lane < 32 ? rpb1 : 0.f;
+        } else if (aux_thread) { *(float2*)(d + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(d + 2 * C + 2) = make_float2(vx.z, vx.w); }
     };
     auto store_out = [&](const float* T, float* dst, int n0, bool live) {      // a [16][64] LDS tile -> rows n0.. of a [N1][64] array, whole rows
         const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
@@ -310,6 +370,9 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
         __builtin_amdgcn_sched_barrier(0);                        // all fragment reads of the tile issued before the first MFMA (hipcc otherwise
                                                                   // sinks each read to its use: an LDS round trip in front of every second MFMA pair)
         f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+        if constexpr (HOIST) {      // w_up[j(row)] * PA[frame(row)][column]: the auxiliary 1x1 of the tile's (at most two) frames
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xaux_a, xaux_b0, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xaux_a, xaux_b1, a1, 0, 0, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][0].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][1].x, a1, 0, 0, 0);
@@ -794,18 +857,21 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
 }
 
 // ------------------------------------------------------------------ host launchers (called from train_host.hip)
-void qpn_launch_prep(const TrainParams& p, hipStream_t stream) {
-    const long items = (long)p.N1 * (p.C / 4 + p.Ap / 4 + p.L);
+void qpn_launch_prep(const TrainParams& p, const AuxGeom& ag, hipStream_t stream) {
+    const long items = (long)p.N1 * (p.C / 4 + (p.hoist ? 0 : p.Ap / 4) + p.L);
     const int blocks = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
-    hipLaunchKernelGGL(k_train_prep, dim3(blocks, p.B), dim3(256), 0, stream, p);
+    // aux hoist: the frame-rate projections PA are extra workgroups of this launch (they need k_refresh's packed biases: the launch before)
+    const int naux = p.hoist ? (p.nfr + 1 + AUXP_FPB - 1) / AUXP_FPB * p.L : 0;
+    const size_t lds = p.hoist ? (size_t)(2 * p.C * p.A + p.A * AUXP_FPB + 8) * sizeof(float) : 0;
+    hipLaunchKernelGGL(k_train_prep, dim3(blocks + naux, p.B), dim3(256), lds, stream, p, ag, blocks);
 }
 
 bool qpn_stack_fwd_fits(const TrainParams& p);
 int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, hipStream_t stream) {
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S;
-    qpn_launch_prep(p, stream);
+    qpn_launch_prep(p, ag, stream);
     qpn_prof_mark(PG_PREP, stream);
     // 16-row tiles everywhere (twice the workgroups of 32-row tiles, all co-resident: measured 8-15 % faster for the layer and post-net kernels)
     const size_t lds_layer = (size_t)16 * (tr_lda(p.Ktp) + tr_lda(C)) * sizeof(float);
@@ -817,7 +883,8 @@ int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, 
     {
         const int flags0 = k.xcd_swizzle ? 2 : 0;
         // persistent register-resident form (n_resch 64, K = 176): 2 workgroups per CU; QPN_LAYER_PERSIST=0 keeps the tile-per-workgroup launches
-        const bool persist = C == 64 && p.Ktp == 176 && p.N1 < (1 << 24) && k.persist_fwd;      // (N1 < 2^24: 32-bit element offsets of one batch item)
+        const bool persist = C == 64 && (p.Ktp == 176 || p.hoist) && p.N1 < (1 << 24) && k.persist_fwd;      // (N1 < 2^24: 32-bit element offsets of one batch item)
+        if (p.hoist && !persist) { qpn_set_error("internal: the frame-rate aux term needs the register-resident layer kernels"); return QPN_EINVAL; }
         // the whole stack as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE=0 keeps a launch per layer
         const bool stack_q = persist && k.stack_q_fwd && sq && sq->flags && p.qctl && qpn_stack_fwd_fits(p);
         if (stack_q) { const int rcq = qpn_launch_stack_fwd(p, *sq, k, stream); if (rcq) return rcq; }
@@ -827,9 +894,15 @@ int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, 
             if (persist) {
                 int G = qpn_num_cus() * 2; if (G > tiles) G = tiles;
                 if (G > 1024) G = 1024;                            // (scratch_rows holds a pair of rows for 1024 workgroups per batch item)
-                const size_t ldsp = (size_t)(32 * tr_lda(176) + 4 * 16 * tr_lda(64)) * sizeof(float);
-                if (l == p.L - 1) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
-                else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                const size_t ldsp = (size_t)(32 * tr_lda(p.Ktp) + 4 * 16 * tr_lda(64)) * sizeof(float);
+                const bool last = l == p.L - 1;
+                if (p.hoist) {
+                    if (last) hipLaunchKernelGGL((k_layer_fwd_p<8, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                    else hipLaunchKernelGGL((k_layer_fwd_p<8, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                } else {
+                    if (last) hipLaunchKernelGGL((k_layer_fwd_p<11, true>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                    else hipLaunchKernelGGL((k_layer_fwd_p<11, false>), dim3(G, p.B), dim3(256), ldsp, stream, p, l, flags0, tiles, p.scratch_rows);
+                }
             } else {
                 if (lds_layer > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_layer_fwd<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_layer);
                 hipLaunchKernelGGL((k_layer_fwd<1>), dim3(tiles, p.B), dim3(256), lds_layer, stream, p, l, (l == p.L - 1 ? 1 : 0) | flags0);

@@ -465,12 +465,12 @@ static GArgs gbase(const TrainParams& p) {
     return g;
 }
 
-void qpn_launch_prep(const TrainParams& p, hipStream_t stream);
+void qpn_launch_prep(const TrainParams& p, const AuxGeom& ag, hipStream_t stream);
 
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const size_t nDX = (size_t)B * N1 * C;
-    qpn_launch_prep(p, stream);
+    { AuxGeom ag0; memset(&ag0, 0, sizeof(ag0)); qpn_launch_prep(p, ag0, stream); }
     qpn_prof_mark(PG_PREP, stream);
     for (int l = 0; l < L; ++l) {
         const TrLayer& ly = p.layers[l];
@@ -524,7 +524,7 @@ int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t st
 }
 
 void qpn_launch_zero_dx(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);
-int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, hipStream_t stream, bool early_done, bool up_done);
+int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom* ag, hipStream_t stream, bool early_done, bool up_done);
 
 // post-net weight gradients dW2 = dlogits^T relu(Y0), dW1 = dY0^T relu(S0) (+ bias column sums) into the `nch` partial slabs
 static void launch_post_wgrad_gemm(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
@@ -620,5 +620,5 @@ int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGem
     }
     launch_post_wgrad_gemm(p, bw, stream);
     qpn_prof_mark(PG_WGRAD, stream);
-    return qpn_launch_grad_tail(p, bw, stream, false, false);
+    return qpn_launch_grad_tail(p, bw, nullptr, stream, false, false);
 }

@@ -7,10 +7,10 @@
 #include <algorithm>
 #include <string.h>
 
-int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const StackQ* sq, hipStream_t stream);
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
 void qpn_stack_fill(TrainParams& p);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const StackQ* sq, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
@@ -19,13 +19,15 @@ int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int
 struct TrainState {
     std::vector<int> h_wmap;                  // gather map of the fragment-ordered weights
     std::vector<int> h_bstart, h_blist;       // CSR of the packed biases
-    std::vector<int> h_gsrc, h_gsrc2;
+    std::vector<int> h_gsrc;
     int* d_wmap; float* d_wp; int* d_bstart; int* d_blist; float* d_bp; int n_bias;
-    int* d_gsrc; int* d_gsrc2; int* d_gdst; int* d_gdst_list; int* d_gzero; int n_gzero;
+    int* d_gdst; int* d_gdst_list; int* d_gzero; int n_gzero;
+    bool hoist;                               // the auxiliary 1x1 runs at frame rate (TrainParams::hoist)
     TrainParams tp;                           // template with block offsets filled in
     TrainBwd bw;
     TrainSlabs slabs;                         // slab offsets of the weight-gradient blocks (bw.sl points here)
     TrainKnobs knobs;                         // launch-plan knobs, parsed once (qpn_train_knobs_parse)
+    AuxGeom ag;                               // aux hoist: per-layer offsets for k_aux_proj / k_aux_tail (s_out refreshed per forward)
     // workspaces (grow only)
     float* d_ws; size_t ws_cap;               // one arena, carved per call
     int* d_tap; size_t tap_cap;
@@ -139,11 +141,6 @@ __global__ void k_refresh(const float* __restrict__ flat, const int* __restrict_
     (void)status;
     if (i >= 16 && i < 16 + 64) loss[i - 16] = 0.0;
 }
-__global__ void k_bias_pack(const float* __restrict__ flat, const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ out, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { float a = 0.f; for (int j = start[i]; j < start[i + 1]; ++j) a += flat[list[j]]; out[i] = a; }
-}
-
 // B[k][n] (K x N valid) -> K-major block [Kp][Np], zero padded; returns the float offset
 template <class F>
 static long kmajor_pack(std::vector<int>& map, int K, int Kp, int N, int Np, F src) {
@@ -180,7 +177,7 @@ static int train_init(qpn_handle* h) {
     if (C % 16 || S % 16 || Q % 16) { qpn_set_error("training kernels need n_resch, n_skipch, n_quantize multiples of 16"); return QPN_EINVAL; }
     TrainState* t = new TrainState();
     memset(&t->tp, 0, sizeof(t->tp)); memset(&t->bw, 0, sizeof(t->bw));
-    t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr; t->d_gsrc = t->d_gsrc2 = nullptr;
+    t->d_wmap = nullptr; t->d_wp = nullptr; t->d_bstart = t->d_blist = nullptr; t->d_bp = nullptr;
     t->d_gdst = t->d_gdst_list = t->d_gzero = nullptr; t->n_gzero = 0;
     t->d_ws = nullptr; t->ws_cap = 0; t->d_tap = nullptr; t->tap_cap = 0; t->d_status = nullptr; t->d_loss = nullptr; t->fwd_valid = false; t->loss_clear = false;
     t->generation = 0; t->side = nullptr; t->ev_fork = t->ev_join = t->ev_mid = nullptr; t->ev_early = nullptr; t->early_recorded = 0; t->early_first = -1;
@@ -192,8 +189,11 @@ static int train_init(qpn_handle* h) {
     if (t->use_gemm && (C % 32 || S % 32 || Q % 32)) { qpn_set_error("the GEMM training path needs n_resch, n_skipch, n_quantize multiples of 32"); delete t; return QPN_EINVAL; }
     TrainParams& p = t->tp;
     const int Ap = (A + 3) / 4 * 4;               // aux columns padded to the MFMA k-step
+    // the auxiliary 1x1 at frame rate (TrainParams::hoist): the n_resch-64 register-resident kernels, at most two frames per 16-row tile
+    t->hoist = !t->use_gemm && C == 64 && g.U >= 16 && A <= 64 && t->knobs.aux_hoist && t->knobs.persist_fwd && t->knobs.persist_bwd;
+    p.hoist = t->hoist ? 1 : 0;
     p.C = C; p.S = S; p.Q = Q; p.A = A; p.Ap = Ap; p.L = L; p.U = g.U;
-    p.Kt = 2 * C + Ap; p.Ktp = (p.Kt + 15) / 16 * 16; p.LC = L * C;
+    p.Kt = t->hoist ? 2 * C : 2 * C + Ap; p.Ktp = (p.Kt + 15) / 16 * 16; p.LC = L * C;
     p.causal_w = g.causal_w; p.causal_b = g.causal_b; p.up_w = g.up_w; p.up_b = g.up_b;
     std::vector<int>& map = t->h_wmap;
     std::vector<std::vector<int>> biases;      // packed bias i <- list of flat indices
@@ -262,6 +262,8 @@ static int train_init(qpn_handle* h) {
         gm.p2 = kmajor_pack(gmap, S, S, Q, gm.Qg, [&](int k, int n) { return g.post2_w + (int64_t)n * S + k; });
         gm.p2t = kmajor_pack(gmap, Q, Q, S, gm.Sg, [&](int k, int n) { return g.post2_w + (int64_t)k * S + n; });
     }
+    memset(&t->ag, 0, sizeof(t->ag));
+    for (int l = 0; l < L; ++l) { t->ag.auxS[l] = (int)g.layers[l].auxS; t->ag.auxT[l] = (int)g.layers[l].auxT; t->ag.bias1[l] = p.layers[l].bias1; }
     t->n_bias = (int)biases.size();
     t->h_bstart.assign(1, 0);
     for (auto& v : biases) { for (int x : v) t->h_blist.push_back(x); t->h_bstart.push_back((int)t->h_blist.size()); }
@@ -272,8 +274,8 @@ static int train_init(qpn_handle* h) {
     bw.sl = &t->slabs;
     int go = 0;
     auto gtake = [&](int n) { int r = go; go += (n + 63) & ~63; return r; };
-    std::vector<int>& gs = t->h_gsrc; std::vector<int>& gs2 = t->h_gsrc2;
-    gs.assign(g.n_params, -1); gs2.assign(g.n_params, -1);
+    std::vector<int>& gs = t->h_gsrc;          // flat-grad entry <- slab element; -1: no slab feeds it (zeroed, then written by a kernel of its own); -2: k_aux_tail stores it
+    gs.assign(g.n_params, -1);
     for (int l = 0; l < L; ++l) {
         sl.g_w1[l] = gtake(2 * C * Ktp);   // dW1[n][k] (n = z row, k = A-tile column), row-major [2C][Ktp]
         sl.g_b1[l] = gtake(2 * C);
@@ -288,7 +290,8 @@ static int train_init(qpn_handle* h) {
         //  stream finishes early: skip 1x1 of every layer, skip bias, post-net; that range is reduced early as well, under the layer backward)
         for (int n = 0; n < 2 * C; ++n) {
             const int half = n / C, r = n % C;
-            for (int k = 0; k < 2 * C + A; ++k) {
+            if (t->hoist) for (int a = 0; a < A; ++a) gs[(half ? y.auxT : y.auxS) + (int64_t)r * A + a] = -2;
+            for (int k = 0; k < (t->hoist ? 2 * C : 2 * C + A); ++k) {
                 int64_t dst;
                 if (k < C) dst = y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
                 else if (k < 2 * C) { const int kk = k - C; dst = y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2; }
@@ -322,7 +325,8 @@ static int train_init(qpn_handle* h) {
     }
     bw.gstage = go; bw.nch = t->use_gemm ? 4 : 64; bw.n_params = g.n_params;
     if (t->knobs.wgrad_chunks > 0) bw.nch = t->knobs.wgrad_chunks;      // tuning knob: time chunks (= partial slabs)
-    // the upsampling kernel's gradient is written by a dedicated kernel (gs stays -1)
+    // the upsampling kernel's gradient is written by a dedicated kernel (gs stays -1: k_up_bwd adds onto the zeroed entries; hoist: k_aux_tail stores them)
+    if (t->hoist) for (int j = 0; j < g.U; ++j) gs[g.up_w + j] = -2;      // (the upsampling bias stays -1: zeroed by the reduction, k_aux_tail adds onto it)
 
     const size_t nmap = t->use_gemm ? 4 : map.size();      // (the GEMM path keeps its own K-major blocks)
     QPN_HIP(hipMalloc(&t->d_wmap, nmap * sizeof(int)));
@@ -330,8 +334,6 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_bstart, t->h_bstart.size() * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_blist, t->h_blist.size() * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_bp, (size_t)t->n_bias * sizeof(float)));
-    QPN_HIP(hipMalloc(&t->d_gsrc, (size_t)g.n_params * sizeof(int)));
-    QPN_HIP(hipMalloc(&t->d_gsrc2, (size_t)g.n_params * sizeof(int)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
     QPN_HIP(hipMemset(t->d_status, 0, 64));
     t->h_status_pinned = nullptr; t->ev_status[0] = t->ev_status[1] = nullptr; t->status_pending[0] = t->status_pending[1] = false; t->status_newest = 0;
@@ -346,12 +348,10 @@ static int train_init(qpn_handle* h) {
     if (!t->use_gemm) QPN_HIP(hipMemcpy(t->d_wmap, map.data(), nmap * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_bstart, t->h_bstart.data(), t->h_bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     QPN_HIP(hipMemcpy(t->d_blist, t->h_blist.data(), t->h_blist.size() * sizeof(int), hipMemcpyHostToDevice));
-    QPN_HIP(hipMemcpy(t->d_gsrc, gs.data(), gs.size() * sizeof(int), hipMemcpyHostToDevice));
-    QPN_HIP(hipMemcpy(t->d_gsrc2, gs2.data(), gs2.size() * sizeof(int), hipMemcpyHostToDevice));
     {   // inverse of gsrc for the slab-order reduction, CSR: a slab element feeds one parameter, or several (a gate's conv / aux /
         // past-tap conv biases share one gradient, every layer's skip bias shares one); entries nothing feeds are listed for zeroing
         std::vector<int> start((size_t)go + 1, 0), list, gz;
-        for (int64_t i = 0; i < g.n_params; ++i) { if (gs[i] >= 0) ++start[(size_t)gs[i] + 1]; else gz.push_back((int)i); }
+        for (int64_t i = 0; i < g.n_params; ++i) { if (gs[i] >= 0) ++start[(size_t)gs[i] + 1]; else if (gs[i] == -1) gz.push_back((int)i); }
         for (int k = 0; k < go; ++k) start[(size_t)k + 1] += start[k];
         list.resize((size_t)start[go] + 1);
         std::vector<int> fill(start.begin(), start.end() - 1);
@@ -393,7 +393,7 @@ static int train_init(qpn_handle* h) {
 
 void qpn_train_destroy(TrainState* t) {
     if (!t) return;
-    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gsrc, t->d_gsrc2, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct, t->d_sq};
+    void* bufs[] = {t->d_wmap, t->d_wp, t->d_bstart, t->d_blist, t->d_bp, t->d_gdst, t->d_gdst_list, t->d_gzero, t->d_ws, t->d_tap, t->d_status, t->d_loss, t->d_gmap, t->d_gwp, t->d_ctmap, t->d_ct, t->d_sq};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (t->h_status_pinned) (void)hipHostFree(t->h_status_pinned);
     if (t->h_loss_pinned) (void)hipHostFree(t->h_loss_pinned);
@@ -442,14 +442,20 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
         TrLayer& ly = p.layers[l];
         ly.s_in = s; s += ly.adaptive ? ly.dilation * maxd : ly.dilation; ly.s_out = s;
         ly.tap_off = (nA++) * B * N1;          // every layer gets a tap table (fixed layers: n - dilation), so the kernels load taps unconditionally
+        t->ag.s_out[l] = ly.s_out;
     }
+    if (t->hoist) {
+        if (N1 >= (1 << 24)) { qpn_set_error("chunk too long for the register-resident layer kernels (%d rows; QPN_AUX_HOIST=0 QPN_LAYER_PERSIST=0 QPN_LAYER_BWD_PERSIST=0 selects the tile-per-workgroup kernels)", N1); return QPN_EINVAL; }
+        p.ffirst = (int)(((int64_t)F * g.U - N1) / g.U); p.nfr = (int)F - p.ffirst;
+    } else { p.ffirst = 0; p.nfr = 0; }
     // ---- carve the arena
-    const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
+    const size_t nPA = t->hoist ? (size_t)L * B * (p.nfr + 1) * 2 * C : 0, nWJ = t->hoist ? (size_t)2 * (N1 + 16) : 0, nGW = t->hoist ? (size_t)L * B * N1 : 0;
+    const size_t nX = (size_t)(L + 1) * B * N1 * C, nG = (size_t)L * B * N1 * C, nH = t->hoist ? 64 : (size_t)B * N1 * p.Ap, nS = (size_t)B * BL * S;
     TrainBwd& bw = t->bw;
     const size_t nDX = (size_t)B * N1 * C, nDZ = (size_t)B * N1 * 2 * C, nDGS = (size_t)B * BL * L * C, nSlab = (size_t)bw.nch * bw.gstage;
     const size_t nXC = (size_t)B * (N1 + 1);
     const size_t nScr = (size_t)B * 1024 * 2 * 128;
-    size_t need = nScr + nX + 2 * nG + nH + 2 * (nS + 96 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 8192;
+    size_t need = nScr + nX + 2 * nG + nH + 2 * (nS + 96 * (size_t)S + 64) + 2 * (size_t)(L + 1) * nDX + (size_t)L * nDZ + 2 * nS + nDGS + nH + nSlab + nXC + (t->use_gemm ? nG : 0) + 2 * nPA + nWJ + nGW + (size_t)L * TR_EB_SLOTS * 2 * C + 8192;
     if (need > t->ws_cap) {
         if (t->d_ws) (void)hipFree(t->d_ws);
         t->d_ws = nullptr; t->ws_cap = 0;
@@ -472,6 +478,9 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     p.XC = (int*)carve(nXC);
     p.scratch_rows = carve(nScr);
     if (t->use_gemm) t->gm.G = carve(nG);
+    p.PA = nullptr; p.WJ = nullptr; bw.DPA = nullptr; bw.GW = nullptr;
+    bw.EB = nullptr;
+    if (t->hoist) { p.PA = carve(nPA); bw.DPA = carve(nPA + (size_t)L * TR_EB_SLOTS * 2 * C); bw.EB = bw.DPA + nPA; p.WJ = (float2*)carve(nWJ); bw.GW = carve(nGW); }
     p.TAP = t->d_tap; p.status = t->d_status;
     {   // stack work queues (train_stack.hip): a flag word per (layer, batch item, 16-row tile) and direction, compared with a per-forward epoch
         // (zeroed only when (re)allocated), and the tile tables k_train_prep writes.  The regions keep their places for the life of an
@@ -518,7 +527,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !t->knobs.ce_separate;
     p.ce_tgt = fuse_ce ? d_targets : nullptr; p.ce_stride = tgt_stride; p.ce_dlogits = d_dlogits; p.ce_loss = t->d_loss;
     if (fuse_ce && !want_logits) p.logits = nullptr;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->knobs, &t->sqf, stream);
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->knobs, t->ag, &t->sqf, stream);
     p.ce_tgt = nullptr; p.logits = d_logits;
     if (rc) return rc;
     t->fwd_valid = true;
@@ -690,7 +699,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     if (!d_dlogits || !d_flatgrad) { qpn_set_error("bad train_backward arguments"); return QPN_EINVAL; }
     TrainState* t = h->train;
     TrainBwd& bw = t->bw;
-    bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gsrc = t->d_gsrc; bw.gsrc2 = t->d_gsrc2; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
+    bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
     bw.gscale = grad_scale; bw.append_scale = append_scale;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
     t->early_recorded = 0; bw.ev_early = t->ev_early; bw.early_recorded = (append_scale && t->early_first >= 0) ? &t->early_recorded : nullptr;
@@ -698,7 +707,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     const bool first_bwd = t->bwd_generation != t->generation;
     t->bwd_generation = t->generation;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_)
-                       : qpn_launch_bwd(t->tp, bw, t->knobs, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
+                       : qpn_launch_bwd(t->tp, bw, t->knobs, t->ag, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
 }
 
 extern "C" int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream_) {

@@ -128,6 +128,7 @@ __device__ __forceinline__ int sq_wait(const StackQ& q, int first, int n, int la
 template <int KS>
 __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
     constexpr int C = 64, Ktp = 16 * KS;
+    constexpr bool HOIST = KS == 8;                               // K = 2C: the auxiliary 1x1 at frame rate (TrainParams::hoist), as in k_layer_fwd_p
     constexpr int lda = ((Ktp + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;
     extern __shared__ float sm[];
     float* Gs = sm + 32 * lda;
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0), nothing else
     };
     auto xrsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
-    int tp = 0; float4 rc, rp, rx;
+    int tp = 0; float4 rc, rp, rx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 rwj = make_float2(0.f, 0.f); float rpb0 = 0.f, rpb1 = 0.f, xaux_a = 0.f, xaux_b0 = 0.f, xaux_b1 = 0.f;      // aux hoist: operands of the extra MFMA step (in flight / in hand)
     auto load_tap = [&](const SqTile& d, int& out) {
         const int n = d.n0 + srow;
         out = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1];
@@ -175,20 +177,25 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)op, 0, SQ_SC1);
         rc = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
         rp = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
-        rx = *(const float4*)(p.HUP + (size_t)d.hrow * Ap + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
-        __builtin_amdgcn_sched_barrier(0);                       // (all three requests before anything waits for one of them)
+        if constexpr (HOIST) {       // (d.hrow: float offset of the tile's first frame in PA; WJ has 16 rows of padding behind row N1 - 1)
+            const float* pa = p.PA + d.hrow + ((lane >> 4) & 1) * 2 * C + 16 * wave + (lane & 15);
+            rwj = p.WJ[d.n0 + (lane & 15)];
+            rpb0 = pa[0]; rpb1 = pa[C];
+        } else rx = *(const float4*)(p.HUP + (size_t)d.hrow * Ap + (__umul24((unsigned)nn, (unsigned)Ap) + (aux_real ? 4u * sc4 : 0u)));
+        __builtin_amdgcn_sched_barrier(0);                       // (all requests before anything waits for one of them)
     };
     auto store_rows = [&](const SqTile& d, float* As) {
         // (all three requests are taken up here by EVERY lane: the lanes without an auxiliary column never read theirs, and a register hipcc believes
         //  pending is waited for where it is next written -- the next tile's first MFMAs, behind the write-through block output)
-        asm volatile("" : "+v"(rx.w));
+        if constexpr (HOIST) asm volatile("" : "+v"(rpb1)); else asm volatile("" : "+v"(rx.w));
         const bool in = d.n0 + srow < N1;
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 vc = in ? rc : z, vp = in ? rp : z, vx = (in && aux_real) ? rx : z;
         float* dd = As + (size_t)srow * lda + 4 * sc4;
         *(float2*)dd = make_float2(vc.x, vc.y); *(float2*)(dd + 2) = make_float2(vc.z, vc.w);
         *(float2*)(dd + C) = make_float2(vp.x, vp.y); *(float2*)(dd + C + 2) = make_float2(vp.z, vp.w);
-        if (aux_thread) { *(float2*)(dd + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(dd + 2 * C + 2) = make_float2(vx.z, vx.w); }
+        if constexpr (HOIST) { xaux_a = tr_aux_a(rwj, lane); xaux_b0 = lane < 32 ? rpb0 : 0.f; xaux_b1 = lane < 32 ? rpb1 : 0.f; }
+        else if (aux_thread) { *(float2*)(dd + 2 * C) = make_float2(vx.x, vx.y); *(float2*)(dd + 2 * C + 2) = make_float2(vx.z, vx.w); }
     };
     auto store_out = [&](const float* T, float* dst, int n0) {      // a [16][64] LDS tile -> rows n0.. of a [N1][64] array (plain stores: read by later kernels only)
         const float2 v0 = *(const float2*)(T + (size_t)orow * ldg + oc2), v1 = *(const float2*)(T + (size_t)(orow + 8) * ldg + oc2);
@@ -274,6 +281,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         __builtin_amdgcn_sched_barrier(0);
         SQ_PRIO(0);
         f32x4 a0 = (f32x4){0, 0, 0, 0}, a1 = (f32x4){0, 0, 0, 0};
+        if constexpr (HOIST) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xaux_a, xaux_b0, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xaux_a, xaux_b1, a1, 0, 0, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][0].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks][0], w1[ks][1].x, a1, 0, 0, 0);
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         // the next tile's rows: ONE request site (a second one inside the branch above makes the row registers phi nodes, and hipcc
         // resolves them with copies -- i.e. waits for the rows, and for the write-through stores in front of them, right here)
 #if SQ_EXP & 256
-        rc = rp = rx = make_float4(0.25f, 0.5f, 0.125f, 0.75f);
+        rc = rp = rx = make_float4(0.25f, 0.5f, 0.125f, 0.75f); rwj = make_float2(0.5f, 0.f); rpb0 = rpb1 = 0.25f;
 #else
         load_rows(next, true);
 #endif
@@ -411,10 +421,12 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
     constexpr int C = 64;
     constexpr int ldx = ((C + 29) / 32) * 32 + 2, ldz = ((2 * C + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
     constexpr int NJ = (NTK + 3) / 4;
+    constexpr bool HOIST = NTK == 8;                              // the auxiliary 1x1 at frame rate (TrainParams::hoist): no aux columns in the input gradient; D / G instead (train_common.h, tr_aux_bwd)
     extern __shared__ float sm[];
     float* Dz = sm + 8 * 16 * ldx;
     float* Os = Dz + 16 * ldz;
     int* ctl = (int*)(Os + 16 * ldo);
+    float* Gp = (float*)(ctl + 32);                               // hoist: [4 waves][16 rows] partial sums of dZ[row][.] * PA[frame(row)][.]
     const int Ap = p.Ap, N1 = p.N1;
     const int tid = threadIdx.x, lane = tid & 63, wave = sq_rfl(tid >> 6);
     const int srow = tid >> 4, sc4 = tid & 15;
@@ -440,11 +452,12 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         }
         // waited for HERE, on the layer change's own path: left to the first MFMA that reads them, the wait lands on every tile's path (hipcc merges
         // the two paths' pending counts), where it waits for the previous tile's outputs instead
-        static_assert(NJ == 3, "the operand list below names every float4 of wr / w1");
+        static_assert(NJ == 3 || NJ == 2, "the operand lists below name every float4 of wr / w1");
         asm volatile("" :: "v"(wr[0].w), "v"(wr[1].w), "v"(wr[2].w), "v"(wr[3].w),
                      "v"(w1[0][0].w), "v"(w1[0][1].w), "v"(w1[0][2].w), "v"(w1[0][3].w), "v"(w1[0][4].w), "v"(w1[0][5].w), "v"(w1[0][6].w), "v"(w1[0][7].w),
-                     "v"(w1[1][0].w), "v"(w1[1][1].w), "v"(w1[1][2].w), "v"(w1[1][3].w), "v"(w1[1][4].w), "v"(w1[1][5].w), "v"(w1[1][6].w), "v"(w1[1][7].w),
-                     "v"(w1[2][0].w), "v"(w1[2][1].w), "v"(w1[2][2].w), "v"(w1[2][3].w), "v"(w1[2][4].w), "v"(w1[2][5].w), "v"(w1[2][6].w), "v"(w1[2][7].w));
+                     "v"(w1[1][0].w), "v"(w1[1][1].w), "v"(w1[1][2].w), "v"(w1[1][3].w), "v"(w1[1][4].w), "v"(w1[1][5].w), "v"(w1[1][6].w), "v"(w1[1][7].w));
+        if constexpr (NJ == 3)
+            asm volatile("" :: "v"(w1[NJ - 1][0].w), "v"(w1[NJ - 1][1].w), "v"(w1[NJ - 1][2].w), "v"(w1[NJ - 1][3].w), "v"(w1[NJ - 1][4].w), "v"(w1[NJ - 1][5].w), "v"(w1[NJ - 1][6].w), "v"(w1[NJ - 1][7].w));
     };
     auto rsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
     // the rows of a tile come from two places: what this layer's forward and the post-net's backward left (sigma, tanh, the skip-path gradient:
@@ -480,6 +493,16 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         float* d0 = B + (size_t)srow * ldx + 4 * sc4;
         *(float2*)d0 = make_float2(dx.x, dx.y); *(float2*)(d0 + 2) = make_float2(dx.z, dx.w);
     };
+    // aux hoist: the WJ entries of this lane's four dZ rows and its four PA values (tr_aux_bwd) -- c*: the tile in hand, n*: the next tile's, in flight
+    float2 cwj[4], nwj[4]; float cpa[4], npa[4]; float dacc[4] = {0.f, 0.f, 0.f, 0.f};
+    float eacc[2] = {0.f, 0.f};
+    auto load_aux = [&](const SqTile& d, float2 (&wj)[4], float (&pa)[4]) {
+        const float2* w = p.WJ + d.n0 + 4 * (lane >> 4);          // (16 rows of padding behind row N1 - 1)
+        const float* q4 = p.PA + d.hrow + 16 * wave + (lane & 15);      // d.hrow: float offset of the tile's first frame in PA / DPA
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wj[i] = w[i];
+        pa[0] = q4[0]; pa[1] = q4[C]; pa[2] = q4[2 * C]; pa[3] = q4[3 * C];
+    };
     int tprow[4];
     auto load_taps = [&](const SqTile& d, int (&tp)[4]) {
 #pragma unroll
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         }
 #endif
         float* DBout = bw.DXB[0] + (size_t)d.xrow * C;
-        float* DH = bw.DHUP + (size_t)d.hrow * Ap;
+        float* DH = HOIST ? nullptr : bw.DHUP + (size_t)d.hrow * Ap;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {      // wave w owns rows 4w .. 4w+3, lane = channel: one 256-byte row per instruction
             const int r = 4 * wave + i, n = d.n0 + r;
@@ -517,11 +540,23 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
                 float* db = DBout + (__umul24((unsigned)tprow[i], (unsigned)C) + lane);
                 atomicAdd(in ? db : dmy + 128 + lane, Os[(size_t)r * ldo + C + lane]);
             }
-            if (lane < Ap) {
+            if constexpr (!HOIST) if (lane < Ap) {
                 float* dh = DH + (__umul24((unsigned)n, (unsigned)Ap) + lane);
                 atomicAdd(in ? dh : dmy + 192 + lane, Os[(size_t)r * ldo + 2 * C + lane]);
             }
 #endif
+        }
+        if constexpr (HOIST) {
+#if !(SQ_EXP & 1)
+            // D_l[frame][gate row] += this tile's share (two frames x sigma / tanh: 64-byte strips of lanes 0..15), and the tile's 16 G values
+            if (lane < 16) {
+                float* dp = bw.DPA + d.hrow + 16 * wave + lane;
+                atomicAdd(dp, dacc[0]); atomicAdd(dp + C, dacc[1]); atomicAdd(dp + 2 * C, dacc[2]); atomicAdd(dp + 3 * C, dacc[3]);
+                float* ep = bw.EB + (size_t)(sq_layer(d) * TR_EB_SLOTS + (blockIdx.x & (TR_EB_SLOTS - 1))) * 2 * C + 16 * wave + lane;       // the gate-bias accumulators: a slab per workgroup index mod 32
+                atomicAdd(ep, eacc[0]); atomicAdd(ep + C, eacc[1]);
+            }
+#endif
+            if (tid < 16 && d.n0 + tid < N1) bw.GW[(size_t)d.xrow + d.n0 + tid] = (Gp[tid] + Gp[16 + tid]) + (Gp[32 + tid] + Gp[48 + tid]);
         }
     };
     auto publishes = [&](const SqTile& d) { return sq_valid(d) && sq_layer(d) > 0; };     // (layer 0's input gradient feeds later kernels only)
@@ -545,6 +580,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
     load_weights(lw, sq_last(cur));
     sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
     load_own(cur); load_ab(cur, ra, rb2);
+    if constexpr (HOIST) load_aux(cur, cwj, cpa);
     load_taps(cur, tprow);
     store_own(cur, sm); store_dx(cur, sm, ra, rb2);
     bool cur_published = false;
@@ -587,13 +623,22 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             }
         }
         SQ_PRIO(2);
+        float dzs[4], dzt[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * (lane >> 4) + i;
             const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
             const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-            Dz[(size_t)r * ldz + c] = dg * th * sg * (1.0f - sg);
-            Dz[(size_t)r * ldz + C + c] = dg * sg * (1.0f - th * th);
+            dzs[i] = dg * th * sg * (1.0f - sg); dzt[i] = dg * sg * (1.0f - th * th);
+            Dz[(size_t)r * ldz + c] = dzs[i];
+            Dz[(size_t)r * ldz + C + c] = dzt[i];
+        }
+        if constexpr (HOIST) {      // the frame-rate aux term's backward (what the 48 aux columns of dZ . W1 and the dH atomics were)
+            const TrAuxBwd ab = tr_aux_bwd(cwj, cpa, dzs, dzt, lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dacc[k] = ab.d[k];
+            eacc[0] = ab.e[0]; eacc[1] = ab.e[1];
+            if ((lane & 15) == 0) { float* gq = Gp + 16 * wave + 4 * (lane >> 4); gq[0] = ab.gp[0]; gq[1] = ab.gp[1]; gq[2] = ab.gp[2]; gq[3] = ab.gp[3]; }
         }
         SQ_STAMPB(1);
         TR_LDS_BARRIER();                                          // B2
@@ -602,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;
         unsigned fv0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fv1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
         load_own(next);
+        if constexpr (HOIST) load_aux(next, nwj, npa);
         int tpn[4]; load_taps(next, tpn);
         unsigned rtk = 0;
         if (tid == 0) rtk = atomicAdd(head, 1u);
@@ -625,7 +671,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         // phase, half of this one), and every quarter of a tile by which a flag is early is one by which its consumer's look is less likely to miss.
         // Counted wait: the request group is younger than those outputs -- eleven requests (twelve in wave 0: the ticket); the count waited down to is
         // two BELOW that, so a group hipcc manages to issue with fewer instructions still cannot let an output through
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        // (hoist: six more requests in the group -- the four WJ entries as two 16-byte loads, four PA values: seventeen, eighteen in wave 0)
+        if constexpr (HOIST) { if (wave == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
+        else { if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
         {
             int old = 0;
             if (lane == 0) old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -644,6 +692,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         // (hipcc does not see that wait: every register the group loaded is named here, or its own wait for the youngest of them -- the taps, the
         //  ticket -- lands behind the publishing store and the outputs, in the middle of their way to memory)
         asm volatile("" : "+v"(fv0), "+v"(fv1), "+v"(rtk), "+v"(tpn[0]), "+v"(tpn[1]), "+v"(tpn[2]), "+v"(tpn[3]));
+        if constexpr (HOIST) asm volatile("" : "+v"(nwj[0].x), "+v"(nwj[1].x), "+v"(nwj[2].x), "+v"(nwj[3].x), "+v"(npa[0]), "+v"(npa[1]), "+v"(npa[2]), "+v"(npa[3]));
         SQ_STAMPB(3);
         bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
 #if SQ_EXP & 32
@@ -715,6 +764,10 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
         SQ_STAMPB(7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) tprow[i] = tpn[i];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cwj[i] = nwj[i]; cpa[i] = npa[i]; }
+        }
         prev = cur; cur = next; next = n2;
         if (!sq_valid(cur)) break;
     }
@@ -735,7 +788,7 @@ static void sq_arm(StackQ& q, const TrainKnobs& k) {
 #endif
 }
 bool qpn_stack_fwd_fits(const TrainParams& p) {
-    return p.C == 64 && p.Ktp == 176 && p.L >= 1 && p.L <= TR_MAXL && p.B < 65536 && (int64_t)p.N1 * p.C * 4 <= (1ll << 30) &&
+    return p.C == 64 && (p.hoist ? p.Ktp == 128 : p.Ktp == 176) && p.L >= 1 && p.L <= TR_MAXL && p.B < 65536 && (int64_t)p.N1 * p.C * 4 <= (1ll << 30) &&
            (int64_t)(p.L + 1) * p.B * p.N1 < (1ll << 31);
 }
 
@@ -764,7 +817,7 @@ static int launch_stack_fwd_k(const TrainParams& p, const StackQ& q, const Train
     return QPN_OK;
 }
 int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
-    return launch_stack_fwd_k<11>(p, q, k, stream);
+    return p.hoist ? launch_stack_fwd_k<8>(p, q, k, stream) : launch_stack_fwd_k<11>(p, q, k, stream);
 }
 
 bool qpn_stack_bwd_fits(const TrainParams& p) {
@@ -774,7 +827,7 @@ bool qpn_stack_bwd_fits(const TrainParams& p) {
 template <int NTK>
 static int launch_stack_bwd_k(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
     constexpr int ldx = ((64 + 29) / 32) * 32 + 2, ldz = ((128 + 29) / 32) * 32 + 2, ldo = ((16 * NTK + 29) / 32) * 32 + 2;
-    const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 128;
+    const size_t lds = (size_t)(8 * 16 * ldx + 16 * ldz + 16 * ldo) * sizeof(float) + 128 + 256;      // + control words, + the hoist form's G partials
     // 1.5 workgroups per CU: the skip / post-net weight gradients run on the side stream while this launch is resident (qpn_launch_bwd), and a
     // launch that fills every CU twice over leaves them no room -- measured on the overlapped step: 0.846 ms with 2 per CU, 0.776 with 1.5,
     // 0.778 with 1, 0.790 for the eight per-layer launches
@@ -788,5 +841,5 @@ static int launch_stack_bwd_k(const TrainParams& p, const TrainBwd& bw, const St
     return QPN_OK;
 }
 int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream) {
-    return launch_stack_bwd_k<11>(p, bw, q, k, stream);
+    return p.hoist ? launch_stack_bwd_k<8>(p, bw, q, k, stream) : launch_stack_bwd_k<11>(p, bw, q, k, stream);
 }

@@ -28,3 +28,58 @@ def run_giveup_child(which, env_name):
     env[env_name] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "giveup_child.py"), which], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "GIVEUP_CHILD_OK " + which in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=1e-4, kink_eps=4e-6, max_units=6):
+    """Per-tensor comparison of a flat gradient with the numpy oracle's hand-derived backward: |g - ref| <= a_scale * max|ref (all tensors)| +
+    a_rel * max|ref (this tensor)|.
+
+    ReLU kinks: where a post-net pre-activation of the oracle's forward lies within fp32 reassociation error of zero (|s0| or |y0| < kink_eps;
+    the logits of two correct fp32 implementations differ by ~1e-6), which side of the kink a unit falls on is decided by summation order, not
+    by the algorithm -- and the side changes that row's gradient by a whole, small, term.  For those units (at most `max_units`) either side is
+    accepted: the gradient must match the oracle's backward for ONE assignment of sides.  Returns the oracle gradient that matched."""
+    import itertools
+    import numpy as np
+    offs, _ = cfg.param_offsets()
+
+    def worst(og):
+        scale = np.abs(og).max()
+        bad = None
+        for k, (o, shp) in offs.items():
+            n = int(np.prod(shp))
+            a, r = grad[o:o + n], og[o:o + n]
+            e, bound = np.abs(a - r).max(), a_scale * scale + a_rel * np.abs(r).max()
+            if e > bound and (bad is None or e / bound > bad[1]):
+                bad = ("%s: err %.3e > bound %.3e" % (k, e, bound), e / bound)
+        return bad
+
+    og = TO.backward(cfg, flat, caches, dl)
+    bad = worst(og)
+    if bad is None:
+        return og
+    units = [(b, key, idx) for b, c in enumerate(caches) for key in ("s0", "y0") for idx in zip(*np.nonzero(np.abs(c[key]) < kink_eps))]
+    assert units and len(units) <= max_units, "grad mismatch in %s (%d pre-activations within %.0e of a ReLU kink)" % (bad[0], len(units), kink_eps)
+    saved = [caches[b][key][idx] for b, key, idx in units]
+    try:
+        for signs in itertools.product((1.0, -1.0), repeat=len(units)):
+            for (b, key, idx), sg in zip(units, signs):
+                caches[b][key][idx] = sg * kink_eps
+            ogv = TO.backward(cfg, flat, caches, dl)
+            if worst(ogv) is None:
+                return ogv
+    finally:
+        for (b, key, idx), v in zip(units, saved):
+            caches[b][key][idx] = v
+    raise AssertionError("grad mismatch in %s, for every side of the %d near-kink units too" % (bad[0], len(units)))
+
+
+def assert_weights_after_adam(w, w_ref, lr, steps, tight=2e-6, frac=0.06, far=0.5):
+    """Final weights after `steps` Adam steps against a reference run.  Adam moves an element by ~lr per step whatever its gradient's size
+    (m / sqrt(v)), so where a gradient is at fp32-noise level -- e.g. after a post-net pre-activation fell on the other side of a ReLU kink that lies
+    within reassociation error of zero (util.assert_grads_match_oracle) -- two correct runs may disagree on a fraction of a step: all but `frac` of the
+    elements agree to `tight`, none differs by more than `far` of the distance travelled.  (The per-step LOSS, north_star's criterion, is checked
+    to 1e-4 next to this; gradients are compared with the oracle tensor by tensor in the autograd tests.)"""
+    import numpy as np
+    d = np.abs(np.asarray(w, dtype=np.float64) - np.asarray(w_ref, dtype=np.float64))
+    assert d.max() <= far * lr * steps, "max |dw| %.3e > %.3e" % (d.max(), far * lr * steps)
+    assert (d > tight).mean() < frac, "%.2f %% of the elements differ by more than %.0e" % (100 * (d > tight).mean(), tight)
