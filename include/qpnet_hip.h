@@ -156,6 +156,9 @@ int qpn_train_status_collect(qpn_handle* h);
 /* ... every enqueued check EXCEPT the newest one: never waits for the work the device still has queued (a fused training loop calls it
  * at the start of every step and reports a bad chunk two steps late at most; reference: the in-line asserts of qpnet.py:294, qpnet_train.py:525). */
 int qpn_train_status_collect_lagged(qpn_handle* h);
+/* The same without ever waiting: only the checks whose copies have already landed are reported (hipEventQuery); *pending (may be NULL)
+ * receives the number still in flight.  For callers that must not stall the host behind queued work (QPNet.status_check = "lazy"). */
+int qpn_train_status_poll(qpn_handle* h, int* pending);
 
 /* torch.nn.CrossEntropyLoss() (mean) on the logits above and, optionally, its gradient
  * (reference src/bin/qpnet_train.py:430,526-528; a target outside [0, n_quantize) is clamped and flagged: qpn_train_status
@@ -223,6 +226,9 @@ int qpn_train_stack_stats(qpn_handle* h, unsigned* h_out, int n, void* stream);
  * `stream` is made to wait for exactly that (an event, no host wait).  The caller all-reduces that range on `stream`, the rest [0, *first) on
  * the stream the backward was enqueued on, and joins the two before qpn_adam_step_ex.  *count = 0: nothing finished early, exchange the whole buffer. */
 int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream);
+/* First element of that tail (a property of the parameter layout; -1 if the layout has no such tail or the handle has not trained yet): ranks
+ * agree on it ONCE before they split the exchange, so that every rank issues the same collectives in every step. */
+int64_t qpn_train_early_first(qpn_handle* h);
 int qpn_train_profile_begin(qpn_handle* h, void* stream);
 int qpn_train_profile_mark(qpn_handle* h, int group, void* stream);   /* attribute the work enqueued since the previous mark to `group` */
 int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);

@@ -8,7 +8,9 @@ File(name, mode) as a context manager, `path in f`, `f[path][()]`, `f[path].shap
 what it writes, and it reads what `h5import` or h5py wrote (tests/test_formats_cpu.py).  Numeric datasets only (the
 reference stores float arrays); contiguous layout, native byte order, as h5py's create_dataset(data=...) does.
 
-QPN_LIBHDF5=<path> names the library; otherwise the loader's search path and a few usual places are tried."""
+QPN_LIBHDF5=<path> names the library; otherwise the loader's search path and a few usual places are tried.  libhdf5 >= 1.10 (64-bit hid_t) is
+required and checked.  The C library is not thread-safe unless built so: a File object and everything read through it stay on the thread that
+opened it (the loaders open, read and close inside one call of the prefetch thread)."""
 import ctypes as C
 import ctypes.util
 import os
@@ -45,6 +47,14 @@ def _lib():
             err = e
     else:
         raise ImportError("no HDF5 library found (tried %s): %s" % (", ".join(names), err))
+    # hid_t (and the H5T_NATIVE_*_g / H5P_* id globals read below) are 64-bit integers since HDF5 1.10; in 1.8.x they are 32-bit ints, and
+    # reading 8 bytes of a 4-byte global or passing 64-bit ids would give garbage ids -- failed or silently wrong reads.  Refuse older libraries.
+    maj, mnr, rel = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    lib.H5get_libversion.restype = C.c_int
+    lib.H5get_libversion.argtypes = [C.POINTER(C.c_uint)] * 3
+    if lib.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel)) < 0 or (maj.value, mnr.value) < (1, 10):
+        raise ImportError("HDF5 %d.%d.%d at %s is older than 1.10 (32-bit hid_t): qpnet_amd._hdf5 needs libhdf5 >= 1.10 or h5py"
+                          % (maj.value, mnr.value, rel.value, n))
     sig = {
         "H5open": (C.c_int, []), "H5Eset_auto2": (C.c_int, [_hid, C.c_void_p, C.c_void_p]),
         "H5Fcreate": (_hid, [C.c_char_p, C.c_uint, _hid, _hid]), "H5Fopen": (_hid, [C.c_char_p, C.c_uint, _hid]),

@@ -43,6 +43,7 @@ SYMBOLS = [
     ("qpn_train_status_enqueue", _i, [_vp, _vp]),
     ("qpn_train_status_collect", _i, [_vp]),
     ("qpn_train_status_collect_lagged", _i, [_vp]),
+    ("qpn_train_status_poll", _i, [_vp, C.POINTER(C.c_int)]),
     ("qpn_train_forward_loss", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     ("qpn_train_loss", _i, [_vp, C.POINTER(C.c_double), _vp]),
     ("qpn_train_loss_enqueue", _i, [_vp, _vp]),
@@ -52,6 +53,7 @@ SYMBOLS = [
     ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     ("qpn_train_stack_stats", _i, [_vp, C.POINTER(C.c_uint), _i, _vp]),
     ("qpn_train_early_bucket", _i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
+    ("qpn_train_early_first", _i64, [_vp]),
     ("qpn_train_profile_begin", _i, [_vp, _vp]),
     ("qpn_train_profile_mark", _i, [_vp, _i, _vp]),
     ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),

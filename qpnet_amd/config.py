@@ -112,3 +112,8 @@ TINY = QPNetConfig(n_resch=32, n_skipch=32, dilationF_depth=2, dilationF_repeat=
 PAPER = QPNetConfig(n_resch=64, n_skipch=256, dilationF_depth=4, dilationF_repeat=1,
                     dilationA_depth=4, dilationA_repeat=1)
 DEFAULT = QPNetConfig()
+# the reference's second shipped network, 'Rd10Rr3Ed4Er1' (src/utils/param_model.py:66-72: 30 fixed layers with dilations up to 512 + 4 adaptive,
+# max_length 22500), at the repo's channel widths ...
+DEEP = QPNetConfig(dilationF_depth=10, dilationF_repeat=3, dilationA_depth=4, dilationA_repeat=1)
+# ... and at the paper-size widths the reference-made fixtures use (tests/golden/*_deep.npz)
+DEEP64 = QPNetConfig(n_resch=64, n_skipch=256, dilationF_depth=10, dilationF_repeat=3, dilationA_depth=4, dilationA_repeat=1)

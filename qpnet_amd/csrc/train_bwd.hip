@@ -1292,9 +1292,13 @@ __global__ __launch_bounds__(128) void k_aux_tail(AuxArgs p) {
 
 // torch.optim.Adam (single tensor semantics, fp32)
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den, const int* __restrict__ status) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // The device-side status word (sticky until the host reads it: a tap / target out of range, an abandoned stack launch) flags results that must not
+    // reach the parameters: the update of a flagged step -- and of the steps enqueued behind it until the host has collected the word, two steps later
+    // at most -- is skipped; weights and both moments stay what the last clean step left (the host raises; the caller may drop the chunk and go on).
+    if (status && *status) return;
     float gi = g[i];
     if (den) gi = gi / den[0];                                  // data-parallel: summed row-weighted gradients / summed row count
     if (wd != 0.f) gi += wd * w[i];
@@ -1565,9 +1569,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }
 
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream) {
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status, hipStream_t stream) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), den);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), den, status);
     qpn_prof_mark(PG_ADAM, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

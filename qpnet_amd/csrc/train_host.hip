@@ -13,7 +13,7 @@ int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, i
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, hipStream_t stream);
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status, hipStream_t stream);
 
 
 struct TrainState {
@@ -609,7 +609,7 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
 
 static int status_to_rc(int st) {
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
-    if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup: this step's results are invalid; the handle runs a launch per layer from here on (QPN_STACK_QUEUE=0 selects that from the start)"); return QPN_ENODEV; }
+    if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup: the flagged step's results are invalid (its Adam update, and that of the steps enqueued behind it until this report, were skipped on the device: parameters and moments are those of the last clean step); the handle runs a launch per layer from here on (QPN_STACK_QUEUE=0 selects that from the start)"); return QPN_ENODEV; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
     return QPN_OK;
 }
@@ -652,6 +652,20 @@ extern "C" int qpn_train_status_collect(qpn_handle* h) {
     TrainState* t = h->train;
     rc = status_collect_slot(t, t->status_newest ^ 1); if (rc) return rc;
     return status_collect_slot(t, t->status_newest);
+}
+// ... and without waiting at all: only the checks whose copies have already landed are looked at (hipEventQuery); *pending = checks still in flight
+extern "C" int qpn_train_status_poll(qpn_handle* h, int* pending) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (pending) *pending = 0;
+    if (!h->train) return QPN_OK;
+    TrainState* t = h->train;
+    for (int k = 0; k < 2; ++k) {
+        const int slot = k == 0 ? t->status_newest ^ 1 : t->status_newest;      // older first
+        if (!t->status_pending[slot]) continue;
+        if (hipEventQuery(t->ev_status[slot]) != hipSuccess) { (void)hipGetLastError(); if (pending) ++*pending; continue; }
+        rc = status_collect_slot(t, slot); if (rc) return rc;
+    }
+    return QPN_OK;
 }
 extern "C" int qpn_train_status_collect_lagged(qpn_handle* h) {
     int rc = need_dev(h); if (rc) return rc;
@@ -721,6 +735,10 @@ extern "C" int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* co
     return QPN_OK;
 }
 
+// first element of the flat-gradient tail that a backward finishes early (the post-net blocks; the 4-float trailer follows them), or -1: a
+// property of the model's parameter layout, known once the handle has trained a step -- what data-parallel ranks agree on before they split the exchange
+extern "C" int64_t qpn_train_early_first(qpn_handle* h) { return (h && h->train && h->device >= 0) ? h->train->early_first : -1; }
+
 extern "C" int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
                              int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream_) {
     return qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream_);
@@ -731,5 +749,5 @@ extern "C" int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_gra
                                 const float* d_grad_denominator, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
-    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, (hipStream_t)stream_);
+    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, h->train ? h->train->d_status : nullptr, (hipStream_t)stream_);
 }

@@ -831,7 +831,10 @@ static int launch_stack_bwd_k(const TrainParams& p, const TrainBwd& bw, const St
     // 1.5 workgroups per CU: the skip / post-net weight gradients run on the side stream while this launch is resident (qpn_launch_bwd), and a
     // launch that fills every CU twice over leaves them no room -- measured on the overlapped step: 0.846 ms with 2 per CU, 0.776 with 1.5,
     // 0.778 with 1, 0.790 for the eight per-layer launches
-    int G = k.stack_wgs_bwd > 0 ? k.stack_wgs_bwd : qpn_num_cus() * 3 / 2;
+    // (round 5, the K = 128 form: 1.25 per CU -- 320 -- measured 1411-1415 steps/s against 1375 at 384 and 1365 at 256; counts whose groups of eight
+    //  do not divide evenly over the eight sub-queues -- 304, 336, 352 -- are 3-4 % slower)
+    int G = k.stack_wgs_bwd > 0 ? k.stack_wgs_bwd : (NTK == 8 ? qpn_num_cus() * 5 / 4 / 64 * 64 : qpn_num_cus() * 3 / 2);
+    if (G < 8) G = qpn_num_cus();
     if (G > q.total) G = q.total;
     if (G > 1024) G = 1024;
     QPN_HIP(hipFuncSetAttribute((const void*)k_stack_bwd<NTK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -73,3 +73,15 @@ def broadcast_parameters(flat, src=0, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+def replica_drift(flat, src=0, group=None):
+    """max |w_r - w_src| over the ranks (0.0 on every rank when the replicas are bit-identical, as identical Adam steps on an identical summed
+    gradient keep them).  One broadcast + one all-reduce of the parameter vector: a check for the END of a run, not for the step."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0.0
+    ref = flat.detach().clone()
+    dist.broadcast(ref, src=src, group=group)
+    d = (flat.detach() - ref).abs().max().reshape(1)
+    dist.all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+    return float(d.item())

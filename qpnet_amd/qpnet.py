@@ -121,6 +121,7 @@ class QPNet(nn.Module):
         self._handle = None
         self._handle_dev = None
         self._qpn_sync_status = False
+        self.status_check = "backward"     # "backward": loss.backward() waits for the forward's device-side check (raised before ANY optimizer steps); "lazy": never waits (train.QPNetFunction.backward)
         self.last_decode_kernel_ms = 0.0
         self.last_decode_plan = ""
         self.sampling_seed = None          # set to an int to pin the sampling-mode random stream
@@ -141,6 +142,15 @@ class QPNet(nn.Module):
                 _lib.check(L.qpn_create(C.byref(_lib.make_config(self.cfg)), C.byref(hp)))
             self._handle, self._handle_dev = hp, device
         return L, self._handle
+
+    def _replicate_for_data_parallel(self):
+        """torch.nn.DataParallel with more than one device (the reference wraps the model so, src/bin/qpnet_train.py:416-423, but forces one GPU:
+        runQP.py:84-88) would call this once per replica.  The module's state -- the native handle, its workspace with the forward's activations, the
+        flat parameter buffer the parameters are views of -- belongs to ONE device and is not carried by replicate(): refuse instead of training on
+        replicas that silently share or lose it.  Multi-GPU here is one process per GPU (python -m qpnet_amd.run_train --n_gpus N: RCCL all-reduce of
+        the flat gradient); DataParallel over a single device never replicates and works."""
+        raise RuntimeError("qpnet_amd.QPNet cannot be replicated by torch.nn.DataParallel over several devices (its native handle and flat parameter "
+                           "buffer are per-device state); use one process per GPU: python -m qpnet_amd.run_train --n_gpus N")
 
     def check_status(self):
         """Raise what the device-side checks of the training forwards so far have found (a dilated factor outside the layer input --

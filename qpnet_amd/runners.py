@@ -267,12 +267,23 @@ def run_train(argv=None, update=False):
             last = trainer.flush_loss() if lagged else None
             if last is not None:
                 loss += last
+            # the device-side checks of the last steps (a dilated factor outside the layer input, a target outside [0, n_quantize), an abandoned
+            # stack launch: the reference asserts in every step, qpnet.py:294, qpnet_train.py:525) are collected HERE -- before an interval
+            # is reported, before a checkpoint and before the final model are written: nothing flagged reaches the disk
+            trainer.check_status()
         if (i + 1) % args.intervals == 0:
             logging.info("(iter:%d) average loss = %.6f (%.3f sec / batch)" % (i + 1, loss / args.intervals, total / args.intervals))
             loss_record.append(loss / args.intervals)
             loss = total = 0.0
         if (i + 1) % args.checkpoint_interval == 0 and rank == 0:
             loaders.save_checkpoint(args.expdir, model, trainer, i + 1)
+    if world > 1:
+        # every rank applied the same Adam step to the same summed gradient: the replicas must still be bit-identical (a rank that consumed a different
+        # chunk count, a diverged knob or a lost collective shows here, before the final model is written)
+        drift = parallel.replica_drift(ensure_flat(model, dev))
+        if drift != 0.0:
+            raise RuntimeError("data-parallel replicas drifted apart: max |w_r - w_0| = %g" % drift)
+        logging.info("replicas identical on %d ranks." % world)
     if rank == 0:
         loaders.save_final(args.expdir, model)
         logging.info("final checkpoint created.")

@@ -135,7 +135,15 @@ class QPNetFunction(torch.autograd.Function):
             raise RuntimeError("qpnet_amd: backward of a forward whose activations have been replaced by a later forward of the "
                                "same model (one outstanding forward per model; run validation forwards after backward)")
         with torch.cuda.device(dev):
-            _lib.check(L.qpn_train_status_collect(hd))       # the forward's gather-bounds / target check (its copy finished long ago)
+            # the forward's gather-bounds / target check.  Default: WAIT for its copy (it sits behind the forward's kernels, so a host that runs ahead of
+            # the device blocks here until the forward has drained) -- the one way to raise BEFORE an optimizer this module does not control (stock
+            # torch.optim.Adam) steps on a flagged gradient, as the reference's in-line assert does (qpnet.py:294).  model.status_check = "lazy": only
+            # what has already landed is looked at (hipEventQuery); the rest is collected by FlatAdam.step / the next forward / model.check_status(),
+            # and the fused Adam kernel skips flagged updates on the device by itself.
+            if getattr(model, "status_check", "backward") == "lazy":
+                _lib.check(L.qpn_train_status_poll(hd, None))
+            else:
+                _lib.check(L.qpn_train_status_collect(hd))
         flat = model._flat
         dl = dlogits.contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -154,7 +162,8 @@ def _anchored_backward(model, L, hd, dl, flat, stream, dev):
     """The reference loop's backward without autograd's 120-way fan-out (qpnet_train.py:527-531: zero_grad, loss.backward(), optimizer.step()).
     The graph holds ONE anchor leaf instead of the 120 parameters, and this function gives every parameter its .grad itself, with
     loss.backward()'s semantics: parameters without a gradient (after optimizer.zero_grad(), whose default sets them to None) get one, the
-    others accumulate.  The gradients are consecutive views of one persistent flat buffer the kernels write directly, so the usual step
+    others accumulate.  The gradients are consecutive views of one persistent flat buffer the kernels write directly (NOTE the aliasing: a reference
+    to a p.grad kept across zero_grad(set_to_none=True) is overwritten by the next backward, unlike torch's fresh tensors), so the usual step
     costs one launch sequence and 120 attribute stores -- measured on the host: 0.63 -> 0.25 ms of the 1.63 ms the unchanged loop spends per step
     (autograd built 120 views and ran 120 AccumulateGrad nodes).  Not visible to this path: torch.autograd.grad() w.r.t. parameters (torch
     reports them as unused in the graph) and tensor hooks on parameters; QPN_DROPIN_FLAT_GRAD=0 hands autograd the parameters as before."""
@@ -363,6 +372,7 @@ class FusedTrainer:
         self._logits = None
         self.last_buckets = (0, 0)
         self._early = None            # the stream the early bucket of the gradient exchange runs on (world_size > 1)
+        self._two_buckets = None      # agreed over the process group at the first data-parallel step (every rank must issue the same collectives)
 
     def _buffers(self, flat):
         if self.m is None or self.m.device != flat.device or self.m.numel() != flat.numel():
@@ -421,8 +431,17 @@ class FusedTrainer:
                     self._early = torch.cuda.Stream(dev)
                 # (opt-in, QPN_EXCHANGE_BUCKETS=2.  Measured with RCCL at one rank: the second call costs 18 us of stream time, 0.841 -> 0.859 ms a
                 #  step; what it can hide at 8 ranks is a quarter of the bandwidth term of a 2.3 MB, latency-bound all-reduce -- DESIGN.md section 7)
-                if os.environ.get("QPN_EXCHANGE_BUCKETS", "1") == "2":
+                if self._two_buckets is None:
+                    # How many collectives a step issues must not be a per-rank decision (environment and launch-plan knobs can differ per rank: a
+                    # rank that sends one all-reduce while its peers send two deadlocks RCCL or corrupts the sum): the split is agreed ONCE, as the
+                    # minimum over the ranks of "this rank wants and can do two buckets"; thereafter every rank issues two all-reduces over the SAME
+                    # ranges in every step, whether or not its early range happened to be ready early in that step.
+                    self._two_buckets = self._agree_two_buckets(L, hd, flat)
+                if self._two_buckets:
                     _lib.check(L.qpn_train_early_bucket(hd, C.byref(first), C.byref(count), self._early.cuda_stream))
+                    if count.value == 0:      # nothing was finished early in this step (one stream: a profile is being taken): same two ranges, after the backward
+                        first.value, count.value = self._two_buckets[0], self._two_buckets[1]
+                        self._early.wait_stream(torch.cuda.current_stream(dev))
                 exchange_two_buckets(self.g, first.value, count.value, self.pg, self._early if count.value else None)
                 self.last_buckets = (first.value, count.value)       # (what the last step exchanged early; (0, 0): one exchange)
                 L.qpn_train_profile_mark(hd, 9, stream)      # QPN_PG_ALLREDUCE (no-op unless a profile is being taken)
@@ -446,6 +465,18 @@ class FusedTrainer:
             elif not capturing:
                 _lib.check(L.qpn_train_status_enqueue(hd, stream))
         return loss.value if want_loss else None
+
+    def _agree_two_buckets(self, L, hd, flat):
+        """(first, count) of the early bucket if EVERY rank asked for two buckets (QPN_EXCHANGE_BUCKETS=2) and reports the same range, else False."""
+        import torch.distributed as dist
+        want = os.environ.get("QPN_EXCHANGE_BUCKETS", "1") == "2"
+        first = int(L.qpn_train_early_first(hd)) if want else -1
+        ok = want and first > 0
+        if dist.is_initialized() and dist.get_world_size(self.pg) > 1:
+            v = torch.tensor([first if ok else -1, -(first if ok else -1)], dtype=torch.int64, device=flat.device if dist.get_backend(self.pg) == "nccl" else "cpu")
+            dist.all_reduce(v, op=dist.ReduceOp.MIN, group=self.pg)      # min(first) == max(first) > 0  <=>  every rank reports the same range
+            ok = int(v[0]) > 0 and int(v[0]) == -int(v[1])
+        return (first, flat.numel() - first + 4) if ok else False
 
     def flush_loss(self):
         """The loss of the last step(want_loss="lagged") (waits for that step), or None if it has been returned already."""

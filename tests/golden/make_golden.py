@@ -6,7 +6,7 @@ data (seeds, small inputs, expected outputs) and are what travels to the GPU box
 Inputs are regenerated from seeds by qpnet_amd.synth (np.random.RandomState: frozen streams),
 so fixtures store only what cannot be regenerated: the reference's outputs.
 
-    python tests/golden/make_golden.py [--only decode|decode2|decode_d|forward|train|kat|default]
+    python tests/golden/make_golden.py [--only decode|decode2|decode_d|forward|train|kat|default|deep]
 """
 import argparse
 import os
@@ -28,7 +28,7 @@ from qpnet_amd import synth  # noqa: E402
 from qpnet_amd.config import TINY, PAPER, QPNetConfig  # noqa: E402
 sys.path.insert(0, HERE)
 from cases import (DECODE_CASES, DECODE_CASES2, DECODE_CASES_D, FORWARD_CASES, TRAIN_CASES, FORWARD_CASES_D, TRAIN_CASES_D,  # noqa: E402
-                   decode2_inputs)
+                   FORWARD_CASES_DEEP, TRAIN_CASES_DEEP, DECODE_CASES_DEEP, decode2_inputs)
 
 torch.set_num_threads(8)
 torch.set_grad_enabled(False)
@@ -182,8 +182,10 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    todo = [a.only] if a.only else ["kat", "decode", "decode2", "decode_d", "forward", "train", "default"]
+    todo = [a.only] if a.only else ["kat", "decode", "decode2", "decode_d", "forward", "train", "default", "deep"]
     for t in todo:
         {"kat": gen_kat, "decode": gen_decode, "decode2": gen_decode2, "forward": gen_forward, "train": gen_train,
          "decode_d": lambda: gen_decode(DECODE_CASES_D, "decode_d.npz"),
-         "default": lambda: (gen_forward(FORWARD_CASES_D, "forward_d.npz"), gen_train(TRAIN_CASES_D, "train_d.npz", 2000))}[t]()
+         "default": lambda: (gen_forward(FORWARD_CASES_D, "forward_d.npz"), gen_train(TRAIN_CASES_D, "train_d.npz", 2000)),
+         "deep": lambda: (gen_forward(FORWARD_CASES_DEEP, "forward_deep.npz"), gen_train(TRAIN_CASES_DEEP, "train_deep.npz", 22500),
+                          gen_decode(DECODE_CASES_DEEP, "decode_deep.npz"))}[t]()

@@ -605,3 +605,20 @@ def test_enqueue_is_asynchronous_and_single_flight(cuda):
     _lib.check(L.qpn_decode_finish(hd, stream))
     assert busy, "qpn_decode_enqueue blocked until the decode had finished"
     assert int(out[0, -1]) >= 0
+
+
+def test_deep_network_decode_matches_reference_stream(cuda, golden_dir, oracle):
+    """The reference's second shipped network, 'Rd10Rr3Ed4Er1' (src/utils/param_model.py:66-72: dilationF_depth 10 x repeat 3 + 4 adaptive = 34 layers,
+    fixed dilations up to 512), at the paper-size widths: the HIP decode against the greedy stream made by the REFERENCE itself (decode_deep.npz,
+    2 199 samples), bit-exact -- and against the oracle with teacher-forced logits, bit for bit."""
+    import torch
+    from cases import DECODE_CASES_DEEP
+    name, cfg, wseed, utts, extra = DECODE_CASES_DEEP[0]
+    g = np.load(golden_dir + "/decode_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, bd, mode="argmax")
+    assert nlist == list(g[name + "_nleft"]) and len(outs) == 1
+    np.testing.assert_array_equal(outs[0], g[name + "_out0"].astype(np.int64), err_msg="HIP vs reference stream")

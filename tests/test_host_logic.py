@@ -70,3 +70,17 @@ def test_synth_is_deterministic():
     np.testing.assert_array_equal(a, b)
     assert a.shape == (50, 39) and a[:, 1].min() >= 45 and a[:, 1].max() <= 450
     assert set(np.unique(a[:, 0])) <= {0.0, 1.0}
+
+
+def test_data_parallel_replicas_are_refused():
+    """torch.nn.DataParallel over several devices would replicate the module (reference wrap: src/bin/qpnet_train.py:416-423, forced to one GPU by
+    runQP.py:84-88); the native handle and the flat parameter buffer are per-device state replicate() does not carry: a clear error, not silence."""
+    import pytest
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.qpnet import QPNet
+    m = QPNet(**TINY.kwargs())
+    wrapped = torch.nn.DataParallel(m)                  # wrapping (and a single device, which never replicates) stays possible
+    assert wrapped.module is m
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        m._replicate_for_data_parallel()                # what torch.nn.parallel.replicate calls for every replica

@@ -243,3 +243,45 @@ def test_train_oracle_default_geometry(golden_dir):
             assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
     np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
     np.testing.assert_allclose(flat[::97], g[name + "_wfinal_sample"], atol=2e-6, rtol=0)
+
+
+# ---------------------------------------------------------------- round 5: the reference's deep network 'Rd10Rr3Ed4Er1' (34 layers, fixed dilations up to 512)
+def test_oracle_deep_network_decode_equals_reference_stream(oracle, golden_dir):
+    """src/utils/param_model.py:66-72 at the paper-size widths: the C oracle against the reference's greedy stream (decode_deep.npz: 2 199 samples; the
+    fixed stack's rings are 2 x 512 rows deep, the receptive field 3 069 + 15 maxd + 1 samples)."""
+    from cases import DECODE_CASES_DEEP
+    name, cfg, wseed, utts, extra = DECODE_CASES_DEEP[0]
+    g = np.load(golden_dir + "/decode_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = oracle.batch_fast_generate(cfg, flat, bx, bh, nlist, bd)
+    assert nlist == list(g[name + "_nleft"])
+    for i, s in enumerate(outs):
+        np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64))
+
+
+def test_train_oracle_deep_network(golden_dir):
+    """the same network: numpy oracle vs the reference's logits / loss / gradient sample / two Adam steps (forward_deep.npz, train_deep.npz)"""
+    from cases import FORWARD_CASES_DEEP, TRAIN_CASES_DEEP
+    from oracle import train_oracle as TO
+    name, cfg, wseed, dseed, bl, ml = FORWARD_CASES_DEEP[0]
+    g = np.load(golden_dir + "/forward_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
+    lg, _ = TO.forward(cfg, flat, x, h, d, b)
+    np.testing.assert_allclose(lg, g[name + "_logits"], atol=5e-5, rtol=0)
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES_DEEP[0]
+    g = np.load(golden_dir + "/train_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    opt = TO.Adam(flat.size)
+    losses = []
+    for step in range(nsteps):
+        x, h, t, d, b = synth.train_inputs(cfg, bl, dseed + step, 22500)
+        loss, grad = TO.train_step(cfg, flat, opt, x, h, t, d, b)
+        losses.append(loss)
+        if step == 0:
+            ref = g[name + "_grad0_sample"]
+            assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    util.assert_weights_after_adam(flat[::97], g[name + "_wfinal_sample"], 1e-4, nsteps)

@@ -103,7 +103,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("cfgname,buckets", [("tiny", 1), ("tiny", 2), ("paper", 2)])
+@pytest.mark.parametrize("cfgname,buckets", [("tiny", 1), ("tiny", 2), ("paper", 2), ("tiny", "mixed")])
 def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, buckets, cuda, tmp_path):
     """Two fresh child processes share GPU 0 and exchange over gloo (RCCL refuses two ranks on one device); each runs the
     product's FusedTrainer(world_size=2) on chunks of unequal batch_length.  Final weights must be bit-identical across
@@ -115,11 +115,13 @@ def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, buckets, cuda, t
     port = 29500 + os.getpid() % 2000
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QPN_EXCHANGE_BUCKETS=str(buckets))
+    # "mixed": the ranks' environments DISAGREE (rank 0 asks for two buckets, rank 1 for one): the split is agreed over the process group at the
+    # first step (train.FusedTrainer._agree_two_buckets), so both fall back to ONE exchange instead of issuing different numbers of collectives
+    envs = [dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", QPN_EXCHANGE_BUCKETS=str((2, 1)[r] if buckets == "mixed" else buckets)) for r in range(2)]
     outs = [str(tmp_path / ("r%d.npz" % r)) for r in range(2)]
     cfg = TINY if cfgname == "tiny" else PAPER
     bls = [300, 410, 350, 280] if cfgname == "tiny" else [1400, 1750, 1500, 1250]
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r], cfgname, ",".join(map(str, bls))], env=env) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r], cfgname, ",".join(map(str, bls))], env=envs[r]) for r in range(2)]
     for p in procs:
         assert p.wait(timeout=420) == 0
     r0, r1 = np.load(outs[0]), np.load(outs[1])

@@ -105,3 +105,51 @@ def test_train_update_validate_decode_entry_points(fmt, cuda, tmp_path, oracle):
     hn = sc.transform(h).astype(np.float32)
     ref = oracle.decode(TINY, flat, np.ascontiguousarray(hn.T), d, np.array([128], dtype=np.int64), h.shape[0] * 110 - 1, maxd=maxd)["samples"]
     np.testing.assert_array_equal(wavfile.read(out + "/u00.wav")[1], loaders.samples_to_int16(ref))
+
+
+def _small_geo(fmt="npy"):
+    return ["--n_resch", "32", "--n_skipch", "32", "--dilationF_depth", "2", "--dilationF_repeat", "1", "--dilationA_depth", "1",
+            "--dilationA_repeat", "1", "--feature_format", fmt, "--batch_length", "1500", "--max_length", "4000", "--verbose", "0"]
+
+
+def test_run_train_two_ranks(cuda, tmp_path, monkeypatch):
+    """python -m qpnet_amd.run_train --n_gpus 2 end to end: the entry point re-launches itself as two ranks under torch.distributed.run (here both
+    on GPU 0 over gloo: QPN_BENCH_ONE_GPU / QPN_DIST_BACKEND, RCCL refuses two ranks on one device), rank r reads chunks r, r + 2, ... of the shared
+    stream, the flat gradient is exchanged once per step, rank 0 alone writes checkpoints -- and before the final model is written the run itself
+    checks that the replicas are still bit-identical (parallel.replica_drift; a drift makes the entry point fail)."""
+    from qpnet_amd import runners
+    monkeypatch.setenv("QPN_BENCH_ONE_GPU", "1"); monkeypatch.setenv("QPN_DIST_BACKEND", "gloo"); monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    root = _corpus(str(tmp_path / "corpus"), n=4)
+    exp = str(tmp_path / "exp")
+    os.makedirs(exp)
+    rc = runners.run_train(["--waveforms", root + "/wav", "--feats", root + "/feat", "--stats", root + "/stats.npz"] + _small_geo() +
+                           ["--expdir", exp, "--config", exp + "/model.conf", "--iters", "4", "--checkpoint_interval", "2", "--intervals", "2",
+                            "--resume", exp + "/none.pkl", "--n_gpus", "2", "--verbose", "1"])
+    assert rc == 0
+    assert sorted(f for f in os.listdir(exp) if f.startswith("checkpoint")) == ["checkpoint-2.pkl", "checkpoint-4.pkl", "checkpoint-final.pkl"]
+    rec = yaml.safe_load(open(exp + "/loss-final.yml"))
+    assert len(rec) == 2 and all(np.isfinite(rec))
+
+
+def test_run_train_does_not_write_a_flagged_model(cuda, tmp_path, monkeypatch):
+    """in run_train's default (lagged) mode the device status of the last steps used to be outstanding when the final model was saved.
+    A target outside [0, n_quantize) injected into the LAST step of a run must raise out of run_train (the reference asserts in the step,
+    qpnet_train.py:525) and leave no checkpoint-final.pkl behind."""
+    from qpnet_amd import _lib, runners
+    from qpnet_amd.train import FusedTrainer
+    root = _corpus(str(tmp_path / "corpus"))
+    exp = str(tmp_path / "exp")
+    os.makedirs(exp)
+    orig = FusedTrainer.step
+
+    def step(self, x, h, t, d, b, **kw):
+        if self.step_count == 4:                    # the fifth and last step
+            t = t.clone(); t[0, -3] = 999
+        return orig(self, x, h, t, d, b, **kw)
+    monkeypatch.setattr(FusedTrainer, "step", step)
+    with pytest.raises(_lib.QpnError) as e:
+        runners.run_train(["--waveforms", root + "/wav", "--feats", root + "/feat", "--stats", root + "/stats.npz"] + _small_geo() +
+                          ["--expdir", exp, "--config", exp + "/model.conf", "--iters", "5", "--checkpoint_interval", "100", "--intervals", "100",
+                           "--resume", exp + "/none.pkl"])
+    assert e.value.code == -4
+    assert not os.path.exists(exp + "/checkpoint-final.pkl")

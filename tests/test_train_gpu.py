@@ -229,6 +229,61 @@ def test_full_size_step_vs_oracle(cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-4, a_rel=2e-3)
 
 
+def test_bench_shape_step_vs_oracle(cuda):
+    """The exact chunk bench.py times (BASELINE config[1] / SURVEY 8d: batch_length 20000, max_length 30000, the corpus' pitch floor 45 Hz pinned in the
+    chunk -> ceil(max d) 62, RF 946, 20 900 samples, 19 954 output rows), default launches (work-queue stack, aux 1x1 at frame rate, side stream):
+    loss within the north_star tolerance and every gradient tensor against the numpy oracle."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    x, h, t, d, b = synth.train_inputs(cfg, 20000, 5000, 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True)
+    BL = int(b[0])
+    assert x.shape[1] == 20900 and BL == 19954 and int(np.ceil(d).max()) == 62
+    m = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=5e-5, rtol=0)
+    util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-4, a_rel=2e-3)
+
+
+def test_a_flagged_step_leaves_parameters_and_moments_alone(cuda):
+    """the device-side status word (here: a target outside [0, n_quantize)) reaches the host up to two steps late in the lagged loop.  The
+    Adam kernel reads the word itself and skips the update while it is set: the flagged step and the steps enqueued behind it change neither the
+    weights nor the moments, check_status() raises, and training goes on from the last clean state."""
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import FusedTrainer
+    cfg = TINY
+    m = util.build_model(cfg, synth.make_weights(cfg, 11), cuda).train()
+    tr = FusedTrainer(m, lr=1e-3)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 41, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    maxd = int(np.ceil(d).max())
+    tr.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)
+    tr.flush_loss(); tr.check_status()
+    w0, m0, v0 = m.flat_parameters().clone(), tr.m.clone(), tr.v.clone()
+    bad = tt.clone(); bad[0, -5] = cfg.n_quantize + 3
+    tr.step(xt, ht, bad, dt, b, want_loss="lagged", maxd=maxd)          # flagged ...
+    tr.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)           # ... and a clean chunk enqueued behind it before the host has looked
+    tr.flush_loss()
+    with pytest.raises(_lib.QpnError) as e:
+        tr.check_status()                                               # (what run_train does before every report / checkpoint / the final model)
+    assert e.value.code == -4
+    assert torch.equal(m.flat_parameters(), w0) and torch.equal(tr.m, m0) and torch.equal(tr.v, v0)
+    tr.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)           # the word has been read: training goes on
+    tr.flush_loss(); tr.check_status()
+    assert not torch.equal(m.flat_parameters(), w0)
+
+
 @pytest.mark.parametrize("geo", [(64, 128, 3, 2, 2, 1), (128, 128, 2, 1, 2, 1), (96, 256, 2, 1, 1, 1)], ids=["C64-F3x2", "C128", "C96"])
 def test_other_geometry_train_vs_oracle(geo, cuda):
     """Geometries outside the BASELINE configs: another skip width and a repeated fixed stack at n_resch 64, and n_resch 96 / 128
@@ -786,3 +841,47 @@ def test_stack_queue_that_gives_up_is_reported_and_replaced(cuda):
     QPN_ENODEV) -- and the handle runs a launch per layer from then on: the next forward is correct.  The hook exists only in the -DQPN_TESTING
     build of the library: tests/giveup_child.py `stack`, in a child process bound to that build."""
     util.run_giveup_child("stack", "QPN_TEST_STACK_GIVES_UP")
+
+
+def test_deep_network_train_vs_reference(cuda, golden_dir):
+    """'Rd10Rr3Ed4Er1' (reference src/utils/param_model.py:66-72: 34 residual layers -- beyond the 32 the training kernels used to carry --, fixed
+    dilations up to 512, max_length 22500) at the paper-size widths: forward logits and loss, per-tensor gradients (numpy oracle) and two fused Adam
+    steps against the reference's fixtures (forward_deep.npz / train_deep.npz).  The stack runs as the one-launch work queue over 34 layers, the post-net
+    on the generic 16-row kernels (the skip sum is K = 34 x 64)."""
+    import torch
+    from cases import FORWARD_CASES_DEEP, TRAIN_CASES_DEEP
+    from oracle import train_oracle as TO
+    from qpnet_amd.train import FusedTrainer
+    name, cfg, wseed, dseed, bl, ml = FORWARD_CASES_DEEP[0]
+    g = np.load(golden_dir + "/forward_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, ml)
+    with torch.no_grad():
+        lg = m(*_to(cuda, x, h, d, b)).cpu().numpy()
+    np.testing.assert_allclose(lg, g[name + "_logits"], atol=5e-5, rtol=0)
+    BL = int(b[0])
+    lse = np.log(np.exp(lg[0].astype(np.float64)).sum(1))
+    assert abs((lse - lg[0][np.arange(BL), t[0, -BL:]]).mean() - float(g[name + "_loss"])) < 1e-4
+    name, cfg, wseed, dseed, bl, nsteps = TRAIN_CASES_DEEP[0]
+    g = np.load(golden_dir + "/train_deep.npz")
+    flat = synth.make_weights(cfg, wseed)
+    m = util.build_model(cfg, flat, cuda).train()
+    x, h, t, d, b = synth.train_inputs(cfg, bl, dseed, 22500)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    BL = int(b[0])
+    loss = torch.nn.CrossEntropyLoss()(m(xt, ht, dt, bt).reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    assert abs(loss.item() - g[name + "_losses"][0]) < 1e-4
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lgo, caches = TO.forward(cfg, flat, x, h, d, b)
+    _, dl = TO.ce_loss(lgo, t[:, -BL:])
+    og0 = TO.backward(cfg, flat, caches, dl)
+    og = util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=2e-4)
+    ref = g[name + "_grad0_sample"] + (og - og0)[::97]
+    assert np.abs(grad[::97] - ref).max() <= 1e-4 * np.abs(ref).max()
+    m2 = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m2, lr=1e-4)
+    losses = [tr.step(*_to(cuda, *synth.train_inputs(cfg, bl, dseed + s, 22500))) for s in range(nsteps)]
+    np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
+    util.assert_weights_after_adam(m2.flat_parameters().cpu().numpy()[::97], g[name + "_wfinal_sample"], 1e-4, nsteps)

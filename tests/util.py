@@ -58,8 +58,26 @@ def assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_r
     if bad is None:
         return og
     units = [(b, key, idx) for b, c in enumerate(caches) for key in ("s0", "y0") for idx in zip(*np.nonzero(np.abs(c[key]) < kink_eps))]
-    assert units and len(units) <= max_units, "grad mismatch in %s (%d pre-activations within %.0e of a ReLU kink)" % (bad[0], len(units), kink_eps)
+    assert units, "grad mismatch in %s (no pre-activation within %.0e of a ReLU kink)" % (bad[0], kink_eps)
     saved = [caches[b][key][idx] for b, key, idx in units]
+    if len(units) > max_units:
+        # too many near-kink units to enumerate their sides (a full-size chunk has ~10 M post-net pre-activations, dozens of them within 4e-6 of
+        # zero): ONE more oracle backward with every such unit on the other side measures what the ambiguity is worth per tensor, and twice that
+        # (the units' contributions may partly cancel in the all-flipped sum) is added to the tensor's bound
+        try:
+            for (b, key, idx), v in zip(units, saved):
+                caches[b][key][idx] = -np.sign(v) * kink_eps if v != 0 else kink_eps
+            ogf = TO.backward(cfg, flat, caches, dl)
+        finally:
+            for (b, key, idx), v in zip(units, saved):
+                caches[b][key][idx] = v
+        scale = np.abs(og).max()
+        for k, (o, shp) in offs.items():
+            n = int(np.prod(shp))
+            a, r = grad[o:o + n], og[o:o + n]
+            bound = a_scale * scale + a_rel * np.abs(r).max() + 2.0 * np.abs(ogf[o:o + n] - r).max()
+            assert np.abs(a - r).max() <= bound, "grad mismatch in %s: err %.3e > bound %.3e (incl. the allowance for %d near-kink units)" % (k, np.abs(a - r).max(), bound, len(units))
+        return og
     try:
         for signs in itertools.product((1.0, -1.0), repeat=len(units)):
             for (b, key, idx), sg in zip(units, signs):

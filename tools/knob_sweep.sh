@@ -1,8 +1,12 @@
 #!/bin/bash
 # dev: two-stream step rate under a list of environment settings ("NAME=VALUE[,NAME=VALUE]" per argument; "-" = none)
-cd $GRAFT_REPO_ROOT
-for kv in "$@"; do
-  envs=""; if [ "$kv" != "-" ]; then envs=$(echo $kv | tr ',' ' '); fi
-  r=$(env $envs timeout -k 10 300 python3 tools/stack_rate.py 2>&1 | grep steps | cut -c1-40)
-  echo "$kv: $r"
-done > gpurun_out/knob_sweep.txt
+#   bash tools/knob_sweep.sh - QPN_STACK_WGS_BWD=512 QPN_STACK_WGS_BWD=256,QPN_WGRAD_CHUNKS_SIDE=32
+for spec in "$@"; do
+  envs=""
+  if [ "$spec" != "-" ]; then envs=$(echo "$spec" | tr ',' ' '); fi
+  v=$(env $envs python3 bench.py --mode train --steps 300 --warmup 30 --no-cpu 2>/dev/null | python3 -c "import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('%.1f steps/s  %.4f ms' % (d['value'], d['ms_per_step']))")
+  echo "$spec : $v"
+done
