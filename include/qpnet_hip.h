@@ -196,6 +196,18 @@ int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d
                      int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                      const float* d_grad_denominator, void* stream);
 
+/* One optimisation step of the reference's training loop (src/bin/qpnet_train.py:517-531: forward, CrossEntropyLoss, backward, Adam.step, loss.item())
+ * behind ONE call: qpn_train_forward_loss + qpn_train_backward + qpn_adam_step and the loss / status bookkeeping, in that order, so that the host side of
+ * a step is a single foreign call.  d_logits / d_dlogits: caller-owned B*BL*n_quantize floats (the logits are not written); d_grad: n (+ 4) floats.
+ * loss_mode 0: none; 1: "lagged" -- this step's loss is copied out behind its kernels, *h_loss receives the previous step's (*h_valid = 0 when there is none;
+ * qpn_train_loss_collect(newest = 1) fetches the last one), the stream is never drained; 2: this step's loss, read in the call.  The device-side status word
+ * (a tap or target out of range) is reported two steps late at most in modes 0 / 1, in the call in mode 2; flagged steps do not touch the parameters. */
+int qpn_train_step(qpn_handle* h, float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                   const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
+                   float* d_logits, float* d_dlogits, float* d_grad, float* d_m, float* d_v, int64_t n,
+                   int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   int loss_mode, double* h_loss, int* h_valid, void* stream);
+
 /* Per-launch-group device timings of the training calls issued between begin and end (HIP events on `stream`; used by bench.py for
  * the roofline).  h_ms[QPN_PG_*] receives milliseconds.  While a profile is being taken a step runs on ONE stream, and every heavy
  * kernel is a group of its own: LAYER_FWD / LAYER_BWD = the residual stack (one work-queue launch each at n_resch 64), WGRAD = the

@@ -751,3 +751,36 @@ extern "C" int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_gra
     if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
     return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, h->train ? h->train->d_status : nullptr, (hipStream_t)stream_);
 }
+
+// One optimisation step behind ONE call -- what a training loop's body is (reference src/bin/qpnet_train.py:517-531: forward, CrossEntropyLoss, backward,
+// Adam.step, loss.item()): the calls FusedTrainer.step used to make one by one, in their order.  The host side of a step is then a single foreign call
+// (a Python caller's other threads -- the loader -- run while it is in progress) instead of seven with interpreter work between them.
+//   loss_mode 0: no loss;  1 "lagged": this step's loss is copied out behind its kernels and *h_loss receives the PREVIOUS step's (*h_valid = 0 at the first
+//   step or right behind a flush: qpn_train_loss_collect(newest = 1) fetches the last one), the stream is never drained;  2: this step's loss, read in the call
+//   (drains the stream, as the reference's loss.item() does).
+// The device-side status word is handled as FusedTrainer.step documents: collected two steps late at most (mode 0 / 1), in the call (mode 2).
+extern "C" int qpn_train_step(qpn_handle* h, float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
+                              const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
+                              float* d_logits, float* d_dlogits, float* d_grad, float* d_m, float* d_v, int64_t n,
+                              int step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int loss_mode, double* h_loss, int* h_valid, void* stream) {
+    if (h_valid) *h_valid = 0;
+    if (h_loss) *h_loss = 0.0;
+    if (loss_mode < 0 || loss_mode > 2 || (loss_mode && (!h_loss || !h_valid))) { qpn_set_error("bad train_step arguments"); return QPN_EINVAL; }
+    int rc = need_dev(h); if (rc) return rc;
+    rc = qpn_train_status_collect_lagged(h); if (rc) return rc;          // the check of the step before the previous one (never waits for queued work)
+    rc = qpn_train_forward_loss(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_targets, tgt_stride, d_logits, 0, d_dlogits, stream); if (rc) return rc;
+    rc = qpn_train_backward(h, d_dlogits, d_grad, stream); if (rc) return rc;
+    rc = qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream); if (rc) return rc;
+    if (loss_mode == 1) {
+        rc = qpn_train_loss_enqueue(h, stream); if (rc) return rc;
+        rc = qpn_train_status_enqueue(h, stream); if (rc) return rc;
+        return qpn_train_loss_collect(h, 0, h_loss, h_valid);
+    }
+    if (loss_mode == 2) {
+        rc = qpn_train_loss(h, h_loss, stream); if (rc) return rc;
+        *h_valid = 1;
+        return qpn_train_status(h, stream);
+    }
+    return qpn_train_status_enqueue(h, stream);
+}

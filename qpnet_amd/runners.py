@@ -86,24 +86,30 @@ class PinnedStager:
 
     def __init__(self, device, depth=4):
         self.device, self.depth = device, depth
-        self.slots = [dict() for _ in range(depth)]       # name -> pinned tensor (grown on demand)
+        self.slots = [None] * depth                        # one pinned byte buffer per slot (grown on demand)
         self.events = [None] * depth
         self.i = 0
 
     def __call__(self, named):
-        """named: {name: cpu tensor} -> {name: device tensor} (asynchronous copies on the current stream)."""
-        slot, k = self.slots[self.i], self.i
+        """named: {name: cpu tensor} -> {name: device tensor}.  ONE asynchronous copy on the current stream: the tensors are packed into the slot's
+        pinned buffer at 256-byte offsets and land in one device buffer the results are views of (a chunk's four small tensors as four copies cost
+        four in-stream DMA packets of ~5 us each between the step's kernels; tools/runner_prof.py)."""
+        k = self.i
         if self.events[k] is not None:
-            self.events[k].synchronize()                  # the copies that last read this slot are done
-        out = {}
+            self.events[k].synchronize()                  # the copy that last read this slot is done
+        offs, total = {}, 0
         for name, t in named.items():
-            buf = slot.get(name)
-            if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
-                buf = torch.empty(max(t.numel(), 1), dtype=t.dtype).pin_memory()
-                slot[name] = buf
-            view = buf[:t.numel()].view(t.shape)
-            view.copy_(t)
-            out[name] = view.to(self.device, non_blocking=True)
+            offs[name] = total
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        buf = self.slots[k]
+        if buf is None or buf.numel() < total:
+            buf = torch.empty(max(total, 1) * 5 // 4, dtype=torch.uint8).pin_memory()
+            self.slots[k] = buf
+        for name, t in named.items():
+            n = t.numel() * t.element_size()
+            buf[offs[name]:offs[name] + n].view(t.dtype).view(t.shape).copy_(t)
+        dbuf = buf[:total].to(self.device, non_blocking=True)
+        out = {name: dbuf[offs[name]:offs[name] + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for name, t in named.items()}
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self.events[k] = ev

@@ -33,6 +33,37 @@ torch.nn.modules.module.register_module_parameter_registration_hook(_on_paramete
 torch.nn.modules.module.register_module_module_registration_hook(_on_parameter_registered)
 
 
+def _fused_adam_prehook(opt, args, kwargs):
+    """The reference trainer builds `torch.optim.Adam(model.parameters(), lr=...)` itself (src/bin/qpnet_train.py:426-429) and steps it once per chunk
+    (:531): with torch's default (foreach) implementation that is ~0.7 ms of host time per step for this model's 120 small tensors -- most of what the
+    unchanged loop spends (tools/dropin_prof.py).  Before the FIRST step of a stock Adam whose parameters are all views of a qpnet_amd flat buffer, this
+    global step pre-hook switches the group to torch's own fused implementation (`fused=True`: one multi-tensor launch sequence, the step counters on the
+    device) -- same update rule, same state_dict layout (reference-made checkpoints resume here and vice versa), nothing in the trainer changes.
+    Left alone: other optimizers, Adam subclasses, groups with foreach / fused / capturable / differentiable / amsgrad set by the caller, parameters of
+    other modules.  QPN_DROPIN_FUSED_ADAM=0 switches the hook off."""
+    if type(opt) is not torch.optim.Adam or opt.__dict__.get("_qpn_checked"):
+        return
+    opt.__dict__["_qpn_checked"] = True
+    if os.environ.get("QPN_DROPIN_FUSED_ADAM", "1") == "0":
+        return
+    for g in opt.param_groups:
+        ps = g["params"]
+        if not ps or g.get("fused") is not None or g.get("foreach") is not None or g.get("capturable") or g.get("differentiable") or g.get("amsgrad"):
+            continue
+        if not all(p.__dict__.get("_qpn_flat_view") and p.is_cuda and p.dtype == torch.float32 for p in ps):
+            continue
+        g["fused"] = True
+        for p in ps:                                  # a state loaded from a checkpoint keeps its step counters on the host: the fused kernel wants them next to the parameter
+            st = opt.state.get(p)
+            if st and "step" in st and torch.is_tensor(st["step"]) and st["step"].device != p.device:
+                st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
+
+
+torch.optim.Optimizer  # (torch.optim.optimizer is the module that owns the global hook registry)
+from torch.optim.optimizer import register_optimizer_step_pre_hook as _register_optimizer_step_pre_hook  # noqa: E402
+_register_optimizer_step_pre_hook(_fused_adam_prehook)
+
+
 def model_params(model):
     """list(model.parameters()), cached (see above)."""
     c = model.__dict__.get("_qpn_params")
@@ -52,19 +83,29 @@ def ensure_flat(model, dev):
     flat = getattr(model, "_flat", None)
     ok = flat is not None and flat.device == dev
     if ok:
+        # 120 data_ptr() calls cost ~60 us of interpreter time per step: the full walk runs when the parameter list was rebuilt and every 64th call,
+        # the first and the last view are looked at every time (.to() / .cuda() / load into new storage replace ALL of them)
+        c = model.__dict__.get("_qpn_flat_chk")
         base = flat.data_ptr()
-        o = 0
-        for p in params:
-            if p.data_ptr() != base + 4 * o or p.dtype != torch.float32:
-                ok = False
-                break
-            o += p.numel()
+        if c is not None and c[0] is params and c[1] < 64:
+            c[1] += 1
+            last = params[-1]
+            ok = params[0].data_ptr() == base and last.data_ptr() == base + 4 * (flat.numel() - last.numel())
+        else:
+            o = 0
+            for p in params:
+                if p.data_ptr() != base + 4 * o or p.dtype != torch.float32:
+                    ok = False
+                    break
+                o += p.numel()
+            model.__dict__["_qpn_flat_chk"] = [params, 0]
     if not ok:
         flat = torch.cat([p.detach().reshape(-1).to(dev, torch.float32) for p in params]).contiguous()
         o = 0
         for p in params:
             n = p.numel()
             p.data = flat[o:o + n].view(p.shape)
+            p.__dict__["_qpn_flat_view"] = True      # (what _fused_adam_prehook recognises this module's parameters by)
             o += n
         model._flat = flat
     return model._flat
@@ -414,6 +455,21 @@ class FusedTrainer:
         # (a step being captured into a hipGraph -- torch.cuda.graph -- may not wait for events or read anything back: no status bookkeeping, the
         #  caller checks with check_status() outside the graph; the library runs the stack as a launch per layer while a stream is capturing)
         capturing = torch.cuda.is_current_stream_capturing()
+        if not multi and not capturing:
+            # the whole step behind ONE foreign call (qpn_train_step: the same calls in the same order as below): while it runs, the interpreter is free
+            # for the loader thread -- the runner loop was bound by the two threads' interleaved Python, not by the device
+            self.step_count += 1
+            valid = C.c_int(0)
+            mode = 1 if want_loss == "lagged" else (2 if want_loss else 0)
+            with torch.cuda.device(dev):
+                rc = L.qpn_train_step(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd, x.data_ptr(), h.data_ptr(), d.data_ptr(),
+                                      t.data_ptr(), t.shape[1], self._logits.data_ptr(), self._dlogits.data_ptr(), self.g.data_ptr(),
+                                      self.m.data_ptr(), self.v.data_ptr(), flat.numel(), self.step_count, self.lr, self.betas[0], self.betas[1],
+                                      self.eps, self.wd, mode, C.byref(loss), C.byref(valid), stream)
+            if rc:
+                self.step_count -= 1                 # (nothing was applied: an argument error, or an earlier step's device-side status raised before this one started)
+                _lib.check(rc)
+            return loss.value if valid.value else None
         with torch.cuda.device(dev):
             if not capturing:
                 _lib.check(L.qpn_train_status_collect_lagged(hd))   # the check of the step before the previous one (never waits for queued work)
