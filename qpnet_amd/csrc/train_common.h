@@ -279,6 +279,22 @@ __device__ __forceinline__ float tr_dpp_row_sum(float a) {   // sum over the 16 
     a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, true));       // quad_perm [1,0,3,2]
     return a;
 }
+// max / sum over the 64 lanes of a wave, the result in every lane: four DPP steps inside the 16-lane rows, then the four row results through
+// v_readlane (scalar operands) -- ~12 VALU instructions and no trip through the LDS crossbar, against six dependent ds_bpermute of __shfl_xor
+__device__ __forceinline__ float tr_wave_max(float a) {
+    a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x128, 0xf, 0xf, true)));
+    a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x124, 0xf, 0xf, true)));
+    a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x4E, 0xf, 0xf, true)));
+    a = fmaxf(a, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0xB1, 0xf, 0xf, true)));
+    const int i = __float_as_int(a);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+__device__ __forceinline__ float tr_wave_sum(float a) {
+    const int i = __float_as_int(tr_dpp_row_sum(a));
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
 // backward of the frame-rate aux term for one wave's share of a 16-row tile.  The lane holds dZ of rows 4 (lane >> 4) + i, i = 0..3, gate
 // columns c (sigma) and C + c (tanh), c = 16 wave + (lane & 15); wj[i] = the WJ entries of those rows, pa = {PA[f0][c], PA[f0][C + c],
 // PA[f0 + 1][c], PA[f0 + 1][C + c]}.

@@ -649,10 +649,10 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
             if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
             float m = -INFINITY;
             for (int q = lane * 4; q < Q; q += 256) { const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */ m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
-            for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
+            m = tr_wave_max(m);
             float se = 0.f;
             for (int q = lane * 4; q < Q; q += 256) { const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */ se += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m)); }
-            for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+            se = tr_wave_sum(se);
             const float lse = logf(se) + m;
             if (p.ce_dlogits) for (int q = lane * 4; q < Q; q += 256) {
                 const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2); const float4 v = make_float4(v01.x, v01.y, v23.x, v23.y);   /* rows are 8-byte aligned in LDS (ld = 2 mod 32) */
@@ -674,6 +674,13 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     }
 }
 
+// dev aid (-DQPN_POST_STAMPS): s_memtime of thread 0 of workgroup `PS_WG` at the stage boundaries of the post-net forward kernels, into the stack queues' control
+// words [600 + 16 * slot + i] (read back with qpn_train_stack_stats; tools/post_stamps.py)
+#ifdef QPN_POST_STAMPS
+#define POST_STAMP(slot, i) do { if (p.qctl && ps_on && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.qctl[600 + 16 * (slot) + (i)] = (unsigned)t_; } } while (0)
+#else
+#define POST_STAMP(slot, i) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------------------ post-net, wide tiles (S = Q = 256)
 // k_post_fwd streams the post-net's 1 MB of weight fragments from L2 once per 16-row tile: 1250 tiles = 1.25 GB per launch, and a
 // 16-deep step's two fragment loads feed only 8 MFMAs (256 cycles) -- the launch runs at the L2's pace, 0.5 of the matrix-core rate.
@@ -739,6 +746,8 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
             if (t0 + r < p.BL) *(float2*)(dst + ((size_t)b * p.BL + t0 + r) * S + kk) = *(const float2*)(T + (size_t)r * lds + kk);
         }
     };
+    const bool ps_on = blockIdx.x == 5 && blockIdx.y == 0; (void)ps_on;
+    POST_STAMP(0, 0);
     f32x4 acc[MT][2];
 #define POSTW_ZERO() _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
     // ---------- skip sum: one K = L*C contraction, layer l's gates in Gb[l & 1]
@@ -752,22 +761,30 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
         post_gemm<MT>(acc, G, ldg, Ws + (size_t)l * (C / 16) * NTS * 64, NTS, nt0, C / 16, lane, bq,
                       l + 1 < L ? Ws + ((size_t)(l + 1) * (C / 16) * NTS + nt0) * 64 + lane : P1 + (size_t)nt0 * 64 + lane);
     }
+    POST_STAMP(0, 1);
     put(acc, bs0, bs1, true);
     TR_LDS_BARRIER();
-    rows_out(p.S0);                                               // relu(s0): sign = the backward's mask, value = the weight gradient's operand
+    POST_STAMP(0, 2);
+    rows_out(p.S0);
+    POST_STAMP(0, 3);                                               // relu(s0): sign = the backward's mask, value = the weight gradient's operand
     // ---------- post 1x1 #1
     POSTW_ZERO();
     post_gemm<MT>(acc, T, lds, P1, NTS, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
+    POST_STAMP(0, 4);
     TR_LDS_BARRIER();                                              // every wave (and rows_out) is done reading T
     put(acc, bp10, bp11, true);
     TR_LDS_BARRIER();
+    POST_STAMP(0, 5);
     rows_out(p.Y0);
+    POST_STAMP(0, 6);
     // ---------- post 1x1 #2
     POSTW_ZERO();
     post_gemm<MT>(acc, T, lds, P2, Q / 16, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
+    POST_STAMP(0, 7);
     TR_LDS_BARRIER();
     put(acc, bp20, bp21, false);
     TR_LDS_BARRIER();
+    POST_STAMP(0, 8);
 #undef POSTW_ZERO
     if (p.logits)
         for (int idx = tid; idx < TM * (Q / 2); idx += 512) {
@@ -788,10 +805,10 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
             if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
             const int q = lane * 4;
             const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2);
-            float m = fmaxf(fmaxf(v01.x, v01.y), fmaxf(v23.x, v23.y));
-            for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft));
-            float se = (__expf(v01.x - m) + __expf(v01.y - m)) + (__expf(v23.x - m) + __expf(v23.y - m));
-            for (int sft = 32; sft >= 1; sft >>= 1) se += __shfl_xor(se, sft);
+            // (the wave reductions are k_ce's: DPP inside the 16-lane rows + v_readlane across them, same order, bit-identical dL/dlogits; as six
+            //  dependent ds_bpermute each they made the cross entropy 25 k of the tile's 232 k cycles: profiles/r05_post_fwd_stamps.txt)
+            const float m = tr_wave_max(fmaxf(fmaxf(v01.x, v01.y), fmaxf(v23.x, v23.y)));
+            const float se = tr_wave_sum((__expf(v01.x - m) + __expf(v01.y - m)) + (__expf(v23.x - m) + __expf(v23.y - m)));
             const float lse = logf(se) + m;
             if (p.ce_dlogits) {
                 float4 gq = make_float4(__expf(v01.x - lse), __expf(v01.y - lse), __expf(v23.x - lse), __expf(v23.y - lse));
@@ -810,6 +827,7 @@ __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
             atomicAdd(p.ce_loss + (blockIdx.x & 63), sacc / (double)rows);
         }
     }
+    POST_STAMP(0, 9);
 }
 
 // mean cross entropy + its gradient, one wave per row, rpw rows per wave (reference qpnet_train.py:430,526-528)
@@ -830,11 +848,11 @@ __global__ __launch_bounds__(256) void k_ce(const float* __restrict__ logits, co
         const bool vec = (Q & 255) == 0;             // 4 contiguous logits per lane per pass (16-byte accesses)
         if (vec) for (int q = lane * 4; q < Q; q += 256) { const float4 v = *(const float4*)(lg + q); m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w)); }
         else for (int q = lane; q < Q; q += 64) m = fmaxf(m, lg[q]);
-        for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+        m = tr_wave_max(m);
         float se = 0.f;
         if (vec) for (int q = lane * 4; q < Q; q += 256) { const float4 v = *(const float4*)(lg + q); se += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m)); }
         else for (int q = lane; q < Q; q += 64) se += expf(lg[q] - m);
-        for (int s = 32; s >= 1; s >>= 1) se += __shfl_xor(se, s);
+        se = tr_wave_sum(se);
         const float lse = logf(se) + m;
         if (dlogits) {
             if (vec) for (int q = lane * 4; q < Q; q += 256) {

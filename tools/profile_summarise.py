@@ -8,6 +8,12 @@ dst = "gpurun_out/profiles_%s" % tag
 os.makedirs(dst, exist_ok=True)
 
 
+def norm(name):
+    """'void k_stack_bwd<8>(TrainParams, TrainBwd, StackQ)' -> 'k_stack_bwd<8>': the name bench.py's roofline.kernels carry"""
+    name = name.split("(")[0].strip()
+    return (name[5:] if name.startswith("void ") else name)[:80]
+
+
 def find(pattern):
     f = glob.glob(os.path.join(src, pattern), recursive=True)
     return f[0] if f else None
@@ -33,7 +39,7 @@ for what in ("train", "decode"):
             continue
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
-            name = name.split("(")[0][:80]
+            name = norm(name)
             agg[name][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "FETCH_SIZE":
                 calls[name] += 1
@@ -45,12 +51,12 @@ fs = find("train_stats/**/*kernel_stats.csv")
 if f and fs:
     avg_ns = {}
     for r in csv.DictReader(open(fs)):
-        avg_ns[r["Name"].split("(")[0][:80]] = float(r["AverageNs"])
+        avg_ns[norm(r["Name"])] = float(r["AverageNs"])
     busy = defaultdict(float); n = defaultdict(int)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != "SQ_VALU_MFMA_BUSY_CYCLES":
             continue
-        name = (r.get("Kernel_Name") or "").split("(")[0][:80]
+        name = norm(r.get("Kernel_Name") or "")
         busy[name] += float(r["Counter_Value"]); n[name] += 1
     for name in busy:
         if name in avg_ns and name in per.get("train", {}):
@@ -58,12 +64,13 @@ if f and fs:
             per["train"][name]["mfma_busy_cycles_per_call"] = per_call
             per["train"][name]["avg_us"] = avg_ns[name] / 1e3
             per["train"][name]["mfma_util"] = per_call / (avg_ns[name] * 2.4 * 1024)
+            per["train"][name]["mfma_busy"] = round(per["train"][name]["mfma_util"], 3)        # (what bench.py's roofline.kernels[].mfma_busy reads)
 # where the waves' cycles go (SQ wait / active counters), per kernel
 f = find("train_WAIT/**/*counter_collection.csv")
 if f:
     agg = defaultdict(lambda: defaultdict(float))
     for r in csv.DictReader(open(f)):
-        agg[(r.get("Kernel_Name") or "").split("(")[0][:80]][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[norm(r.get("Kernel_Name") or "")][r["Counter_Name"]] += float(r["Counter_Value"])
     with open(os.path.join(dst, "%s_train_wait_pmc.txt" % tag), "w") as o:
         o.write("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU\n")
         o.write("  -- python3 bench.py --mode train --steps 2 --warmup 1 --no-cpu   (QPN_TRAIN_SERIAL=1); fractions of SQ_WAVE_CYCLES summed over a kernel's dispatches\n")
@@ -86,7 +93,7 @@ if wg:
     steps = 3.0    # 1 warmup + 2 timed steps in the PMC runs (the profiled extra steps of bench.py are included: see calls)
     calls = max(v["calls"] for _, v in wg)
     nsteps = max(per["train"].get("k_train_prep", {}).get("calls", 0), 1)          # steps of the profiled command (timed + warm-up + bench.py's per-group steps)
-    GROUP = (("k_train_prep", "prep+pack"), ("k_refresh", "prep+pack"), ("k_stack_fwd", "k_layer_fwd"), ("k_layer_fwd", "k_layer_fwd"), ("k_post_fwd", "k_post_fwd"),
+    GROUP = (("k_train_prep", "prep+pack"), ("k_refresh", "prep+pack"), ("k_aux_tail", "grad_tail"), ("k_stack_fwd", "k_layer_fwd"), ("k_layer_fwd", "k_layer_fwd"), ("k_post_fwd", "k_post_fwd"),
              ("k_ce", "k_ce"), ("k_post_bwd", "k_post_bwd"), ("k_wgrad", "k_wgrad"), ("k_stack_bwd", "k_layer_bwd"), ("k_layer_bwd", "k_layer_bwd"),
              ("k_reduce_grad", "grad_tail"), ("k_up_bwd", "grad_tail"), ("k_causal_bwd", "grad_tail"), ("k_zero_dx", "k_post_bwd"), ("k_adam", "k_adam"))
     by_group = defaultdict(float)
@@ -99,7 +106,8 @@ if wg:
                         "steps_profiled": nsteps,
                         "hbm_bytes_per_step": by_group.get("k_wgrad", 0.0),
                         "hbm_bytes_by_group": {k: round(v) for k, v in by_group.items()},
-                        "hbm_bytes_per_step_all_kernels": round(sum(v["hbm_bytes"] for k, v in per["train"].items() if k.startswith(("k_", "void k_"))) / nsteps)}
+                        "hbm_bytes_by_kernel": {k: round(v["hbm_bytes"] / max(v["calls"], 1)) for k, v in per["train"].items() if k.startswith("k_")},      # per LAUNCH
+                        "hbm_bytes_per_step_all_kernels": round(sum(v["hbm_bytes"] for k, v in per["train"].items() if k.startswith("k_")) / nsteps)}
 traffic["commit"] = os.environ.get("QPN_COMMIT", "?")
 json.dump(traffic, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
