@@ -20,6 +20,12 @@ BUDGET = {
                                                                   # the K role needs all 256 registers); non-inlined roles cost 2.6 KB of scratch instead
     "k_decode_coop": ("decode_coop.hip", 0, 3),             # 768 threads: three waves per SIMD, nothing in scratch memory
     "k_layer_fwd_pILi11ELb0E": ("train_fwd.hip", 0, 2),     # persistent layer forward: two workgroups per CU, weights in registers
+    "k_layer_fwd_pILi8ELb0E": ("train_fwd.hip", 0, 2),      # ... the K = 128 form (aux 1x1 at frame rate)
+    "k_layer_bwd_pILi8ELb0E": ("train_bwd.hip", 0, 2),
+    "k_stack_fwdILi8EE": ("train_stack.hip", 0, 2),         # the one-launch residual stack (work queue), K = 128: two workgroups per CU, nothing in scratch
+    "k_stack_bwdILi8EE": ("train_stack.hip", 0, 2),
+    "k_stack_fwdILi11EE": ("train_stack.hip", 0, 2),        # ... and the K = 176 form (upsampling_factor 0 / < 16, QPN_AUX_HOIST=0)
+    "k_stack_bwdILi11EE": ("train_stack.hip", 0, 2),
     "k_post_fwd_wILi5E": ("train_fwd.hip", 0, 2),           # 80-row post-net tiles: one 512-thread workgroup per CU
     "k_post_bwd_wILi5E": ("train_bwd.hip", 0, 2),
     "k_layer_fwdILi1E": ("train_fwd.hip", 0, 5),          # five 16-row workgroups per CU must be co-resident
@@ -28,6 +34,8 @@ BUDGET = {
     "k_wgrad3ILi1ELi4ELi4ELb0ELi2EE": ("train_bwd.hip", 0, 2),      # post-net weight gradients (both in one launch: 512 workgroups, two per CU)
     "k_wgrad3ILi2ELi4ELi4ELb0ELi2EE": ("train_bwd.hip", 0, 2),      # skip 1x1
     "k_wgrad3ILi3ELi2ELi11ELb0ELi1EE": ("train_bwd.hip", 0, 2),     # dW1: 159 VGPRs + 88 accumulators, two workgroups per CU
+    "k_wgrad3ILi3ELi2ELi8ELb0ELi1EE": ("train_bwd.hip", 0, 2),      # dW1 at K = 128 (aux 1x1 at frame rate)
+    "k_aux_tail": ("train_bwd.hip", 0, 2),                             # 64 accumulator rows in registers at once, nothing in scratch
     "k_wgrad3ILi2ELi1ELi4ELb1ELi1EE": ("train_bwd.hip", 0, 4),      # residual 1x1 (memory-bound: occupancy is what it lives on)
     "k_up_bwd": ("train_bwd.hip", 0, 2),                               # a row's 16 float4 words in registers at once, still nothing in scratch
     "k_gemm_nnILi0ELi1E": ("train_gemm.hip", 0, 3),
