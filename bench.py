@@ -211,6 +211,8 @@ def run_decode(args, rank, local, world):
         "roofline": {"bound": bound, "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance",
                      "frac": floor / us if us > 0 else 0.0,
                      "hbm_algorithmic": 172, "hbm_bytes_per_sample": hbm_meas,
+                     # measured HBM bytes per generated sample / the 172 algorithmic ones: the write-through granules and polling loads of the hand-offs
+                     "traffic_ratio": (hbm_meas / 172.0) if hbm_meas else None,
                      "hbm_achieved_GBps": 172.0 * sum(ns) / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                      "traffic": hbm_meas * sum(ns) if hbm_meas else None,
                      "traffic_source": "%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per sample x samples of this launch)" % tr.get("_file"),
