@@ -164,7 +164,9 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                 if (q == 0 && !half) gr_store(X + c.o_g + (size_t)l * C + ch, tag, qgate(z, zo));
             }
             const bool has_res = l + 1 < L;               // the last block's residual output is unused (qpnet.py:505)
-            const int nres = has_res ? CB / rpt : 0, nsk = SB / rpt;
+            // (a slice smaller than a 4 KiB tile -- G = 128 / 256 at C = 512: one or two skip / post-net rows per workgroup -- takes the tile that holds its rows
+            //  and keeps the lane groups of those rows)
+            const int nres = has_res ? CB / rpt : 0, nsk = (SB + rpt - 1) / rpt;
             if (wave < nres + nsk)
                 load_tile(wrN, p.wpk, wave < nres ? f.w_res[l] + (c0 / rpt + wave) * 256 : f.w_skip[l] + (s0 / rpt + (wave - nres)) * 256, lane);
             gather_vec(X + c.o_g + (size_t)l * C, C, tag, sm + o_g, tid, c.abort, p.status);
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
                         }
                     } else {
                         const int row = (s0 / rpt + (i - nres)) * rpt + grp;
-                        if (q == 0) {
+                        if (q == 0 && row >= s0 && row < s0 + SB) {
                             const int a = o_acc + (f.adaptive[l] ? SB : 0) + (row - s0);
                             sm[a] = sm[a] + (acc + sm[o_bsk + l * SB + (row - s0)]);
                         }
@@ -207,7 +209,8 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             const float tot = sm[o_acc + r] + sm[o_acc + SB + r];     // sum(skip_F) + sum(skip_A)  (qpnet.py:505)
             gr_store(X + c.o_y1 + s0 + r, tag, tot > 0.0f ? tot : 0.0f);
         }
-        if (wave < SB / rpts) load_tile(wrN, p.wpk, f.w_p1 + (s0 / rpts + wave) * 256, lane);
+        const int np1 = (SB + rpts - 1) / rpts, np2 = (QB + rpts - 1) / rpts;
+        if (wave < np1) load_tile(wrN, p.wpk, f.w_p1 + (s0 / rpts + wave) * 256, lane);
         gather_vec(X + c.o_y1, S, tag, sm + o_y1, tid, c.abort, p.status);
         __syncthreads();
         {
@@ -215,15 +218,15 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             const float4* yv = (const float4*)(sm + o_y1 + 16 * qs);
 #pragma unroll
             for (int k = 0; k < 4; ++k) xq[k] = yv[k];
-            for (int i = wave; i < SB / rpts; i += COOP_NW) {
+            for (int i = wave; i < np1; i += COOP_NW) {
                 const int ti = s0 / rpts + i;
                 if (i != wave) load_tile(wrN, p.wpk, f.w_p1 + ti * 256, lane);
                 const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
-                if (qs == 0) { const float v = acc + sm[o_bp1 + (row - s0)]; gr_store(X + c.o_y2 + row, tag, v > 0.0f ? v : 0.0f); }
+                if (qs == 0 && row >= s0 && row < s0 + SB) { const float v = acc + sm[o_bp1 + (row - s0)]; gr_store(X + c.o_y2 + row, tag, v > 0.0f ? v : 0.0f); }
             }
         }
-        if (wave < QB / rpts) load_tile(wrN, p.wpk, f.w_p2 + (q0 / rpts + wave) * 256, lane);
+        if (wave < np2) load_tile(wrN, p.wpk, f.w_p2 + (q0 / rpts + wave) * 256, lane);
         gather_vec(X + c.o_y2, S, tag, sm + o_y2, tid, c.abort, p.status);
         __syncthreads();
         {
@@ -231,12 +234,12 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
             const float4* yv = (const float4*)(sm + o_y2 + 16 * qs);
 #pragma unroll
             for (int k = 0; k < 4; ++k) xq[k] = yv[k];
-            for (int i = wave; i < QB / rpts; i += COOP_NW) {
+            for (int i = wave; i < np2; i += COOP_NW) {
                 const int ti = q0 / rpts + i;
                 if (i != wave) load_tile(wrN, p.wpk, f.w_p2 + ti * 256, lane);
                 const float acc = tree_reduce(chunk16(wrN, xq), logRs);
                 const int row = ti * rpts + grps;
-                if (qs == 0) gr_store(X + c.o_lg + row, tag, acc + sm[o_bp2 + (row - q0)]);
+                if (qs == 0 && row >= q0 && row < q0 + QB) gr_store(X + c.o_lg + row, tag, acc + sm[o_bp2 + (row - q0)]);
             }
         }
         gather_vec(X + c.o_lg, Q, tag, sm + o_lg, tid, c.abort, p.status);
@@ -268,14 +271,16 @@ __global__ __launch_bounds__(COOP_NT) void k_decode_coop(DecodeParams p, FastPar
 // ------------------------------------------------------------------------------------------ host side
 static int ilog2c(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// largest power-of-two group size G <= limit whose row slices are whole tiles
+// largest power-of-two group size G <= limit: the gate and residual row slices are whole 4 KiB tiles; a skip / post-net slice may be a fraction of ONE tile
+// (round 5: G = 128 / 256 for the C = 512 geometry -- the workgroup takes the tile that holds its one or two rows and keeps their lane groups)
 int qpn_coop_group_size(const Geom& g, int limit) {
     const int rpt = 64 / (g.Cp / 16), rpts = 64 / (g.Sp / 16);
+    auto slice_ok = [](int rows, int per_tile) { return rows % per_tile == 0 || (rows < per_tile && per_tile % rows == 0); };
     int best = 1;
     for (int G = 1; G <= limit; G *= 2) {
         if (g.C % G || g.S % G || g.Q % G) break;
         const int CB = g.C / G, SB = g.S / G, QB = g.Q / G;
-        if ((2 * CB) % rpt || CB % rpt || SB % rpt || SB % rpts || QB % rpts) break;
+        if ((2 * CB) % rpt || CB % rpt || !slice_ok(SB, rpt) || !slice_ok(SB, rpts) || !slice_ok(QB, rpts)) break;
         best = G;
     }
     return best;
