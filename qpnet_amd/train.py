@@ -9,6 +9,7 @@ the same model before the first one's backward would replace them.  Every forwar
 number from the library; a backward whose forward is no longer the current one raises instead of
 using the wrong activations."""
 import os
+import weakref
 import ctypes as C
 
 import numpy as np
@@ -33,19 +34,173 @@ torch.nn.modules.module.register_module_parameter_registration_hook(_on_paramete
 torch.nn.modules.module.register_module_module_registration_hook(_on_parameter_registered)
 
 
-def _fused_adam_prehook(opt, args, kwargs):
+class _AdoptedAdam:
+    """What the step hooks keep per stock `torch.optim.Adam` they step themselves (see _adam_prehook)."""
+    __slots__ = ("model", "n", "m", "v", "steps", "step_t", "stash", "mviews", "vviews")
+
+
+_EMPTY = []
+_FLAT_OWNERS = weakref.WeakValueDictionary()
+
+
+def _adam_group_is_plain(g):
+    return not (g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or g.get("foreach")) \
+        and isinstance(g["lr"], float) and g.get("decoupled_weight_decay") in (None, False)
+
+
+def _adam_adopt(opt):
+    """-> _AdoptedAdam when `opt` is a stock Adam with ONE group holding exactly one qpnet_amd module's parameters in order (what
+    `torch.optim.Adam(model.parameters(), ...)` builds, reference src/bin/qpnet_train.py:426-429), else None.  The optimizer's state becomes VIEWS of two
+    flat moment buffers (a state loaded from a checkpoint is copied into them first), so state_dict() / load_state_dict() keep torch's layout and a
+    reference-made checkpoint resumes here and vice versa."""
+    if len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    ps = g["params"]
+    if not ps or not _adam_group_is_plain(g):
+        return None
+    model = _FLAT_OWNERS.get(id(ps[0])) if ps[0].__dict__.get("_qpn_flat_view") else None
+    if model is None:
+        return None
+    params = model_params(model)
+    flat = getattr(model, "_flat", None)
+    if flat is None or not flat.is_cuda or len(params) != len(ps) or any(a is not b for a, b in zip(params, ps)):
+        return None
+    a = _AdoptedAdam()
+    a.model, a.n, a.stash = weakref.ref(model), len(ps), None
+    a.m, a.v = torch.zeros_like(flat), torch.zeros_like(flat)
+    a.mviews, a.vviews = _split_like(model, a.m), _split_like(model, a.v)
+    steps = None
+    for p, mv, vv in zip(ps, a.mviews, a.vviews):
+        st = opt.state.get(p)
+        if not st:
+            k = 0
+        else:
+            if set(st) != {"step", "exp_avg", "exp_avg_sq"}:
+                return None
+            k = int(float(st["step"]))                    # (a read-back per parameter: once per adoption, i.e. once per optimizer or load_state_dict)
+            mv.copy_(st["exp_avg"]); vv.copy_(st["exp_avg_sq"])
+        if steps is not None and k != steps:
+            return None                                   # parameters stepped a different number of times (some had no gradient): torch's own loop keeps them
+        steps = k
+    a.steps = steps
+    a.step_t = torch.tensor(float(steps), dtype=torch.float32)
+    if steps > 0:
+        _adam_bind_state(opt, a, ps)
+    if not opt.__dict__.get("_qpn_sd_hook"):
+        opt.__dict__["_qpn_sd_hook"] = True
+        opt.register_state_dict_post_hook(_adam_state_dict_posthook)
+    return a
+
+
+def _adam_state_dict_posthook(opt, sd):
+    """state_dict() of an adopted optimizer: every parameter gets a step counter of its OWN (inside the optimizer they all are one host scalar, bumped once
+    per step; whoever loads the checkpoint -- torch's own Adam in the reference trainer -- increments them one by one, in place)."""
+    a = opt.__dict__.get("_qpn_adopt")
+    if a and a.steps > 0:
+        sd["state"] = {k: (dict(st, step=torch.tensor(float(a.steps), dtype=torch.float32)) if st.get("step") is a.step_t else st) for k, st in sd["state"].items()}
+    return sd
+
+
+def _adam_bind_state(opt, a, ps):
+    for p, mv, vv in zip(ps, a.mviews, a.vviews):
+        opt.state[p] = {"step": a.step_t, "exp_avg": mv, "exp_avg_sq": vv}
+
+
+def _adam_release(opt, a, ps):
+    """hand the state back to torch's own implementation (fused=True wants a step counter per parameter, on the device)."""
+    if a.steps > 0:
+        for p in ps:
+            opt.state[p]["step"] = torch.tensor(float(a.steps), dtype=torch.float32, device=p.device)
+    opt.__dict__["_qpn_adopt"] = None                     # looked at again at the next step
+
+
+def _adam_prehook(opt, args, kwargs):
     """The reference trainer builds `torch.optim.Adam(model.parameters(), lr=...)` itself (src/bin/qpnet_train.py:426-429) and steps it once per chunk
-    (:531): with torch's default (foreach) implementation that is ~0.7 ms of host time per step for this model's 120 small tensors -- most of what the
-    unchanged loop spends (tools/dropin_prof.py).  Before the FIRST step of a stock Adam whose parameters are all views of a qpnet_amd flat buffer, this
-    global step pre-hook switches the group to torch's own fused implementation (`fused=True`: one multi-tensor launch sequence, the step counters on the
-    device) -- same update rule, same state_dict layout (reference-made checkpoints resume here and vice versa), nothing in the trainer changes.
-    Left alone: other optimizers, Adam subclasses, groups with foreach / fused / capturable / differentiable / amsgrad set by the caller, parameters of
-    other modules.  QPN_DROPIN_FUSED_ADAM=0 switches the hook off."""
-    if type(opt) is not torch.optim.Adam or opt.__dict__.get("_qpn_checked"):
+    (:531).  With torch's default (foreach) implementation that is ~0.7 ms of host time per step for this model's 120 small tensors, with `fused=True`
+    still ~0.25 ms (the per-parameter state walk in Python) -- most of what the unchanged loop spends (tools/dropin_prof.py).  This global step pre-hook
+    makes the caller's stock Adam step through the library's ONE Adam kernel over the flat parameter buffer (qpn_adam_step: same update rule, tested
+    against torch's, tests/test_train_gpu.py) when that is exactly equivalent:
+      * type(opt) is torch.optim.Adam, one group, its parameters = one qpnet_amd module's parameters in order, no amsgrad / maximize / capturable /
+        differentiable / foreach / tensor lr, no closure;
+      * every p.grad is the view the module's backward handed out (_anchored_backward) -- clipped or rescaled in place is fine; a gradient that was
+        replaced is gathered; a missing one (torch skips that parameter) leaves the step to torch.
+    The optimizer's state is kept as views of two flat moment buffers (_adam_adopt), the group's hyper-parameters are read every step (lr schedulers
+    work unchanged), and while torch's own `step` body runs the group's parameter list is empty, so it does nothing (restored by the post-hook).
+    Everything else -- other optimizers, subclasses, several groups -- falls back to `fused=True` on eligible groups or is left alone.
+    QPN_DROPIN_FUSED_ADAM=0 switches the hooks off, =torch keeps only the `fused=True` switch."""
+    if type(opt) is not torch.optim.Adam:
         return
-    opt.__dict__["_qpn_checked"] = True
-    if os.environ.get("QPN_DROPIN_FUSED_ADAM", "1") == "0":
+    d = opt.__dict__
+    a = d.get("_qpn_adopt")
+    if a is False:
         return
+    has_closure = (args[1] if len(args) > 1 else kwargs.get("closure")) is not None       # (args = (optimizer, *step's positional arguments))
+    g0 = opt.param_groups[0] if opt.param_groups else None
+    if a is not None and a.stash is not None:            # a step that raised between the hooks
+        g0["params"] = a.stash; a.stash = None
+    if a is None:
+        mode = os.environ.get("QPN_DROPIN_FUSED_ADAM", "1")
+        if mode == "0":
+            d["_qpn_adopt"] = False
+            return
+        if not d.get("_qpn_checked"):
+            d["_qpn_checked"] = True
+            _adam_switch_to_fused(opt)
+        if mode == "torch" or has_closure:
+            return
+        a = _adam_adopt(opt)
+        if a is None:
+            d["_qpn_adopt"] = False
+            return
+        d["_qpn_adopt"] = a
+    ps = g0["params"]
+    model = a.model()
+    if has_closure or len(opt.param_groups) != 1 or model is None or len(ps) != a.n or not _adam_group_is_plain(g0):
+        return _adam_release(opt, a, ps)
+    flat = getattr(model, "_flat", None)
+    if flat is None or flat.numel() != a.m.numel() or flat.device != a.m.device or ps[0].data_ptr() != flat.data_ptr():
+        return _adam_release(opt, a, ps)
+    c = model.__dict__.get("_qpn_gflat")
+    gbuf = None
+    if c is not None:
+        for p, v in zip(ps, c[2]):
+            if p.grad is not v:
+                break
+        else:
+            gbuf = c[1]
+    if gbuf is None:
+        if any(p.grad is None for p in ps):
+            return _adam_release(opt, a, ps)
+        gbuf = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in ps])
+    if a.steps > 0:
+        st = opt.state.get(ps[0]); st1 = opt.state.get(ps[-1])
+        if not st or not st1 or st.get("exp_avg") is not a.mviews[0] or st1.get("exp_avg_sq") is not a.vviews[-1] or st["step"] is not a.step_t:
+            return _adam_release(opt, a, ps)              # load_state_dict() replaced the state: adopted again at the next step
+    dev = flat.device
+    L, hd = model._native(dev)
+    b1, b2 = g0["betas"]
+    with torch.cuda.device(dev):
+        _lib.check(L.qpn_train_status_collect(hd))       # a pending forward check (no-op after a backward has collected it)
+        _lib.check(L.qpn_adam_step(hd, flat.data_ptr(), gbuf.data_ptr(), a.m.data_ptr(), a.v.data_ptr(), flat.numel(), a.steps + 1,
+                                   g0["lr"], b1, b2, g0["eps"], g0["weight_decay"], torch.cuda.current_stream(dev).cuda_stream))
+    a.steps += 1
+    a.step_t += 1
+    if a.steps == 1:
+        _adam_bind_state(opt, a, ps)
+    a.stash = ps
+    g0["params"] = _EMPTY
+
+
+def _adam_posthook(opt, args, kwargs):
+    a = opt.__dict__.get("_qpn_adopt")
+    if a and a.stash is not None:
+        opt.param_groups[0]["params"] = a.stash
+        a.stash = None
+
+
+def _adam_switch_to_fused(opt):
+    """eligible groups of a stock Adam -> torch's own fused implementation (what runs whenever _adam_prehook leaves a step to torch)."""
     for g in opt.param_groups:
         ps = g["params"]
         if not ps or g.get("fused") is not None or g.get("foreach") is not None or g.get("capturable") or g.get("differentiable") or g.get("amsgrad"):
@@ -59,9 +214,10 @@ def _fused_adam_prehook(opt, args, kwargs):
                 st["step"] = st["step"].to(device=p.device, dtype=torch.float32)
 
 
-torch.optim.Optimizer  # (torch.optim.optimizer is the module that owns the global hook registry)
 from torch.optim.optimizer import register_optimizer_step_pre_hook as _register_optimizer_step_pre_hook  # noqa: E402
-_register_optimizer_step_pre_hook(_fused_adam_prehook)
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_optimizer_step_post_hook  # noqa: E402
+_register_optimizer_step_pre_hook(_adam_prehook)
+_register_optimizer_step_post_hook(_adam_posthook)
 
 
 def model_params(model):
@@ -102,10 +258,11 @@ def ensure_flat(model, dev):
     if not ok:
         flat = torch.cat([p.detach().reshape(-1).to(dev, torch.float32) for p in params]).contiguous()
         o = 0
+        _FLAT_OWNERS[id(params[0])] = model             # (looked up by _adam_adopt, which checks every parameter's identity against this module's)
         for p in params:
             n = p.numel()
             p.data = flat[o:o + n].view(p.shape)
-            p.__dict__["_qpn_flat_view"] = True      # (what _fused_adam_prehook recognises this module's parameters by)
+            p.__dict__["_qpn_flat_view"] = True      # (what _adam_prehook recognises this module's parameters by; a plain bool: parameters get pickled)
             o += n
         model._flat = flat
     return model._flat

@@ -311,14 +311,15 @@ def test_other_geometry_train_vs_oracle(geo, cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=0.0)
 
 
-def test_flat_adam_matches_torch_adam(cuda):
-    """FlatAdam (one kernel over the flat parameter buffer) == torch.optim.Adam on the same loop, three steps."""
+def test_flat_adam_matches_torch_adam(cuda, monkeypatch):
+    """FlatAdam (one kernel over the flat parameter buffer) == torch.optim.Adam's OWN update (the step hooks off) on the same loop, three steps."""
     import torch
     from qpnet_amd.config import TINY
     from qpnet_amd.train import FlatAdam
     cfg = TINY
     flat = synth.make_weights(cfg, 11)
     ws = []
+    monkeypatch.setenv("QPN_DROPIN_FUSED_ADAM", "0")
     for kind in ("torch", "flat"):
         m = util.build_model(cfg, flat, cuda).train()
         opt = torch.optim.Adam(m.parameters(), lr=1e-3) if kind == "torch" else FlatAdam(m, lr=1e-3)
@@ -332,6 +333,120 @@ def test_flat_adam_matches_torch_adam(cuda):
             opt.step()
         ws.append(torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy())
     np.testing.assert_allclose(ws[0], ws[1], atol=2e-6, rtol=0)
+
+
+def _ref_loop_step(m, opt, cfg, cuda, seed, bl=700, clip=None):
+    import torch
+    x, h, t, d, b = synth.train_inputs(cfg, bl, seed, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    out = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(out.reshape(-1, cfg.n_quantize), tt[:, -out.shape[1]:].reshape(-1))
+    opt.zero_grad()
+    loss.backward()
+    if clip is not None:
+        torch.nn.utils.clip_grad_norm_(m.parameters(), clip)
+    opt.step()
+    return float(loss.item())
+
+
+def test_stock_adam_stepped_by_the_library_equals_torchs_own(cuda, monkeypatch):
+    """The reference loop's `torch.optim.Adam(model.parameters())` (src/bin/qpnet_train.py:426-429) is stepped by the library's Adam kernel through
+    the optimizer step hooks (train._adam_prehook).  Against torch's own implementation (hooks off) on the same chunks: weights, moments and step
+    counters agree to fp32 rounding, with an lr scheduler, weight decay and in-place gradient clipping in the loop; state_dict() keeps torch's
+    layout in both directions (torch -> adopted mid-run, adopted -> torch); a parameter without a gradient hands that step back to torch."""
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    flat = synth.make_weights(cfg, 12)
+
+    def run(mode, nsteps, resume=None, drop_grad_at=None):
+        monkeypatch.setenv("QPN_DROPIN_FUSED_ADAM", mode)
+        m = util.build_model(cfg, flat, cuda).train()
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=1e-3)
+        first = 0
+        if resume is not None:
+            m.load_state_dict(resume["model"]); opt.load_state_dict(resume["opt"]); first = resume["step"]
+        n_params = len(opt.param_groups[0]["params"])
+        for step in range(first, nsteps):
+            opt.param_groups[0]["lr"] = 1e-3 * 0.5 ** (step // 2)          # (what a StepLR(step_size=2, gamma=0.5) writes into the group)
+            if step == drop_grad_at:
+                # torch skips a parameter whose gradient is None (no moment decay, no step count): that step is torch's, the next ones the library's again
+                x, h, t, d, b = synth.train_inputs(cfg, 700, 80 + step, 30000)
+                xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+                out = m(xt, ht, dt, bt)
+                loss = torch.nn.CrossEntropyLoss()(out.reshape(-1, cfg.n_quantize), tt[:, -out.shape[1]:].reshape(-1))
+                opt.zero_grad(); loss.backward()
+                m.causal.conv.bias.grad = None
+                opt.step()
+            else:
+                _ref_loop_step(m, opt, cfg, cuda, 80 + step, clip=5.0)
+            assert len(opt.param_groups[0]["params"]) == n_params          # (emptied only while torch's step body runs)
+        return m, opt
+
+    m0, o0 = run("0", 5)
+    m1, o1 = run("1", 5)
+    assert o1.__dict__["_qpn_adopt"] and not o0.__dict__.get("_qpn_adopt")
+    w0 = torch.cat([p.detach().reshape(-1) for p in m0.parameters()]).cpu().numpy()
+    w1 = torch.cat([p.detach().reshape(-1) for p in m1.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(w1, w0, atol=2e-6, rtol=0)
+    assert np.abs(w0 - flat).max() > 1e-3
+    s0, s1 = o0.state_dict(), o1.state_dict()
+    assert s0["param_groups"][0]["params"] == s1["param_groups"][0]["params"] and set(s0["state"]) == set(s1["state"])
+    assert abs(s1["param_groups"][0]["lr"] - s0["param_groups"][0]["lr"]) < 1e-12 and s1["param_groups"][0]["lr"] < 1e-3     # the scheduler's lr is what stepped
+    for i in s0["state"]:
+        assert float(s1["state"][i]["step"]) == float(s0["state"][i]["step"]) == 5.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b = s0["state"][i][k].cpu().numpy(), s1["state"][i][k].cpu().numpy()
+            assert a.shape == b.shape
+            # (two runs of the same backward differ by float-atomics order, ~1e-6 of the largest gradient; the second moment squares it)
+            np.testing.assert_allclose(b, a, rtol=0, atol=(1e-5 if k == "exp_avg" else 4e-5) * max(float(np.abs(a).max()), 1e-30))
+    # resume across the two implementations, both ways, at step 3 of 5
+    ma, oa = run("0", 3)
+    ckpt = {"model": {k: v.clone() for k, v in ma.state_dict().items()}, "opt": oa.state_dict(), "step": 3}
+    m2, o2 = run("1", 5, resume=ckpt)                    # torch-made state, continued by the library
+    assert o2.__dict__["_qpn_adopt"]
+    mb, ob = run("1", 3)
+    ckpt = {"model": {k: v.clone() for k, v in mb.state_dict().items()}, "opt": ob.state_dict(), "step": 3}
+    m3, o3 = run("0", 5, resume=ckpt)                    # library-made state, continued by torch
+    for mm in (m2, m3):
+        w = torch.cat([p.detach().reshape(-1) for p in mm.parameters()]).cpu().numpy()
+        np.testing.assert_allclose(w, w0, atol=3e-6, rtol=0)
+    # a missing gradient: identical to torch's own handling of the same loop
+    m4, o4 = run("0", 5, drop_grad_at=2)
+    m5, o5 = run("1", 5, drop_grad_at=2)
+    w4 = torch.cat([p.detach().reshape(-1) for p in m4.parameters()]).cpu().numpy()
+    w5 = torch.cat([p.detach().reshape(-1) for p in m5.parameters()]).cpu().numpy()
+    np.testing.assert_allclose(w5, w4, atol=3e-6, rtol=0)
+    assert o5.__dict__["_qpn_adopt"] is False            # (step counts differ across parameters from there on: torch's loop keeps the optimizer)
+    s4, s5 = o4.state_dict(), o5.state_dict()
+    assert [float(s5["state"][i]["step"]) for i in s5["state"]] == [float(s4["state"][i]["step"]) for i in s4["state"]]
+
+
+def test_stock_adam_left_alone_when_not_this_modules(cuda, monkeypatch):
+    """two groups, or a closure: torch's own step runs (with fused=True on eligible groups), results as before."""
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    monkeypatch.setenv("QPN_DROPIN_FUSED_ADAM", "1")
+    m = util.build_model(cfg, synth.make_weights(cfg, 12), cuda).train()
+    ps = list(m.parameters())
+    opt = torch.optim.Adam([{"params": ps[:4]}, {"params": ps[4:], "lr": 5e-4}], lr=1e-3)
+    _ref_loop_step(m, opt, cfg, cuda, 80)
+    assert opt.__dict__["_qpn_adopt"] is False and all(g["fused"] for g in opt.param_groups)
+    opt2 = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x, h, t, d, b = synth.train_inputs(cfg, 700, 81, 30000)
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+
+    def closure():
+        opt2.zero_grad()
+        out = m(xt, ht, dt, bt)
+        loss = torch.nn.CrossEntropyLoss()(out.reshape(-1, cfg.n_quantize), tt[:, -out.shape[1]:].reshape(-1))
+        loss.backward()
+        return loss
+    w_before = m.flat_parameters().clone()
+    loss = opt2.step(closure)
+    assert float(loss.detach()) > 0 and float((m.flat_parameters().detach() - w_before).abs().max()) > 1e-5
+    assert not opt2.__dict__.get("_qpn_adopt")
 
 
 def test_grad_accumulation_and_zero_grad_in_place(cuda):

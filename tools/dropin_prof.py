@@ -17,8 +17,15 @@ def step():
     opt.zero_grad()
     loss.backward()
     opt.step()
-for _ in range(10): step()
-torch.cuda.synchronize()
+import time
+for _ in range(20): step()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(300): step()
+    torch.cuda.synchronize()
+    print("reference-style loop: %.1f steps/s" % (300 / (time.perf_counter() - t0)), flush=True)
+if "--rate" in sys.argv:
+    sys.exit(0)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 pr.disable(); torch.cuda.synchronize()
