@@ -1291,9 +1291,16 @@ __global__ __launch_bounds__(128) void k_aux_tail(AuxArgs p) {
 }
 
 // torch.optim.Adam (single tensor semantics, fp32)
+// rep: the step's reports, written straight into pinned host memory by the step's last kernel (a copy engine launch each -- 3-4 us on the stream -- otherwise):
+// the status word and, when asked for, the 64 partial sums of the loss (qpn_train_step)
+struct AdamReports { int* h_status; double* h_loss; const double* d_loss; };
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den, const int* __restrict__ status) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den, const int* __restrict__ status, AdamReports rep) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (rep.h_loss && threadIdx.x < 64) rep.h_loss[threadIdx.x] = rep.d_loss[threadIdx.x];
+        if (rep.h_status && threadIdx.x == 0) *rep.h_status = *status;
+    }
     if (i >= n) return;
     // The device-side status word (sticky until the host reads it: a tap / target out of range, an abandoned stack launch) flags results that must not
     // reach the parameters: the update of a flagged step -- and of the steps enqueued behind it until the host has collected the word, two steps later
@@ -1569,9 +1576,11 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }
 
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status, hipStream_t stream) {
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status,
+                    int* h_status, double* h_loss, const double* d_loss, hipStream_t stream) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), den, status);
+    AdamReports rep; rep.h_status = status ? h_status : nullptr; rep.h_loss = d_loss ? h_loss : nullptr; rep.d_loss = d_loss;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), den, status, rep);
     qpn_prof_mark(PG_ADAM, stream);
     QPN_HIP(hipGetLastError());
     return QPN_OK;

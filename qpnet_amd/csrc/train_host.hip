@@ -13,7 +13,8 @@ int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, i
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status, hipStream_t stream);
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status,
+                    int* h_status, double* h_loss, const double* d_loss, hipStream_t stream);
 
 
 struct TrainState {
@@ -749,7 +750,7 @@ extern "C" int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_gra
                                 const float* d_grad_denominator, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
-    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, h->train ? h->train->d_status : nullptr, (hipStream_t)stream_);
+    return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, h->train ? h->train->d_status : nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream_);
 }
 
 // One optimisation step behind ONE call -- what a training loop's body is (reference src/bin/qpnet_train.py:517-531: forward, CrossEntropyLoss, backward,
@@ -771,16 +772,29 @@ extern "C" int qpn_train_step(qpn_handle* h, float* d_flat, int B, int64_t T, in
     rc = qpn_train_status_collect_lagged(h); if (rc) return rc;          // the check of the step before the previous one (never waits for queued work)
     rc = qpn_train_forward_loss(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_targets, tgt_stride, d_logits, 0, d_dlogits, stream); if (rc) return rc;
     rc = qpn_train_backward(h, d_dlogits, d_grad, stream); if (rc) return rc;
-    rc = qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream); if (rc) return rc;
-    if (loss_mode == 1) {
-        rc = qpn_train_loss_enqueue(h, stream); if (rc) return rc;
-        rc = qpn_train_status_enqueue(h, stream); if (rc) return rc;
-        return qpn_train_loss_collect(h, 0, h_loss, h_valid);
-    }
     if (loss_mode == 2) {
+        rc = qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream); if (rc) return rc;
         rc = qpn_train_loss(h, h_loss, stream); if (rc) return rc;
         *h_valid = 1;
         return qpn_train_status(h, stream);
     }
-    return qpn_train_status_enqueue(h, stream);
+    // modes 0 / 1: the Adam kernel -- the step's last -- writes the status word (and the loss partials) into the pinned slots itself: what
+    // qpn_train_status_enqueue / qpn_train_loss_enqueue do with a copy each, without the two copy-engine launches behind the step
+    if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
+    TrainState* t = h->train;
+    const int sslot = t->status_newest ^ 1;
+    rc = status_collect_slot(t, sslot); if (rc) return rc;               // (two enqueues old: long done)
+    const int lslot = t->loss_newest ^ 1;
+    if (loss_mode == 1 && t->loss_pending[lslot]) QPN_HIP(hipEventSynchronize(t->ev_loss[lslot]));      // (an uncollected copy of two calls ago: dropped)
+    rc = qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, t->d_status, t->h_status_pinned + sslot,
+                         loss_mode == 1 ? t->h_loss_pinned + 64 * lslot : nullptr, loss_mode == 1 ? t->d_loss : nullptr, (hipStream_t)stream);
+    if (rc) return rc;
+    QPN_HIP(hipEventRecord(t->ev_status[sslot], (hipStream_t)stream));
+    t->status_pending[sslot] = true; t->status_newest = sslot;
+    if (loss_mode == 1) {
+        QPN_HIP(hipEventRecord(t->ev_loss[lslot], (hipStream_t)stream));
+        t->loss_pending[lslot] = true; t->loss_newest = lslot;
+        return qpn_train_loss_collect(h, 0, h_loss, h_valid);
+    }
+    return QPN_OK;
 }
