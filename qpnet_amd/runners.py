@@ -89,6 +89,9 @@ class PinnedStager:
         self.slots = [None] * depth                        # one pinned byte buffer per slot (grown on demand)
         self.events = [None] * depth
         self.i = 0
+        # the copies run on a stream of their own: on the compute stream a 0.5 MB chunk is a DMA packet BETWEEN two of the step's kernels (the queue is in
+        # order: ~25 us of every 705 us step with the compute units idle, tools/step_timeline.py on the run_train loop).  QPN_STAGE_STREAM=0: the caller's stream.
+        self.copy_stream = torch.cuda.Stream(device) if (torch.device(device).type == "cuda" and os.environ.get("QPN_STAGE_STREAM", "1") != "0") else None
 
     def __call__(self, named):
         """named: {name: cpu tensor} -> {name: device tensor}.  ONE asynchronous copy on the current stream: the tensors are packed into the slot's
@@ -108,11 +111,20 @@ class PinnedStager:
         for name, t in named.items():
             n = t.numel() * t.element_size()
             buf[offs[name]:offs[name] + n].view(t.dtype).view(t.shape).copy_(t)
-        dbuf = buf[:total].to(self.device, non_blocking=True)
+        cs = self.copy_stream
+        if cs is not None:
+            with torch.cuda.stream(cs):
+                dbuf = buf[:total].to(self.device, non_blocking=True)
+        else:
+            dbuf = buf[:total].to(self.device, non_blocking=True)
         out = {name: dbuf[offs[name]:offs[name] + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for name, t in named.items()}
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(cs if cs is not None else torch.cuda.current_stream(self.device))
         self.events[k] = ev
+        if cs is not None:
+            # whoever consumes the batch joins the copy: FusedTrainer.step / QPNet.forward look at their FIRST input (train.join_staged)
+            for t in out.values():
+                t.__dict__["_qpn_staged"] = (ev, dbuf)
         self.i = (self.i + 1) % self.depth
         return out
 

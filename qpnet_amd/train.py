@@ -220,6 +220,18 @@ _register_optimizer_step_pre_hook(_adam_prehook)
 _register_optimizer_step_post_hook(_adam_posthook)
 
 
+def join_staged(x, dev):
+    """Inputs copied to the device on a stream of their own (runners.PinnedStager: the copy must not sit between the step's kernels on the compute stream) carry
+    {ready event, device buffer}: the consumer's stream waits for the copy -- long done when a prefetch thread is ahead, so the wait is a queue packet, not a
+    stall -- and the buffer is marked as used on that stream (the caching allocator will not hand it out again before the step that reads it has run)."""
+    st = x.__dict__.get("_qpn_staged") if isinstance(x, torch.Tensor) else None
+    if st is not None:
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(st[0])
+        st[1].record_stream(cur)
+        del x.__dict__["_qpn_staged"]                  # (once per batch)
+
+
 def model_params(model):
     """list(model.parameters()), cached (see above)."""
     c = model.__dict__.get("_qpn_params")
@@ -422,6 +434,7 @@ def qpnet_forward(model, x, h, dilated_factors, blength):
     bl_host = blength.tolist() if hasattr(blength, "tolist") else list(blength)
     assert all(v == bl_host[0] for v in bl_host)
     BL = int(bl_host[0])
+    join_staged(x, dev)
     maxd = forward_maxd(model, x.shape[1], h.shape[2], dilated_factors.shape[1], BL, dilated_factors)
     x = x.to(dev, torch.int64).contiguous()
     h = h.to(dev, torch.float32).contiguous()
@@ -596,6 +609,7 @@ class FusedTrainer:
         L, hd = model._native(dev)
         flat = ensure_flat(model, dev)
         self._buffers(flat)
+        join_staged(x, dev)
         x = self._norm(x, torch.int64, dev); t = self._norm(t, torch.int64, dev)
         h = self._norm(h, torch.float32, dev); d = self._norm(d, torch.float32, dev)
         assert x.dim() == 2 and t.shape[0] == x.shape[0] and h.dim() == 3 and h.shape[1] == model.n_aux and d.dim() == 2

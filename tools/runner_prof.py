@@ -1,7 +1,8 @@
 # dev: where the run_train loop's time goes.  The same generator chunks (a) pre-staged on the device and stepped in a plain loop (what the device can do
 # on THIS chunk mix), (b) the same with the lagged loss, (c) through the real pipeline (generator -> PinnedStager -> prefetch thread -> step):
 #   python tools/runner_prof.py
-import sys, time
+import os, sys, time
+if os.environ.get('SWITCH'): sys.setswitchinterval(float(os.environ['SWITCH']))
 import numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from qpnet_amd import loaders, synth

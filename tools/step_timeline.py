@@ -16,6 +16,12 @@ steps = [ks[a:b] for a, b in zip(starts[:-1], starts[1:])]
 steps = [s for s in steps if any(k["n"].startswith("k_adam") for k in s)][-8:]
 durs = [s[-1]["e"] - s[0]["s"] for s in steps]
 period = [b[0]["s"] - a[0]["s"] for a, b in zip(steps[:-1], steps[1:])]
+inter = [b[0]["s"] - max(k["e"] for k in a) for a, b in zip(steps[:-1], steps[1:])]
+allsteps = [ks[a:b] for a, b in zip(starts[:-1], starts[1:])]
+allinter = sorted((b[0]["s"] - max(k["e"] for k in a)) / 1e3 for a, b in zip(allsteps[:-1], allsteps[1:]) if a and b)
+if allinter:
+    n = len(allinter)
+    print("idle between a step's last kernel and the next step's first, all %d steps: median %.1f us, mean %.1f, p90 %.1f, max %.1f" % (n, allinter[n // 2], sum(allinter) / n, allinter[int(n * 0.9)], allinter[-1]))
 print("steps analysed %d; first-kernel-start to last-kernel-end: median %.1f us; step period median %.1f us" % (len(steps), statistics.median(durs) / 1e3, statistics.median(period) / 1e3 if period else 0))
 s = steps[len(steps) // 2]
 t0 = s[0]["s"]
