@@ -305,7 +305,7 @@ def cpu_baseline_train(cfg, flat, batch):
             "note": "the reference's own torch-CPU step: 1.20 s/step on 8 threads in the survey container (BASELINE.md section 2)"}
 
 
-def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=30):
+def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=200):
     """The reference trainer's loop, unchanged, on the drop-in module (src/bin/qpnet_train.py:517-531):
     model(x,h,d,b) -> nn.CrossEntropyLoss -> zero_grad -> backward -> Adam.step."""
     import torch
@@ -321,7 +321,9 @@ def dropin_loop_rate(m, cfg, batches, nchunks, flat_adam, steps=30):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    for i in range(3):
+    # (torch loads the code objects of its own loss kernels lazily: the first cross_entropy costs ~95 ms, the eighth backward ~80 ms on this image -- both
+    #  inside a 30-step window made the first leg read 230-310 steps/s)
+    for i in range(12):
         step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(steps):
