@@ -1402,6 +1402,12 @@ int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ&
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const TrainSlabs& sl = *bw.sl;
+    const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
+    const bool persist = C == 64 && (p.Ktp == 176 || p.hoist) && p.Ap <= 64 && off32 && k.persist_bwd;
+    // the whole stack's backward as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE_BWD=0 (or
+    // QPN_STACK_QUEUE=0) keeps a launch per layer
+    const bool stack_q = persist && k.stack_q_bwd && sq && sq->flags && p.qctl && qpn_stack_bwd_fits(p);
+    const bool wr_summed = stack_q;
     const size_t nDX = (size_t)B * N1 * C;
     // 16-row tiles (measured 11-15 % faster than 32 rows: twice the workgroups, a shorter last round)
     const size_t lds_post = (size_t)16 * (tr_lda(Q > S ? Q : S) + tr_lda(S)) * sizeof(float);
@@ -1481,7 +1487,8 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     };
     auto build_wr = [&]() {     // dWr_l = dXout_l^T g_l (dXout_l = grad wrt X[l+1]); zero rows for the last layer
         Wg2 w = wbase;
-        w.A = bw.DXA[0] + nDX; w.A2 = bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
+        // (the stack queue's tiles have replaced the own-row part by the sum of both parts: store_dx in k_stack_bwd)
+        w.A = bw.DXA[0] + nDX; w.A2 = wr_summed ? nullptr : bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
         w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
         w.nlayers = L; w.ncol_groups = wgrad_col_groups(w.M, w.N);
         for (int l = 0; l < L; ++l) {
@@ -1512,12 +1519,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
         if (early_reduce && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
     }
     const int swz = k.xcd_swizzle ? 1 : 0;
-    const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
-    const bool persist = C == 64 && (p.Ktp == 176 || p.hoist) && p.Ap <= 64 && off32 && k.persist_bwd;
     if (p.hoist && !persist) { qpn_set_error("internal: the frame-rate aux term needs the register-resident layer kernels"); return QPN_EINVAL; }
-    // the whole stack's backward as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE_BWD=0 (or
-    // QPN_STACK_QUEUE=0) keeps a launch per layer
-    const bool stack_q = persist && k.stack_q_bwd && sq && sq->flags && p.qctl && qpn_stack_bwd_fits(p);
     if (stack_q) { const int rcq = qpn_launch_stack_bwd(p, bw, *sq, k, stream); if (rcq) return rcq; }
     for (int l = L - 1; l >= 0 && !stack_q; --l) {
         const TrLayer& ly = p.layers[l];
