@@ -153,3 +153,40 @@ def test_run_train_does_not_write_a_flagged_model(cuda, tmp_path, monkeypatch):
                            "--resume", exp + "/none.pkl"])
     assert e.value.code == -4
     assert not os.path.exists(exp + "/checkpoint-final.pkl")
+
+
+def test_staged_chunks_arrive_on_a_copy_stream_and_are_joined_by_their_first_use(cuda, monkeypatch):
+    """runners.PinnedStager copies a chunk on a stream of its own; the tensors carry {ready event, device buffer} until the step / forward that first uses them
+    has made its stream wait for the copy (train.join_staged).  Same logits and the same step as with the chunk copied on the compute stream."""
+    import torch
+    from qpnet_amd.runners import PinnedStager
+    from qpnet_amd.train import FusedTrainer
+    import util
+    cfg = TINY
+    flat = synth.make_weights(cfg, 9)
+    x, h, t, d, b = synth.train_inputs(cfg, 600, 33, 30000)
+    host = {"x": torch.from_numpy(x), "h": torch.from_numpy(h), "t": torch.from_numpy(t), "d": torch.from_numpy(d)}
+    outs, ws = [], []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QPN_STAGE_STREAM", mode)
+        stage = PinnedStager(cuda)
+        assert (stage.copy_stream is not None) == (mode == "1")
+        m = util.build_model(cfg, flat, cuda).train()
+        dv = stage(host)
+        assert ("_qpn_staged" in dv["x"].__dict__) == (mode == "1")
+        for k in host:
+            assert dv[k].device.type == "cuda" and dv[k].dtype == host[k].dtype and tuple(dv[k].shape) == tuple(host[k].shape)
+        with torch.no_grad():
+            outs.append(m(dv["x"], dv["h"], dv["d"], b).cpu().numpy())          # QPNet.forward joins the copy
+        assert "_qpn_staged" not in dv["x"].__dict__
+        for k in host:
+            np.testing.assert_array_equal(dv[k].cpu().numpy(), host[k].numpy())
+        tr = FusedTrainer(m, lr=1e-3)
+        for i in range(6):                                                         # the ring of pinned slots (depth 4) is reused
+            dv = stage(host)
+            tr.step(dv["x"], dv["h"], dv["t"], dv["d"], b, want_loss=False, maxd=int(np.ceil(d.max())))
+            assert "_qpn_staged" not in dv["x"].__dict__
+        tr.check_status()
+        ws.append(m.flat_parameters().detach().cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(ws[0], ws[1], rtol=0, atol=2e-6)                    # (float-atomics order inside a step)
