@@ -1127,6 +1127,20 @@ static int wgrad_col_groups(int M, int N) {
 }
 
 static bool wgrad2_any(const Wg2& w, int nch, bool generic, hipStream_t stream) {
+    if (w.M > 256 && w.bmode != 4) {
+        // more output rows than a workgroup's tile budget (n_skipch / n_quantize > 256): blocks of 256 rows of dW, each a launch of its own -- the A operand's
+        // columns, the slab rows and the bias entries shift together
+        bool ok = true;
+        for (int m0 = 0; m0 < w.M && ok; m0 += 256) {
+            Wg2 sub = w;
+            sub.A = w.A + m0; if (w.A2) sub.A2 = w.A2 + m0;
+            sub.M = w.M - m0 < 256 ? w.M - m0 : 256;
+            for (int l = 0; l < w.nlayers; ++l) { sub.goff[l] = w.goff[l] + m0 * w.ldc; if (w.gbias[l] >= 0) sub.gbias[l] = w.gbias[l] + m0; }
+            sub.ncol_groups = wgrad_col_groups(sub.M, sub.N);
+            ok = wgrad2_any(sub, nch, generic, stream);
+        }
+        return ok;
+    }
     if (wgrad3_any(w, nch, generic, stream)) return true;
     switch (w.bmode) {
     case 4: return false;                       // one-hot operand: k_wgrad3 only (the launcher checks the geometry first)
@@ -1172,10 +1186,9 @@ __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __res
 }
 
 // causal conv weight grad: dW[c][q][tap] = sum over rows whose sample == q; LDS table per channel block
-__global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, int rows_per_wg) {
-    extern __shared__ float tab[];                 // [2][Q][CB]
+__global__ __launch_bounds__(256) void k_causal_bwd(TrainParams p, TrainBwd bw, int rows_per_wg, int CB) {
+    extern __shared__ float tab[];                 // [2][Q][CB]; CB: channels per pass (64, fewer when the class count is large: the table stays within 128 KB)
     const int C = p.C, Q = p.Q;
-    const int CB = C < 64 ? C : 64;
     const int tid = threadIdx.x;
     const int64_t total = (int64_t)p.B * p.N1;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < total ? r0 + rows_per_wg : total;
@@ -1384,10 +1397,14 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom
     {
         const int64_t total = (int64_t)B * N1;
         const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
-        const int CB = C < 64 ? C : 64;
-        const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
-        if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
-        if (sl.g_cw < 0) hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw);
+        if (sl.g_cw < 0) {
+            int CB = C < 64 ? C : 64;
+            while (CB > 1 && (size_t)2 * Q * CB * sizeof(float) > 128 * 1024) CB /= 2;
+            const size_t lds_c = (size_t)2 * Q * CB * sizeof(float);
+            if (lds_c > 160 * 1024) { qpn_set_error("causal-table gradient: n_quantize too large for the LDS histogram"); return QPN_EINVAL; }
+            if (lds_c > 48 * 1024) QPN_HIP(hipFuncSetAttribute((const void*)k_causal_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+            hipLaunchKernelGGL(k_causal_bwd, dim3(nwg), dim3(256), lds_c, stream, p, bw, rpw, CB);
+        }
         if (p.U > 0 && !up_done && !p.hoist) launch_up_bwd(p, bw, stream);
         if (p.hoist && ag && !up_done) launch_aux_tail(p, bw, *ag, stream);      // (behind the reduction's zeroing: it adds onto the upsampling-bias entry; up_done: it ran on the side stream)
     }
@@ -1573,7 +1590,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     if (!overlap) launch_skip_post(stream);
     if (sl.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, gen, stream);
     if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
-    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128, n_skipch/n_quantize <= 256)"); return QPN_EINVAL; }
+    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128 on this path; wider stacks take the GEMM path)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD_CAUSAL, stream);
     return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }

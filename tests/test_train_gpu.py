@@ -311,6 +311,31 @@ def test_other_geometry_train_vs_oracle(geo, cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=0.0)
 
 
+@pytest.mark.parametrize("geo", [(64, 512, 256), (64, 384, 1024), (128, 512, 512)], ids=["S512", "S384-Q1024", "C128-S512-Q512"])
+def test_wide_post_net_train_vs_oracle(geo, cuda):
+    """n_skipch / n_quantize above 256 (the reference takes any, qpnet.py:174-178): the skip / post-net weight gradients go out as blocks of 256 output rows,
+    the causal table's gradient -- an LDS histogram when the one-hot contraction's tiles do not fit -- takes fewer channels per pass."""
+    import torch
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import QPNetConfig
+    C, S, Q = geo
+    cfg = QPNetConfig(n_quantize=Q, n_resch=C, n_skipch=S, dilationF_depth=2, dilationF_repeat=1, dilationA_depth=2, dilationA_repeat=1)
+    flat = synth.make_weights(cfg, 7)
+    x, h, t, d, b = synth.train_inputs(cfg, 500, 6, 4000)
+    BL = int(b[0])
+    m = util.build_model(cfg, flat, cuda).train()
+    xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+    logits = m(xt, ht, dt, bt)
+    loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tt[:, -BL:].reshape(-1))
+    loss.backward()
+    grad = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss.item() - float(oloss)) < 1e-4
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), lg, atol=2e-5, rtol=0)
+    util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=0.0)
+
+
 def test_flat_adam_matches_torch_adam(cuda, monkeypatch):
     """FlatAdam (one kernel over the flat parameter buffer) == torch.optim.Adam's OWN update (the step hooks off) on the same loop, three steps."""
     import torch
