@@ -149,7 +149,10 @@ def _adam_prehook(opt, args, kwargs):
             _adam_switch_to_fused(opt)
         if mode == "torch" or has_closure:
             return
-        a = _adam_adopt(opt)
+        try:
+            a = _adam_adopt(opt)
+        except Exception:                                # (an optimizer state this code does not know: torch's own step, as if the hooks were off)
+            a = None
         if a is None:
             d["_qpn_adopt"] = False
             return

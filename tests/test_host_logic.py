@@ -84,3 +84,34 @@ def test_data_parallel_replicas_are_refused():
     assert wrapped.module is m
     with pytest.raises(RuntimeError, match="one process per GPU"):
         m._replicate_for_data_parallel()                # what torch.nn.parallel.replicate calls for every replica
+
+
+def test_optimizer_step_hooks_leave_other_modules_alone():
+    """qpnet_amd.train registers global torch.optim step hooks (the reference loop's stock Adam is stepped by the library, train._adam_prehook): an Adam over
+    any other module's parameters -- or an optimizer of another class -- is looked at once and never again, and steps exactly as without the hooks."""
+    import torch
+    import qpnet_amd.train  # noqa: F401  (registers the hooks)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    ref = torch.nn.Linear(5, 3)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.randn(7, 5)
+    opt = torch.optim.Adam(lin.parameters(), lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad(); lin(x).pow(2).sum().backward(); opt.step()
+    assert opt.__dict__.get("_qpn_adopt") is False and len(opt.param_groups[0]["params"]) == 2
+    # the same three steps computed by hand (torch's documented update rule)
+    ps = list(ref.parameters()); m = [torch.zeros_like(p) for p in ps]; v = [torch.zeros_like(p) for p in ps]
+    for k in range(1, 4):
+        for p in ps:
+            p.grad = None
+        ref(x).pow(2).sum().backward()
+        with torch.no_grad():
+            for p, mi, vi in zip(ps, m, v):
+                mi.mul_(0.9).add_(p.grad, alpha=0.1); vi.mul_(0.999).addcmul_(p.grad, p.grad, value=0.001)
+                p.addcdiv_(mi / (1 - 0.9 ** k), (vi / (1 - 0.999 ** k)).sqrt() + 1e-8, value=-1e-2)
+    for a, b in zip(lin.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6, rtol=0)
+    sgd = torch.optim.SGD(lin.parameters(), lr=0.1)
+    sgd.zero_grad(); lin(x).sum().backward(); sgd.step()
+    assert "_qpn_adopt" not in sgd.__dict__
