@@ -445,6 +445,11 @@ def run_train(args, rank, local, world):
     hoist = os.environ.get("QPN_AUX_HOIST", "1") != "0"
     fl_algo, fl = train_flops(cfg, N1, BL, starts, hoist)
     knames = pg_kernel_names(hoist)
+    if os.environ.get("QPN_POST_FUSE", "1") != "0":
+        # the fused step runs the post-net's forward (with the cross entropy) and backward of a row tile as ONE kernel: its time is in the forward's group
+        knames[2] = "k_post_fb_w<5>"; del knames[4]
+        fl = list(fl); fl_algo = list(fl_algo)
+        fl[2] += fl[4]; fl[4] = 0.0; fl_algo[2] += fl_algo[4]; fl_algo[4] = 0.0
     tr_meas = measured_traffic() or {}
     pmc = measured_pmc() or {}
     kernels = []
@@ -457,6 +462,7 @@ def run_train(args, rank, local, world):
                         "mfma_busy": pmc.get(kname), "hbm_bytes": tr_meas.get("train", {}).get("hbm_bytes_by_kernel", {}).get(kname)})
     kernels.sort(key=lambda k: -k["us"])
     dom = kernels[0]                               # the single longest kernel of the step (per-launch HIP events on the launch stream)
+    low = min((k_ for k_ in kernels if k_["gflop"] > 0), key=lambda k_: k_["frac"])      # ... and the one furthest below the roofline
     wg_ms = sum(ms[i] for i in PG_WGRAD); wg_fl = sum(fl[i] for i in PG_WGRAD)
     total_flops, total_algo = sum(fl), sum(fl_algo)
     value = args.steps * world / dt
@@ -480,6 +486,8 @@ def run_train(args, rank, local, world):
                      # every heavy kernel of the step, longest first: us from HIP events around the launch (one stream), gflop = EXECUTED FLOPs,
                      # mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES fraction from the committed PMC pass (profiles/), hbm_bytes per launch likewise
                      "kernels": kernels[:8],
+                     # the kernel furthest below the matrix-core roofline (since round 5 the longest kernel is the fused post-net tile kernel; this one is not it)
+                     "lowest": {"name": low["name"], "us": low["us"], "frac": low["frac"], "mfma_busy": low["mfma_busy"]},
                      "wgrad_group": {"launches": 5, "ms": round(wg_ms, 4), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms > 0 else None,
                                      "frac": round(wg_fl / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3) if wg_ms > 0 else None},
                      "step_tflops": total_flops / (sum(ms) * 1e-3) / 1e12, "step_device_ms": sum(ms),
@@ -488,7 +496,7 @@ def run_train(args, rank, local, world):
                      "step_frac": total_flops / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "step_frac_algorithmic": total_algo / (dt / args.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                      "groups_ms": dict(zip(PG_NAMES, [round(v, 4) for v in ms])),
-                     "note": "roofline.kernel = the single longest kernel of the step; achieved = its EXECUTED FLOPs / its device time from HIP events "
+                     "note": "roofline.kernel = the single longest kernel of the step (roofline.lowest: the heavy kernel with the smallest fraction); achieved = its EXECUTED FLOPs / its device time from HIP events "
                              "around the launch (the profile step runs on ONE stream; the timed steps run the skip / post-net weight gradients, the early "
                              "slab reduction and the aux-gradient tail on a side stream under the layer backward).  step_frac counts executed FLOPs over the "
                              "timed loop's ms_per_step; step_frac_algorithmic credits the reference's sample-rate aux 1x1 (SURVEY 8d) instead."},

@@ -172,8 +172,12 @@ int qpn_ce_loss(qpn_handle* h, const float* d_logits, const int64_t* d_targets, 
  * `batch_output = model(...)`, `criterion(batch_output[i], batch_t[i])`), with the cross entropy and its gradient computed
  * inside the post-net kernel while a tile's logits are still in LDS (paper-size stacks; wider ones run the separate kernel
  * behind the forward -- same results either way).  d_targets / tgt_stride / d_dlogits as in qpn_ce_loss.  d_logits must be a
- * (B x BL x n_quantize) buffer; with want_logits == 0 the implementation may leave it unwritten.  The loss stays on the
- * device until qpn_train_loss (synchronises) is called. */
+ * (B x BL x n_quantize) buffer; with want_logits bit 0 clear the implementation may leave it unwritten.  want_logits bit 1
+ * (QPN_FWD_BACKWARD_FOLLOWS = 2): the caller promises to run qpn_train_backward[_ex] of this forward next, with this same
+ * d_dlogits untouched -- the post-net's backward may then run inside the forward's launch sequence (one kernel for both
+ * directions of a row tile); a backward with another buffer, or a repeated one, still computes everything itself.  The loss
+ * stays on the device until qpn_train_loss (synchronises) is called. */
+#define QPN_FWD_BACKWARD_FOLLOWS 2
 int qpn_train_forward_loss(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
                            const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
                            float* d_logits, int want_logits, float* d_dlogits, void* stream);

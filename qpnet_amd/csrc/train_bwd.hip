@@ -12,6 +12,7 @@
 //   k_up_bwd     : gradient of the (1,1,1,U) upsampling kernel and its bias
 //   k_reduce_grad: slabs -> flat gradient in state_dict order;  k_adam: torch.optim.Adam update.
 #include "train_common.h"
+#include "train_post.h"
 #include "qpn_handle.h"
 #include <string.h>
 #include <stdlib.h>
@@ -168,89 +169,20 @@ __device__ __forceinline__ void zero_dx_slice(const TrainParams& p, const TrainB
 template <int MT>
 __global__ __launch_bounds__(512) void k_post_bwd_w(TrainParams p, TrainBwd bw, int zero_dx) {
     if (zero_dx) for (int j = 0; j < p.L; ++j) zero_dx_slice(p, bw, j, blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, 512);
-    constexpr int TM = 16 * MT, S = 256, Q = 256;
-    constexpr int lds = ((S + 29) / 32) * 32 + 2;
     extern __shared__ float sm[];
-    float* T = sm;
-    const int LC = p.LC, b = blockIdx.y, t0 = blockIdx.x * TM;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt0 = 2 * wave, NTS = S / 16;
-    const int c0 = 16 * nt0 + (lane & 15), c1 = c0 + 16;
-    const float4* P2t = p.wp + p.p2t_f4; const float4* P1t = p.wp + p.p1t_f4; const float4* Wst = p.wp + p.wst_f4;
-    const int NTL = LC / 16;
-    float4 bq[2] = {P2t[(size_t)nt0 * 64 + lane], P2t[(size_t)(nt0 + 1) * 64 + lane]};
-    float mk[MT][4][2];
-    auto mask_load = [&](const float* src) {                      // rows past the chunk end read the arena's padding rows (masked at the store)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const size_t o = ((size_t)b * p.BL + t0 + 16 * mt + 4 * (lane >> 4) + i) * S;
-                mk[mt][i][0] = src[o + c0]; mk[mt][i][1] = src[o + c1];
-            }
-    };
-    auto put = [&](const f32x4 (&acc)[MT][2], bool masked) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * mt + 4 * (lane >> 4) + i;
-                const bool in = t0 + r < p.BL;
-                T[(size_t)r * lds + c0] = (in && (!masked || mk[mt][i][0] > 0.f)) ? acc[mt][0][i] : 0.f;
-                T[(size_t)r * lds + c1] = (in && (!masked || mk[mt][i][1] > 0.f)) ? acc[mt][1][i] : 0.f;
-            }
-    };
-    auto rows_out = [&](float* dst, size_t ld, int col0) {       // T -> rows t0.. of dst[B][BL][ld], columns col0 .. col0 + 255
-        for (int idx = tid; idx < TM * (S / 2); idx += 512) {
-            const int r = idx / (S / 2), kk = (idx - r * (S / 2)) * 2;
-            if (t0 + r < p.BL) *(float2*)(dst + ((size_t)b * p.BL + t0 + r) * ld + col0 + kk) = *(const float2*)(T + (size_t)r * lds + kk);
-        }
-    };
-    mask_load(p.Y0);
-    for (int idx = tid; idx < TM * (Q / 2); idx += 512) {          // stage the dlogits rows
-        const int r = idx / (Q / 2), kk = (idx - r * (Q / 2)) * 2;
-        float2 v = make_float2(0.f, 0.f);
-        if (t0 + r < p.BL) v = *(const float2*)(bw.dlogits + ((size_t)b * p.BL + t0 + r) * Q + kk);
-        *(float2*)(T + (size_t)r * lds + kk) = v;
-    }
-    TR_LDS_BARRIER();
-    f32x4 acc[MT][2], acc2[MT][2];
-#define POSTW_ZERO(a) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { a[mt][0] = (f32x4){0, 0, 0, 0}; a[mt][1] = (f32x4){0, 0, 0, 0}; }
-    // ---------- dY0 = (dlogits . W2) * (Y0 > 0)
-    POSTW_ZERO(acc);
-    post_gemm<MT>(acc, T, lds, P2t, NTS, nt0, Q / 16, lane, bq, P1t + (size_t)nt0 * 64 + lane);
-    TR_LDS_BARRIER();
-    put(acc, true);
-    mask_load(p.S0);                                              // (the Y0 signs are consumed: same registers)
-    TR_LDS_BARRIER();
-    rows_out(bw.DY0, S, 0);
-    // ---------- dS0 = (dY0 . W1post) * (S0 > 0)
-    POSTW_ZERO(acc);
-    post_gemm<MT>(acc, T, lds, P1t, NTS, nt0, S / 16, lane, bq, Wst + (size_t)nt0 * 64 + lane);
-    TR_LDS_BARRIER();
-    put(acc, true);
-    TR_LDS_BARRIER();
-    rows_out(bw.DS0, S, 0);
-    // ---------- DGS[t][l*C + c] = sum_s dS0[t][s] Ws_l[s][c]: L*C columns in passes of 2 x 256 (both held in registers, then
-    //            written through T one after the other)
-    for (int cb = 0; cb < LC; cb += 512) {
-        const int nta = cb / 16 + nt0, ntb = nta + NTS;
-        const bool two = cb + 256 < LC;
-        POSTW_ZERO(acc); POSTW_ZERO(acc2);
-        post_gemm<MT>(acc, T, lds, Wst, NTL, nta, S / 16, lane, bq, Wst + (size_t)(two ? ntb : nta) * 64 + lane);
-        if (two) post_gemm<MT>(acc2, T, lds, Wst, NTL, ntb, S / 16, lane, bq, Wst + (size_t)(cb + 512 < LC ? nta + 2 * NTS : nta) * 64 + lane);
-        TR_LDS_BARRIER();                                          // all reads of dS0 done (a later column pass would need it again: LC <= 512 here)
-        put(acc, false);
-        TR_LDS_BARRIER();
-        rows_out(bw.DGS, (size_t)LC, cb);
-        if (two) {
-            TR_LDS_BARRIER();
-            put(acc2, false);
-            TR_LDS_BARRIER();
-            rows_out(bw.DGS, (size_t)LC, cb + 256);
-        }
-    }
-#undef POSTW_ZERO
+    float4 bq[2];
+    post_bwd_w_tile<MT, false>(p, bw, sm, 0ull, 0ull, bq);
+}
+// Forward (skip sum, post-net, cross entropy) AND backward of a row tile in one kernel, for callers that run both anyway (qpn_train_step): dL/dlogits goes from the cross entropy
+// to the first backward contraction through the LDS tile it is already in, the two ReLU masks are 40 sign bits a lane instead of 160 scattered loads, one launch, one prologue
+// and the gap between two kernels less (the separate backward alone: 116 -> 104 us without its staging and mask loads).
+template <int MT>
+__global__ __launch_bounds__(512) void k_post_fb_w(TrainParams p, TrainBwd bw, int zero_dx) {
+    if (zero_dx) for (int j = 0; j < p.L; ++j) zero_dx_slice(p, bw, j, blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, 512);
+    extern __shared__ float sm[];
+    unsigned long long mS = 0ull, mY = 0ull; float4 bq[2];
+    post_fwd_w_tile<MT, true>(p, sm, mS, mY, bq);
+    post_bwd_w_tile<MT, true>(p, bw, sm, mS, mY, bq);
 }
 
 // ------------------------------------------------------------------------------------------ layer backward
@@ -1416,7 +1348,15 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom
 bool qpn_stack_bwd_fits(const TrainParams& p);
 int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream) {
+void qpn_launch_post_fb(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
+    constexpr int MTW = 5;
+    const size_t ldsw = (size_t)16 * MTW * (tr_lda(256) + 2 * tr_lda(64)) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)k_post_fb_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+    hipLaunchKernelGGL((k_post_fb_w<MTW>), dim3((p.BL + 16 * MTW - 1) / (16 * MTW), p.B), dim3(512), ldsw, stream, p, bw, 1);
+}
+
+// post_done: the forward's launch sequence has run the post-net's backward (and the zeroing) already
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream, bool post_done) {
     const int C = p.C, S = p.S, Q = p.Q, L = p.L, B = p.B, N1 = p.N1, BL = p.BL;
     const TrainSlabs& sl = *bw.sl;
     const bool off32 = N1 < (1 << 24) && (int64_t)N1 * (p.LC > 2 * C ? p.LC : 2 * C) < (1ll << 32);       // k_layer_bwd_p's 32-bit element offsets (one batch item)
@@ -1436,8 +1376,10 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     const bool overlap = side && !qpn_prof_active() && !k.serial;
     const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && k.post_wide;
     const bool zero_in_post = post_wide && k.zero_in_post;
-    if (!zero_in_post) qpn_launch_zero_dx(p, bw, stream);
-    if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
+    if (post_done) { }
+    else if (!zero_in_post) qpn_launch_zero_dx(p, bw, stream);
+    if (post_done) { }
+    else if (post_wide) {      // 80 rows per workgroup (k_post_bwd_w)
         constexpr int MTW = 5;
         const size_t ldsw = (size_t)16 * MTW * tr_lda(256) * sizeof(float);
         QPN_HIP(hipFuncSetAttribute((const void*)k_post_bwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));

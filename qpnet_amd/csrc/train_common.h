@@ -128,6 +128,7 @@ struct TrainKnobs {
     bool persist_fwd, persist_bwd;    // QPN_LAYER_PERSIST=0 / QPN_LAYER_BWD_PERSIST=0: the tile-per-workgroup layer kernels at n_resch 64
     bool wgrad_generic;               // QPN_WGRAD_GENERIC=1: the run-time-tiled weight-gradient kernel (k_wgrad2)
     int wgrad_chunks, wgrad_chunks_side;   // QPN_WGRAD_CHUNKS / QPN_WGRAD_CHUNKS_SIDE: time chunks (= partial slabs) of the weight gradients
+    bool post_fuse;                        // QPN_POST_FUSE=0: qpn_train_step runs the post-net's forward and backward as two kernels (k_post_fwd_w, k_post_bwd_w) instead of k_post_fb_w
     bool up_side, reduce_early, wr_side;   // QPN_UP_SIDE=0 / QPN_REDUCE_EARLY=0 / QPN_WR_SIDE=0: where the backward's small launches run
     bool post_pair, zero_in_post, post_wide;   // QPN_POST_WGRAD_PAIR=0 / QPN_ZERO_IN_POST=0 / QPN_POST_WIDE=0
     bool xcd_swizzle;                 // QPN_NO_XCD_SWIZZLE=1 clears it

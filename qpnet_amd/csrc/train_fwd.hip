@@ -13,6 +13,7 @@
 //                  (_postprocess, qpnet.py:566-571), all on MFMA, logits written time-major
 //                  (B, BL, Q) exactly as the reference returns them.
 #include "train_common.h"
+#include "train_post.h"
 
 // gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32): ~6 instructions each instead of
 // the ~50 of libm's expf/tanhf, which made the epilogue as long as the GEMM; abs error ~1e-7 (tolerance: loss 1e-4)
@@ -674,160 +675,12 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
     }
 }
 
-// dev aid (-DQPN_POST_STAMPS): s_memtime of thread 0 of workgroup `PS_WG` at the stage boundaries of the post-net forward kernels, into the stack queues' control
-// words [600 + 16 * slot + i] (read back with qpn_train_stack_stats; tools/post_stamps.py)
-#ifdef QPN_POST_STAMPS
-#define POST_STAMP(slot, i) do { if (p.qctl && ps_on && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); p.qctl[600 + 16 * (slot) + (i)] = (unsigned)t_; } } while (0)
-#else
-#define POST_STAMP(slot, i) do { } while (0)
-#endif
-// ------------------------------------------------------------------------------------------------ post-net, wide tiles (S = Q = 256)
-// k_post_fwd streams the post-net's 1 MB of weight fragments from L2 once per 16-row tile: 1250 tiles = 1.25 GB per launch, and a
-// 16-deep step's two fragment loads feed only 8 MFMAs (256 cycles) -- the launch runs at the L2's pace, 0.5 of the matrix-core rate.
-// Here a workgroup takes 16 * MT rows (MT = 5: 80 rows, so a 20 000-row chunk is 250 workgroups = ONE round on 256 CUs): the same
-// two loads feed 8 * MT MFMAs, weight traffic drops MT-fold, and the K = L*C skip sum runs as one continuous fragment stream with
-// the gate rows of layer l+1 landing in the other LDS buffer under layer l's contraction.  One [16 MT][S] LDS tile is reused IN
-// PLACE by the three stages (every wave holds its outputs in registers across the barrier that ends the reads), and relu(s0) /
-// relu(y0) leave from it as whole rows -- the backward only needs their sign (the ReLU mask) and the rectified values (weight
-// gradients), so the rectified values are what is stored.   (reference: _postprocess, src/nets/qpnet.py:566-571, 283-309)
+// ------------------------------------------------------------------------------------------------ post-net, wide tiles (S = Q = 256): train_post.h
 template <int MT>
 __global__ __launch_bounds__(512) void k_post_fwd_w(TrainParams p) {
-    constexpr int TM = 16 * MT, S = 256, Q = 256, C = 64, NTS = S / 16;
-    constexpr int lds = ((S + 29) / 32) * 32 + 2, ldg = ((C + 29) / 32) * 32 + 2;
-    constexpr int NG = (TM * (C / 2) + 511) / 512;               // float2 pairs of a [TM][C] gate tile per thread
     extern __shared__ float sm[];
-    float* T = sm;                                                // [TM][lds]; gate staging: T + TM*lds + {0, TM*ldg}
-    float* Gb = sm + TM * lds;
-    const int L = p.L, b = blockIdx.y, t0 = blockIdx.x * TM;
-    const int nbase = p.N1 - p.BL + t0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt0 = 2 * wave;                                     // this wave's two column tiles (of 16) in every stage
-    const int c0 = 16 * nt0 + (lane & 15), c1 = c0 + 16;
-    const float bs0 = p.bp[p.bias_s + c0], bs1 = p.bp[p.bias_s + c1], bp10 = p.bp[p.bias_p1 + c0], bp11 = p.bp[p.bias_p1 + c1],
-                bp20 = p.bp[p.bias_p2 + c0], bp21 = p.bp[p.bias_p2 + c1];
-    const float4* Ws = p.wp + p.ws_f4; const float4* P1 = p.wp + p.p1_f4; const float4* P2 = p.wp + p.p2_f4;
-    float4 bq[2] = {Ws[(size_t)nt0 * 64 + lane], Ws[(size_t)(nt0 + 1) * 64 + lane]};
-    // ---- gate rows of one layer: thread -> NG (row, column pair) items; sigma and tanh halves multiplied on the way into LDS
-    float2 ga[NG], gt[NG];
-    auto gfetch = [&](int l) {
-        const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
-        const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
-            const bool ok = idx < TM * (C / 2) && t0 + r < p.BL;
-            const size_t o = ok ? (size_t)(nbase + r) * C + kk : 0;
-            ga[k] = *(const float2*)(SG + o); gt[k] = *(const float2*)(TH + o);
-        }
-    };
-    auto gstore = [&](float* G) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
-            if (idx < TM * (C / 2)) *(float2*)(G + (size_t)r * ldg + kk) = t0 + r < p.BL ? make_float2(ga[k].x * gt[k].x, ga[k].y * gt[k].y) : make_float2(0.f, 0.f);
-        }
-    };
-    // a finished stage: rectified outputs into T (in place: every wave has passed the barrier that ends the stage's reads) ...
-    auto put = [&](const f32x4 (&acc)[MT][2], float bias0, float bias1, bool relu) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 16 * mt + 4 * (lane >> 4) + i;
-                float v0 = acc[mt][0][i] + bias0, v1 = acc[mt][1][i] + bias1;
-                if (relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
-                T[(size_t)r * lds + c0] = v0; T[(size_t)r * lds + c1] = v1;
-            }
-    };
-    // ... and from there to a [BL][256] array as whole 1 KB rows
-    auto rows_out = [&](float* dst) {
-        for (int idx = tid; idx < TM * (S / 2); idx += 512) {
-            const int r = idx / (S / 2), kk = (idx - r * (S / 2)) * 2;
-            if (t0 + r < p.BL) *(float2*)(dst + ((size_t)b * p.BL + t0 + r) * S + kk) = *(const float2*)(T + (size_t)r * lds + kk);
-        }
-    };
-    const bool ps_on = blockIdx.x == 5 && blockIdx.y == 0; (void)ps_on;
-    POST_STAMP(0, 0);
-    f32x4 acc[MT][2];
-#define POSTW_ZERO() _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { acc[mt][0] = (f32x4){0, 0, 0, 0}; acc[mt][1] = (f32x4){0, 0, 0, 0}; }
-    // ---------- skip sum: one K = L*C contraction, layer l's gates in Gb[l & 1]
-    POSTW_ZERO();
-    gfetch(0);
-    for (int l = 0; l < L; ++l) {
-        float* G = Gb + (l & 1) * TM * ldg;
-        gstore(G);
-        TR_LDS_BARRIER();                                          // G complete; the other buffer's readers (layer l-1) are done
-        if (l + 1 < L) gfetch(l + 1);
-        post_gemm<MT>(acc, G, ldg, Ws + (size_t)l * (C / 16) * NTS * 64, NTS, nt0, C / 16, lane, bq,
-                      l + 1 < L ? Ws + ((size_t)(l + 1) * (C / 16) * NTS + nt0) * 64 + lane : P1 + (size_t)nt0 * 64 + lane);
-    }
-    POST_STAMP(0, 1);
-    put(acc, bs0, bs1, true);
-    TR_LDS_BARRIER();
-    POST_STAMP(0, 2);
-    rows_out(p.S0);
-    POST_STAMP(0, 3);                                               // relu(s0): sign = the backward's mask, value = the weight gradient's operand
-    // ---------- post 1x1 #1
-    POSTW_ZERO();
-    post_gemm<MT>(acc, T, lds, P1, NTS, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
-    POST_STAMP(0, 4);
-    TR_LDS_BARRIER();                                              // every wave (and rows_out) is done reading T
-    put(acc, bp10, bp11, true);
-    TR_LDS_BARRIER();
-    POST_STAMP(0, 5);
-    rows_out(p.Y0);
-    POST_STAMP(0, 6);
-    // ---------- post 1x1 #2
-    POSTW_ZERO();
-    post_gemm<MT>(acc, T, lds, P2, Q / 16, nt0, S / 16, lane, bq, P2 + (size_t)nt0 * 64 + lane);
-    POST_STAMP(0, 7);
-    TR_LDS_BARRIER();
-    put(acc, bp20, bp21, false);
-    TR_LDS_BARRIER();
-    POST_STAMP(0, 8);
-#undef POSTW_ZERO
-    if (p.logits)
-        for (int idx = tid; idx < TM * (Q / 2); idx += 512) {
-            const int r = idx / (Q / 2), kk = (idx - r * (Q / 2)) * 2;
-            if (t0 + r < p.BL) *(float2*)(p.logits + ((size_t)b * p.BL + t0 + r) * Q + kk) = *(const float2*)(T + (size_t)r * lds + kk);
-        }
-    if (!p.ce_tgt) return;
-    // ---------- fused torch.nn.CrossEntropyLoss() (mean) and its gradient while the logits are in LDS (same arithmetic as k_ce)
-    {
-        const int64_t rows = (int64_t)p.B * p.BL;
-        const float inv = 1.0f / (float)rows;
-        double lsum = 0.0;
-        for (int r = wave; r < TM; r += 8) {
-            if (t0 + r >= p.BL) break;
-            const float* lg = T + (size_t)r * lds;
-            const int64_t row = (int64_t)b * p.BL + t0 + r;
-            int64_t tg = p.ce_tgt[(size_t)b * p.ce_stride + (p.ce_stride - p.BL) + t0 + r];
-            if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
-            const int q = lane * 4;
-            const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2);
-            // (the wave reductions are k_ce's: DPP inside the 16-lane rows + v_readlane across them, same order, bit-identical dL/dlogits; as six
-            //  dependent ds_bpermute each they made the cross entropy 25 k of the tile's 232 k cycles: profiles/r05_post_fwd_stamps.txt)
-            const float m = tr_wave_max(fmaxf(fmaxf(v01.x, v01.y), fmaxf(v23.x, v23.y)));
-            const float se = tr_wave_sum((__expf(v01.x - m) + __expf(v01.y - m)) + (__expf(v23.x - m) + __expf(v23.y - m)));
-            const float lse = logf(se) + m;
-            if (p.ce_dlogits) {
-                float4 gq = make_float4(__expf(v01.x - lse), __expf(v01.y - lse), __expf(v23.x - lse), __expf(v23.y - lse));
-                const int dq = (int)tg - q;
-                if (dq == 0) gq.x -= 1.0f; else if (dq == 1) gq.y -= 1.0f; else if (dq == 2) gq.z -= 1.0f; else if (dq == 3) gq.w -= 1.0f;
-                *(float4*)(p.ce_dlogits + (size_t)row * Q + q) = make_float4(gq.x * inv, gq.y * inv, gq.z * inv, gq.w * inv);
-            }
-            lsum += (double)(lse - lg[tg]);
-        }
-        double* part = (double*)Gb;                               // the gate staging is dead
-        if (lane == 0) part[wave] = lsum;
-        __syncthreads();
-        if (tid == 0) {
-            double sacc = 0.0;
-            for (int w8 = 0; w8 < 8; ++w8) sacc += part[w8];
-            atomicAdd(p.ce_loss + (blockIdx.x & 63), sacc / (double)rows);
-        }
-    }
-    POST_STAMP(0, 9);
+    unsigned long long mS, mY; float4 bq[2];
+    post_fwd_w_tile<MT, false>(p, sm, mS, mY, bq);
 }
 
 // mean cross entropy + its gradient, one wave per row, rpw rows per wave (reference qpnet_train.py:430,526-528)
@@ -887,7 +740,10 @@ void qpn_launch_prep(const TrainParams& p, const AuxGeom& ag, hipStream_t stream
 bool qpn_stack_fwd_fits(const TrainParams& p);
 int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
-int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream) {
+void qpn_launch_post_fb(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);      // train_bwd.hip: k_post_fb_w
+
+// fuse_post_bwd: the post-net's backward runs inside this launch sequence too (the caller has checked the geometry: the wide tiles, cross entropy fused)
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream, const TrainBwd* fuse_post_bwd) {
     const int C = p.C, S = p.S;
     qpn_launch_prep(p, ag, stream);
     qpn_prof_mark(PG_PREP, stream);
@@ -930,7 +786,8 @@ int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag,
     qpn_prof_mark(PG_LAYER_FWD, stream);
     // wide post-net tiles (S = Q = 256, n_resch 64): 16 * MT rows per workgroup, MT chosen so that the chunk is one round of workgroups
     const bool post_wide = S == 256 && p.Q == 256 && C == 64 && k.post_wide;
-    if (post_wide) {
+    if (post_wide && fuse_post_bwd) qpn_launch_post_fb(p, *fuse_post_bwd, stream);
+    else if (post_wide) {
         constexpr int MTW = 5;
         const size_t ldsw = (size_t)16 * MTW * (tr_lda(256) + 2 * tr_lda(64)) * sizeof(float);
         QPN_HIP(hipFuncSetAttribute((const void*)k_post_fwd_w<MTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw));

@@ -7,10 +7,10 @@
 #include <algorithm>
 #include <string.h>
 
-int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
+int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream, const TrainBwd* fuse_post_bwd);
 void qpn_stack_fill(TrainParams& p);
 int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, int B, int BL, int Q, float* dlogits, double* loss, int* status, bool loss_cleared, hipStream_t stream);
-int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream);
+int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream, bool post_done);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status,
@@ -45,6 +45,8 @@ struct TrainState {
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream for the weight gradients that overlap the layer backward
     hipEvent_t ev_early; int early_recorded; int64_t early_first;   // qpn_train_early_bucket: the flat-gradient tail that is final before the layer backward ends
     int64_t bwd_generation;                                  // generation of the forward the last backward belonged to
+    const float* post_bwd_dlogits;                           // ... on this dL/dlogits buffer
+    bool post_bwd_done;                                      // the last forward ran the post-net's backward too (k_post_fb_w: qpn_train_step)
     bool stack_disabled;                                     // a stack-queue launch gave up once (status bit 4): this handle keeps to a launch per layer
     unsigned* d_sq; size_t sq_pos_cap, sq_per_dir;                           // stack work queues (train_stack.hip): [16 control words | forward flags | backward flags]
     StackQ sqf, sqb;
@@ -66,6 +68,7 @@ void qpn_train_knobs_parse(TrainKnobs& k) {
     k.up_side = env_int("QPN_UP_SIDE", 1) != 0;
     k.reduce_early = env_int("QPN_REDUCE_EARLY", 1) != 0;
     k.wr_side = env_int("QPN_WR_SIDE", 1) != 0;
+    k.post_fuse = env_int("QPN_POST_FUSE", 1) != 0;
     k.post_pair = env_int("QPN_POST_WGRAD_PAIR", 1) != 0;
     k.zero_in_post = env_int("QPN_ZERO_IN_POST", 1) != 0;
     k.post_wide = env_int("QPN_POST_WIDE", 1) != 0;
@@ -416,9 +419,10 @@ static int need_dev(qpn_handle* h) {
 
 // targets == nullptr: plain forward.  Otherwise the mean cross entropy (and d_dlogits) is computed too: inside the post-net kernel
 // when the tile path can hold a row of logits in LDS, by a k_ce launch behind the forward otherwise.
+// fuse_bwd: the caller runs this forward's backward next, with the same d_dlogits, whatever the loss is (qpn_train_step): the post-net's backward may run inside the forward's launch
 static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t T, int64_t F, int64_t Td, int BL, int maxd,
                               const int64_t* d_x, const float* d_h, const float* d_dfac, float* d_logits,
-                              const int64_t* d_targets, int64_t tgt_stride, float* d_dlogits, int want_logits, void* stream_) {
+                              const int64_t* d_targets, int64_t tgt_stride, float* d_dlogits, int want_logits, void* stream_, bool fuse_bwd = false) {
     int rc = need_dev(h); if (rc) return rc;
     rc = train_init(h); if (rc) return rc;
     TrainState* t = h->train;
@@ -528,7 +532,10 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     const bool fuse_ce = d_targets && !t->use_gemm && g.Q <= g.S && g.Q % 256 == 0 && !t->knobs.ce_separate;
     p.ce_tgt = fuse_ce ? d_targets : nullptr; p.ce_stride = tgt_stride; p.ce_dlogits = d_dlogits; p.ce_loss = t->d_loss;
     if (fuse_ce && !want_logits) p.logits = nullptr;
-    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->knobs, t->ag, &t->sqf, stream);
+    const bool fuse_post = fuse_bwd && fuse_ce && d_dlogits && t->knobs.post_fuse && t->knobs.post_wide && t->knobs.zero_in_post && g.S == 256 && g.Q == 256 && g.C == 64 && (p.LC == 256 || p.LC == 512);
+    t->post_bwd_done = false;
+    rc = t->use_gemm ? qpn_launch_fwd_gemm(p, t->gm, stream) : qpn_launch_fwd(p, t->knobs, t->ag, &t->sqf, stream, fuse_post ? &t->bw : nullptr);
+    if (!rc) { t->post_bwd_done = fuse_post; t->post_bwd_dlogits = d_dlogits; }
     p.ce_tgt = nullptr; p.logits = d_logits;
     if (rc) return rc;
     t->fwd_valid = true;
@@ -549,7 +556,7 @@ extern "C" int qpn_train_forward_loss(qpn_handle* h, const float* d_flat, int B,
                                       const int64_t* d_x, const float* d_h, const float* d_dfac, const int64_t* d_targets, int64_t tgt_stride,
                                       float* d_logits, int want_logits, float* d_dlogits, void* stream_) {
     if (!d_targets) { qpn_set_error("bad train_forward_loss arguments: no targets"); return QPN_EINVAL; }
-    return train_forward_impl(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_logits, d_targets, tgt_stride, d_dlogits, want_logits, stream_);
+    return train_forward_impl(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_logits, d_targets, tgt_stride, d_dlogits, want_logits & 1, stream_, (want_logits & QPN_FWD_BACKWARD_FOLLOWS) != 0);
 }
 
 extern "C" int qpn_train_loss(qpn_handle* h, double* h_loss, void* stream_) {
@@ -721,8 +728,10 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     // (the backward queue's heads and flags belong to ONE backward per forward: a repeated backward of the same forward runs a launch per layer)
     const bool first_bwd = t->bwd_generation != t->generation;
     t->bwd_generation = t->generation;
+    const bool post_done = t->post_bwd_done && first_bwd && d_dlogits == t->post_bwd_dlogits;      // (a repeated backward, or another dL/dlogits: the separate kernel)
+    t->post_bwd_done = false;
     return t->use_gemm ? qpn_launch_bwd_gemm(t->tp, bw, t->gm, (hipStream_t)stream_)
-                       : qpn_launch_bwd(t->tp, bw, t->knobs, t->ag, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_);
+                       : qpn_launch_bwd(t->tp, bw, t->knobs, t->ag, first_bwd ? &t->sqb : nullptr, (hipStream_t)stream_, post_done);
 }
 
 extern "C" int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* stream_) {
@@ -770,7 +779,8 @@ extern "C" int qpn_train_step(qpn_handle* h, float* d_flat, int B, int64_t T, in
     if (loss_mode < 0 || loss_mode > 2 || (loss_mode && (!h_loss || !h_valid))) { qpn_set_error("bad train_step arguments"); return QPN_EINVAL; }
     int rc = need_dev(h); if (rc) return rc;
     rc = qpn_train_status_collect_lagged(h); if (rc) return rc;          // the check of the step before the previous one (never waits for queued work)
-    rc = qpn_train_forward_loss(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_targets, tgt_stride, d_logits, 0, d_dlogits, stream); if (rc) return rc;
+    if (!d_targets || !d_dlogits) { qpn_set_error("qpn_train_forward_loss needs targets and a dlogits buffer"); return QPN_EINVAL; }
+    rc = train_forward_impl(h, d_flat, B, T, F, Td, BL, maxd, d_x, d_h, d_dfac, d_logits, d_targets, tgt_stride, d_dlogits, 0, stream, true); if (rc) return rc;
     rc = qpn_train_backward(h, d_dlogits, d_grad, stream); if (rc) return rc;
     if (loss_mode == 2) {
         rc = qpn_adam_step_ex(h, d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, nullptr, stream); if (rc) return rc;

@@ -650,7 +650,7 @@ class FusedTrainer:
             # forward + CrossEntropyLoss + dL/dlogits in one call (the loss stays on the device unless asked for)
             _lib.check(L.qpn_train_forward_loss(hd, flat.data_ptr(), B, T, h.shape[2], d.shape[1], BL, maxd,
                                                 x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
-                                                self._logits.data_ptr(), 0, self._dlogits.data_ptr(), stream))
+                                                self._logits.data_ptr(), 2, self._dlogits.data_ptr(), stream))      # (2: the backward of this forward follows, same dL/dlogits)
             if multi:
                 # g <- n_r * grad_r with n_r appended; SUM over ranks; Adam divides by the summed row count on the device
                 _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 1, stream))

@@ -28,6 +28,7 @@ BUDGET = {
     "k_stack_bwdILi11EE": ("train_stack.hip", 0, 2),
     "k_post_fwd_wILi5E": ("train_fwd.hip", 0, 2),           # 80-row post-net tiles: one 512-thread workgroup per CU
     "k_post_bwd_wILi5E": ("train_bwd.hip", 0, 2),
+    "k_post_fb_wILi5E": ("train_bwd.hip", 0, 2),            # forward + backward of a post-net row tile in one kernel (qpn_train_step)
     "k_layer_fwdILi1E": ("train_fwd.hip", 0, 5),          # five 16-row workgroups per CU must be co-resident
     "k_post_fwdILi1E": ("train_fwd.hip", 0, 5),
     "k_layer_bwdILi1E": ("train_bwd.hip", 0, 5),

@@ -336,6 +336,36 @@ def test_wide_post_net_train_vs_oracle(geo, cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=0.0)
 
 
+def test_post_net_tile_kernel_fused_equals_separate(cuda, monkeypatch):
+    """qpn_train_step runs the post-net's forward, the cross entropy and the backward of a row tile as ONE kernel (k_post_fb_w: dL/dlogits handed over in LDS, the ReLU
+    masks as sign bits in registers); QPN_POST_FUSE=0 keeps k_post_fwd_w + k_post_bwd_w.  Same tile arithmetic: loss identical, gradients equal up to the float-atomics
+    order of the OTHER kernels; a ragged last tile (rows past the chunk end) and two batch items included."""
+    import torch
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.train import FusedTrainer
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 17)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("QPN_POST_FUSE", mode)
+        out = []
+        for bl, B in ((1500, 1), (333, 2)):
+            x, h, t, d, b = synth.train_inputs(cfg, bl, 44, 30000)
+            if B == 2:
+                x = np.concatenate([x, x[:, ::-1]]); t = np.concatenate([t, t[:, ::-1]]); h = np.concatenate([h, h]); d = np.concatenate([d, d]); b = np.concatenate([b, b])
+            m = util.build_model(cfg, flat, cuda).train()
+            tr = FusedTrainer(m, lr=1e-4)
+            xt, ht, tt, dt, bt = _to(cuda, x, h, t, d, b)
+            loss = tr.step(xt, ht, tt, dt, b, want_loss=True)
+            tr.check_status()
+            out.append((loss, tr.g[:flat.size].cpu().numpy(), tr._dlogits.cpu().numpy()))
+        res[mode] = out
+    for (l1, g1, dl1), (l0, g0, dl0) in zip(res["1"], res["0"]):
+        assert abs(l1 - l0) < 1e-9
+        np.testing.assert_array_equal(dl1, dl0)                      # dL/dlogits also reaches memory (the post-net weight gradients read it)
+        np.testing.assert_allclose(g1, g0, rtol=0, atol=2e-6 * np.abs(g0).max())
+
+
 def test_flat_adam_matches_torch_adam(cuda, monkeypatch):
     """FlatAdam (one kernel over the flat parameter buffer) == torch.optim.Adam's OWN update (the step hooks off) on the same loop, three steps."""
     import torch
