@@ -113,6 +113,14 @@ __device__ __forceinline__ void post_fwd_w_tile(const TrainParams& p, float* sm,
     POST_STAMP(0, 5);
     rows_out(p.Y0);
     POST_STAMP(0, 6);
+    // the targets of this wave's cross-entropy rows, asked for a whole contraction ahead (one dependent global load per row inside the row loop was most of that phase)
+    constexpr int NCE = TM / 8;
+    int64_t tgv[NCE];
+#pragma unroll
+    for (int k = 0; k < NCE; ++k) {
+        const int r = wave + 8 * k;
+        tgv[k] = (p.ce_tgt && t0 + r < p.BL) ? p.ce_tgt[(size_t)b * p.ce_stride + (p.ce_stride - p.BL) + t0 + r] : 0;
+    }
     // ---------- post 1x1 #2
     POSTW_ZERO();
     post_gemm<MT>(acc, T, lds, P2, Q / 16, nt0, S / 16, lane, bq, (FUSED ? p.wp + p.p2t_f4 : P2) + (size_t)nt0 * 64 + lane);
@@ -133,11 +141,13 @@ __device__ __forceinline__ void post_fwd_w_tile(const TrainParams& p, float* sm,
         const int64_t rows = (int64_t)p.B * p.BL;
         const float inv = 1.0f / (float)rows;
         double lsum = 0.0;
-        for (int r = wave; r < TM; r += 8) {
+#pragma unroll
+        for (int k = 0; k < NCE; ++k) {
+            const int r = wave + 8 * k;
             if (t0 + r >= p.BL) break;
             const float* lg = T + (size_t)r * lds;
             const int64_t row = (int64_t)b * p.BL + t0 + r;
-            int64_t tg = p.ce_tgt[(size_t)b * p.ce_stride + (p.ce_stride - p.BL) + t0 + r];
+            int64_t tg = tgv[k];
             if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
             const int q = lane * 4;
             const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2);
