@@ -462,7 +462,7 @@ def run_train(args, rank, local, world):
                         "mfma_busy": pmc.get(kname), "hbm_bytes": tr_meas.get("train", {}).get("hbm_bytes_by_kernel", {}).get(kname)})
     kernels.sort(key=lambda k: -k["us"])
     dom = kernels[0]                               # the single longest kernel of the step (per-launch HIP events on the launch stream)
-    low = min((k_ for k_ in kernels if k_["gflop"] > 0), key=lambda k_: k_["frac"])      # ... and the one furthest below the roofline
+    low = min((k_ for k_ in kernels if k_["gflop"] > 0 and k_["us"] >= 50.0), key=lambda k_: k_["frac"])      # ... and, of the kernels of 50 us and more, the one furthest below the roofline
     wg_ms = sum(ms[i] for i in PG_WGRAD); wg_fl = sum(fl[i] for i in PG_WGRAD)
     total_flops, total_algo = sum(fl), sum(fl_algo)
     value = args.steps * world / dt
@@ -486,7 +486,7 @@ def run_train(args, rank, local, world):
                      # every heavy kernel of the step, longest first: us from HIP events around the launch (one stream), gflop = EXECUTED FLOPs,
                      # mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES fraction from the committed PMC pass (profiles/), hbm_bytes per launch likewise
                      "kernels": kernels[:8],
-                     # the kernel furthest below the matrix-core roofline (since round 5 the longest kernel is the fused post-net tile kernel; this one is not it)
+                     # the kernel (of those >= 50 us) furthest below the matrix-core roofline (since round 5 the longest kernel is the fused post-net tile kernel; this one is not it)
                      "lowest": {"name": low["name"], "us": low["us"], "frac": low["frac"], "mfma_busy": low["mfma_busy"]},
                      "wgrad_group": {"launches": 5, "ms": round(wg_ms, 4), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1) if wg_ms > 0 else None,
                                      "frac": round(wg_fl / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 3) if wg_ms > 0 else None},
