@@ -198,6 +198,8 @@ __device__ __forceinline__ void post_bwd_w_tile(const TrainParams& p, const Trai
     const float4* P2t = p.wp + p.p2t_f4; const float4* P1t = p.wp + p.p1t_f4; const float4* Wst = p.wp + p.wst_f4;
     const int NTL = LC / 16;
     if (!FUSED) { bq[0] = P2t[(size_t)nt0 * 64 + lane]; bq[1] = P2t[(size_t)(nt0 + 1) * 64 + lane]; }
+    const bool ps_on = blockIdx.x == 5 && blockIdx.y == 0; (void)ps_on;
+    POST_STAMP(1, 0);
     float mk[MT][4][2];
     auto mask_load = [&](const float* src) {                      // rows past the chunk end read the arena's padding rows (masked at the store)
 #pragma unroll
@@ -242,37 +244,49 @@ __device__ __forceinline__ void post_bwd_w_tile(const TrainParams& p, const Trai
 #define POSTW_ZERO(a) _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { a[mt][0] = (f32x4){0, 0, 0, 0}; a[mt][1] = (f32x4){0, 0, 0, 0}; }
     // ---------- dY0 = (dlogits . W2) * (Y0 > 0)
     POSTW_ZERO(acc);
+    POST_STAMP(1, 1);
     post_gemm<MT>(acc, T, lds, P2t, NTS, nt0, Q / 16, lane, bq, P1t + (size_t)nt0 * 64 + lane);
+    POST_STAMP(1, 2);
     TR_LDS_BARRIER();
     put(acc, true);
     if (FUSED) mbits = mS; else mask_load(p.S0);                  // (the Y0 signs are consumed: same registers)
     TR_LDS_BARRIER();
+    POST_STAMP(1, 3);
     rows_out(bw.DY0, S, 0);
+    POST_STAMP(1, 4);
     // ---------- dS0 = (dY0 . W1post) * (S0 > 0)
     POSTW_ZERO(acc);
     post_gemm<MT>(acc, T, lds, P1t, NTS, nt0, S / 16, lane, bq, Wst + (size_t)nt0 * 64 + lane);
+    POST_STAMP(1, 5);
     TR_LDS_BARRIER();
     put(acc, true);
     TR_LDS_BARRIER();
+    POST_STAMP(1, 6);
     rows_out(bw.DS0, S, 0);
-    // ---------- DGS[t][l*C + c] = sum_s dS0[t][s] Ws_l[s][c]: L*C columns in passes of 2 x 256 (both held in registers, then
-    //            written through T one after the other)
+    POST_STAMP(1, 7);
+    // ---------- DGS[t][l*C + c] = sum_s dS0[t][s] Ws_l[s][c]: L*C columns in passes of 2 x 256, both held in registers and stored from there (through the LDS tile,
+    //            one half after the other, the kernel's last 27 k cycles were two barrier-separated round trips with nothing to overlap them: 1460 -> 1465 steps/s)
     for (int cb = 0; cb < LC; cb += 512) {
         const int nta = cb / 16 + nt0, ntb = nta + NTS;
         const bool two = cb + 256 < LC;
         POSTW_ZERO(acc); POSTW_ZERO(acc2);
         post_gemm<MT>(acc, T, lds, Wst, NTL, nta, S / 16, lane, bq, Wst + (size_t)(two ? ntb : nta) * 64 + lane);
         if (two) post_gemm<MT>(acc2, T, lds, Wst, NTL, ntb, S / 16, lane, bq, Wst + (size_t)(cb + 512 < LC ? nta + 2 * NTS : nta) * 64 + lane);
-        TR_LDS_BARRIER();                                          // all reads of dS0 done (a later column pass would need it again: LC <= 512 here)
-        put(acc, false);
-        TR_LDS_BARRIER();
-        rows_out(bw.DGS, (size_t)LC, cb);
-        if (two) {
-            TR_LDS_BARRIER();
-            put(acc2, false);
-            TR_LDS_BARRIER();
-            rows_out(bw.DGS, (size_t)LC, cb + 256);
-        }
+        POST_STAMP(1, 8);
+        // the kernel's last outputs leave straight from the accumulators (nothing is left to overlap an LDS round trip with)
+        auto direct = [&](const f32x4 (&a)[MT][2], int col0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * mt + 4 * (lane >> 4) + i;
+                    if (t0 + r < p.BL) { float* d = bw.DGS + ((size_t)b * p.BL + t0 + r) * LC + col0; d[c0] = a[mt][0][i]; d[c1] = a[mt][1][i]; }
+                }
+        };
+        direct(acc, cb);
+        if (two) direct(acc2, cb + 256);
+        if (cb + 512 < LC) TR_LDS_BARRIER();
     }
 #undef POSTW_ZERO
+    POST_STAMP(1, 9);
 }

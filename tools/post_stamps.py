@@ -20,7 +20,9 @@ torch.cuda.synchronize()
 st = (C.c_uint * 1024)()
 _lib.check(_lib.lib().qpn_train_stack_stats(m._handle, st, 1024, None))
 names = ["start", "skip-sum done", "put+barrier", "rows_out S0 issued", "gemm P1 done", "put+barrier", "rows_out Y0 issued", "gemm P2 done", "put+barrier", "end (logits, CE)"]
-for slot, what in ((0, "k_post_fwd_w wg 5"), (1, "k_post_bwd_w wg 5")):
+names_b = ["start", "prologue (staging / masks; fused: none)", "gemm dY0 done", "put+barrier", "rows_out dY0 issued", "gemm dS0 done", "put+barrier", "rows_out dS0 issued", "gemms DGS done (2 x 256 columns)", "end (outputs stored from the accumulators)"]
+for slot, what in ((0, "forward tile, wg 5"), (1, "backward tile, wg 5")):
+    if slot == 1: names = names_b
     v = [st[600 + 16 * slot + i] for i in range(10)]
     if v[0] == 0 and v[9] == 0:
         continue
