@@ -141,33 +141,43 @@ __device__ __forceinline__ void post_fwd_w_tile(const TrainParams& p, float* sm,
         const int64_t rows = (int64_t)p.B * p.BL;
         const float inv = 1.0f / (float)rows;
         double lsum = 0.0;
+        // every row's logits (and the target's logit) are read first, THEN the ten rows' reductions run as independent chains (one row at a time, each chain -- two wave
+        // reductions, a logarithm, eight exponentials -- waited for the row before it: the LDS stores of one row and the loads of the next could not be reordered)
+        float lv[NCE][4], ltg[NCE];
+        int tgi[NCE];
 #pragma unroll
         for (int k = 0; k < NCE; ++k) {
             const int r = wave + 8 * k;
-            if (t0 + r >= p.BL) break;
             const float* lg = T + (size_t)r * lds;
-            const int64_t row = (int64_t)b * p.BL + t0 + r;
             int64_t tg = tgv[k];
-            if (tg < 0 || tg >= Q) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
+            if (t0 + r < p.BL && (tg < 0 || tg >= Q)) { if (lane == 0) atomicOr(p.status, 2); tg = tg < 0 ? 0 : Q - 1; }
+            tgi[k] = (int)tg;
+            const float2 v01 = *(const float2*)(lg + lane * 4), v23 = *(const float2*)(lg + lane * 4 + 2);
+            lv[k][0] = v01.x; lv[k][1] = v01.y; lv[k][2] = v23.x; lv[k][3] = v23.y;
+            ltg[k] = lg[tgi[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NCE; ++k) {
+            const int r = wave + 8 * k;
+            const bool in = t0 + r < p.BL;
+            const int64_t row = (int64_t)b * p.BL + t0 + r;
             const int q = lane * 4;
-            const float2 v01 = *(const float2*)(lg + q), v23 = *(const float2*)(lg + q + 2);
             // (the wave reductions are k_ce's: DPP inside the 16-lane rows + v_readlane across them, same order, bit-identical dL/dlogits; as six
             //  dependent ds_bpermute each they made the cross entropy 25 k of the tile's 232 k cycles: profiles/r05_post_fwd_stamps.txt)
-            const float m = tr_wave_max(fmaxf(fmaxf(v01.x, v01.y), fmaxf(v23.x, v23.y)));
-            const float se = tr_wave_sum((__expf(v01.x - m) + __expf(v01.y - m)) + (__expf(v23.x - m) + __expf(v23.y - m)));
+            const float m = tr_wave_max(fmaxf(fmaxf(lv[k][0], lv[k][1]), fmaxf(lv[k][2], lv[k][3])));
+            const float se = tr_wave_sum((__expf(lv[k][0] - m) + __expf(lv[k][1] - m)) + (__expf(lv[k][2] - m) + __expf(lv[k][3] - m)));
             const float lse = logf(se) + m;
-            if (p.ce_dlogits) {
-                float4 gq = make_float4(__expf(v01.x - lse), __expf(v01.y - lse), __expf(v23.x - lse), __expf(v23.y - lse));
-                const int dq = (int)tg - q;
+            if (p.ce_dlogits && in) {
+                float4 gq = make_float4(__expf(lv[k][0] - lse), __expf(lv[k][1] - lse), __expf(lv[k][2] - lse), __expf(lv[k][3] - lse));
+                const int dq = tgi[k] - q;
                 if (dq == 0) gq.x -= 1.0f; else if (dq == 1) gq.y -= 1.0f; else if (dq == 2) gq.z -= 1.0f; else if (dq == 3) gq.w -= 1.0f;
                 *(float4*)(p.ce_dlogits + (size_t)row * Q + q) = make_float4(gq.x * inv, gq.y * inv, gq.z * inv, gq.w * inv);
-                if (FUSED) {                                        // (behind the row's last read of the logits: lg[tg] below is taken first)
-                    lsum += (double)(lse - lg[tg]);
+                if (FUSED) {
                     float* dl = T + (size_t)r * lds + q;
                     *(float2*)dl = make_float2(gq.x * inv, gq.y * inv); *(float2*)(dl + 2) = make_float2(gq.z * inv, gq.w * inv);
                 }
             }
-            if (!FUSED || !p.ce_dlogits) lsum += (double)(lse - lg[tg]);
+            if (in) lsum += (double)(lse - ltg[k]);
         }
         if (FUSED) for (int r = wave; r < TM; r += 8) if (t0 + r >= p.BL) { float* dl = T + (size_t)r * lds + lane * 4; *(float2*)dl = make_float2(0.f, 0.f); *(float2*)(dl + 2) = make_float2(0.f, 0.f); }
         double* part = (double*)Gb;                               // the gate staging is dead
