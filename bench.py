@@ -241,8 +241,9 @@ def pg_kernel_names(hoist):
     """rocprofv3's kernel names of the launches behind each profile group (paper-size geometry; profiles/r05_train_kernel_stats.csv)."""
     ks = 8 if hoist else 11
     return {1: "k_stack_fwd<%d>" % ks, 2: "k_post_fwd_w<5>", 4: "k_post_bwd_w<5>", 5: "k_wgrad3<3, 2, %d, false, 1>" % ks, 6: "k_stack_bwd<%d>" % ks,
-            10: "k_wgrad3<2, 1, 4, false, 1>" if os.environ.get("QPN_STACK_QUEUE_BWD", "1") != "0" and os.environ.get("QPN_STACK_QUEUE", "1") != "0" else "k_wgrad3<2, 1, 4, true, 1>",     # (one A array behind the stack queue, which sums dXout's two parts in place)
-            11: "k_wgrad3<2, 4, 4, false, 2>", 12: "k_wgrad3<1, 4, 4, false, 2>", 13: "k_wgrad3<4, 1, 4, true, 1>"}
+            10: "k_wgrad3<0, 1, 4, false, 1>" if os.environ.get("QPN_STACK_QUEUE_BWD", "1") != "0" and os.environ.get("QPN_STACK_QUEUE", "1") != "0" else "k_wgrad3<0, 1, 4, true, 1>",     # (one A array behind the stack queue, which sums dXout's two parts in place)
+            11: "k_wgrad3<0, 4, 4, false, 2>",      # (B = the gate product p.TH)
+            12: "k_wgrad3<1, 4, 4, false, 2>", 13: "k_wgrad3<4, 1, 4, true, 1>"}
 
 
 def train_flops(cfg, N1, BL, starts_out, hoist):

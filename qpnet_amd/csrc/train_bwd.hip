@@ -257,8 +257,7 @@ __global__ __launch_bounds__(256) void k_layer_bwd(TrainParams p, TrainBwd bw, i
                 const int r = 16 * mt + 4 * (lane >> 4) + i, n = n0 + r;
                 const float dg = acc[mt][0][i] + Dg[(size_t)r * ldx + c];
                 const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-                const float dzs = dg * th * sg * (1.0f - sg);
-                const float dzt = dg * sg * (1.0f - th * th);
+                float dzs, dzt; tr_gate_bwd(dg, sg, th, dzs, dzt);      // (th: the gate product the Th tile holds)
                 if (n < p.N1) { DZg[(size_t)n * 2 * C + c] = dzs; DZg[(size_t)n * 2 * C + C + c] = dzt; }
                 Dz[(size_t)r * ldz + c] = dzs; Dz[(size_t)r * ldz + C + c] = dzt;
             }
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p(TrainParams p, TrainBwd 
             const int r = 4 * (lane >> 4) + i;
             const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
             const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-            dzs[i] = dg * th * sg * (1.0f - sg); dzt[i] = dg * sg * (1.0f - th * th);
+            tr_gate_bwd(dg, sg, th, dzs[i], dzt[i]);              // (th: the gate product the Th tile holds)
             Dz[(size_t)r * ldz + c] = dzs[i];
             Dz[(size_t)r * ldz + C + c] = dzt[i];
         }
@@ -1044,8 +1043,8 @@ static bool wgrad3_any(const Wg2& w, int nch, bool generic, hipStream_t stream) 
     if (generic) return false;
     switch (w.bmode) {
     case 3: return launch_wgrad3<3, 2, 11>(w, nch, stream) || launch_wgrad3<3, 2, 8>(w, nch, stream) || launch_wgrad3<3, 1, 7>(w, nch, stream);      // C = 64 (K = 176 / 128: aux at sample / frame rate), C = 32, n_aux 33..48
-    case 2: return launch_wgrad3<2, 1, 4>(w, nch, stream) || launch_wgrad3<2, 4, 4>(w, nch, stream);       // res / skip 1x1 at C = 64
-    case 1: return launch_wgrad3<1, 4, 4>(w, nch, stream);                                                  // post-net, 64-column groups
+    case 0: return launch_wgrad3<0, 1, 4>(w, nch, stream) || launch_wgrad3<0, 4, 4>(w, nch, stream);      // res / skip 1x1 at C = 64 (B = the gate product)
+    case 1: return launch_wgrad3<1, 4, 4>(w, nch, stream);                                                  // post-net (B rectified), 64-column groups
     default: return false;
     }
 }
@@ -1404,7 +1403,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
         {   // dWs_l = dS0^T g_l over the last BL rows; the shared skip-bias grad = colsum(dS0) (layer 0's block only)
             w.nlayers = L;
             w.A = bw.DS0; w.A2 = nullptr; w.A_lstride = 0; w.lda = S; w.M = S; w.rowsA = BL;
-            w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+            w.bmode = 0; w.B1 = p.TH; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;      // (p.TH: the gate product, as it is)
             w.ncol_groups = wgrad_col_groups(w.M, w.N);
             for (int l = 0; l < L; ++l) { w.row0A[l] = 0; w.row0B[l] = N1 - BL; w.R[l] = BL; w.goff[l] = sl.g_ws[l]; w.gbias[l] = l == 0 ? sl.g_bs : -1; w.tap_off[l] = -1; }
             ok = ok && wgrad2_any(w, nch_side_, gen, st);
@@ -1448,7 +1447,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
         Wg2 w = wbase;
         // (the stack queue's tiles have replaced the own-row part by the sum of both parts: store_dx in k_stack_bwd)
         w.A = bw.DXA[0] + nDX; w.A2 = wr_summed ? nullptr : bw.DXB[0] + nDX; w.A_lstride = nDX; w.lda = C; w.M = C; w.rowsA = N1;
-        w.bmode = 2; w.B1 = p.SG; w.B2 = p.TH; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;
+        w.bmode = 0; w.B1 = p.TH; w.B2 = nullptr; w.B_lstride = nDX; w.ldb = C; w.N = C; w.Nvalid = C; w.rowsB = N1; w.ldc = C;      // (p.TH: the gate product, as it is)
         w.nlayers = L; w.ncol_groups = wgrad_col_groups(w.M, w.N);
         for (int l = 0; l < L; ++l) {
             w.row0A[l] = w.row0B[l] = p.layers[l].s_out;

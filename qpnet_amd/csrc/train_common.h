@@ -426,6 +426,16 @@ __device__ __forceinline__ void wave_gemm_deep(f32x4 (&acc)[MT][NJ], const float
     wave_gemm_run<MT, NJ, PD>(acc, A_lds, lda, bq, Bp, NT, nts, K, lane);
 }
 
+// Gate backward from what the tile path's forward keeps: sigma (p.SG) and the gate PRODUCT g = sigma * tanh (p.TH -- the product is what the skip sum, the skip / residual
+// weight gradients and the residual 1x1 read, so they read ONE array; only this derivative wants tanh itself).  tanh = g / sigma; where sigma has underflowed to 0 the
+// product is 0 as well and both derivatives vanish.  dz_sigma = dg tanh sigma (1 - sigma) = dg g (1 - sigma);  dz_tanh = dg sigma (1 - tanh^2).
+// (the GEMM path of the wide stacks keeps sigma, tanh and the product: train_gemm.hip)
+__device__ __forceinline__ void tr_gate_bwd(float dg, float sg, float g, float& dzs, float& dzt) {
+    const float th = sg > 0.f ? g * __builtin_amdgcn_rcpf(sg) : 0.f;
+    dzs = dg * g * (1.0f - sg);
+    dzt = dg * sg * (1.0f - th * th);
+}
+
 // ---- wide post-net tiles (k_post_fwd_w / k_post_bwd_w): a wave owns two column tiles and 16 MT rows
 template <int MT>
 __device__ __forceinline__ void post_load_a(float (&x)[MT][4], const float* __restrict__ A, int lda, int ks, int arow, int ak) {

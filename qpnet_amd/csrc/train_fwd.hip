@@ -227,8 +227,9 @@ __device__ __forceinline__ void layer_fwd_tile(const TrainParams& p, const int l
                 const int r = 16 * mt + 4 * (lane >> 4) + i;
                 const float sg = sigmoidf_(acc[mt][0][i] + bs);
                 const float th = tanhf_(acc[mt][1][i] + bt);
-                Gs[(size_t)r * ldg + c] = sg * th;
-                if (n0 + r < p.N1) { SG[(size_t)(n0 + r) * C + c] = sg; TH[(size_t)(n0 + r) * C + c] = th; }
+                const float gg = sg * th;
+                Gs[(size_t)r * ldg + c] = gg;
+                if (n0 + r < p.N1) { SG[(size_t)(n0 + r) * C + c] = sg; TH[(size_t)(n0 + r) * C + c] = gg; }      // (p.TH holds the gate PRODUCT sigma * tanh: train_common.h)
             }
     }
     if (last) return;               // the last block's residual output is never used (qpnet.py:306-309)
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
         for (int i = 0; i < 4; ++i) {
             const int o = (4 * (lane >> 4) + i) * ldg + c;
             const float sg = sigmoidf_(a0[i] + bs), th = tanhf_(a1[i] + bt);
-            Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
+            Gs[o] = sg * th; SGs[o] = sg;
         }
         TR_LDS_BARRIER();
         if (!LAST) {                                              // the last block's residual output is never used (qpnet.py:306-309)
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
                 ar0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks][3], wr[ks].w, ar0, 0, 0, 0); ar1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[ks + 1][3], wr[ks + 1].w, ar1, 0, 0, 0);
             }
             store_out(SGs, SG, n0, true);                         // (under the residual contraction)
-            store_out(THs, TH, n0, true);
+            store_out(Gs, TH, n0, true);                          // the gate product (p.TH: train_common.h)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * (lane >> 4) + i;
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_p(TrainParams p, int l, in
             }
         } else {
             store_out(SGs, SG, n0, true);
-            store_out(THs, TH, n0, true);
+            store_out(Gs, TH, n0, true);                          // the gate product (p.TH: train_common.h)
         }
         // the next tile's rows have had a whole tile of matrix work to arrive: into the OTHER buffer (its last readers were
         // the previous trip's contractions, two barriers ago)
@@ -465,8 +466,7 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
             float2 g = make_float2(0.f, 0.f);
             if (t0 + r < p.BL) {
                 const size_t o = ((size_t)(l * p.B + b) * p.N1 + nbase + r) * C + k;
-                const float2 a = *(const float2*)(p.SG + o), t = *(const float2*)(p.TH + o);
-                g = make_float2(a.x * t.x, a.y * t.y);
+                g = *(const float2*)(p.TH + o);                     // (p.TH holds the gate product sigma * tanh: train_common.h)
             }
             *(float2*)(Gall + (size_t)r * ldall + kk) = g;
         }
@@ -511,9 +511,8 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
         // one exposed memory round trip per tile instead of one per layer
         constexpr int NG = (TM * 32 + 511) / 512;           // float2 pairs per thread for C <= 64 (more: second pass below)
         const int gper = TM * (C / 2);
-        float2 ga[NG], gt[NG];
+        float2 gt[NG];
         auto gfetch = [&](int l) {
-            const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
             const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
 #pragma unroll
             for (int k = 0; k < NG; ++k) {
@@ -521,8 +520,8 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
                 const int r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
                 const bool ok = idx < gper && t0 + r < p.BL;
                 const size_t o = ok ? (size_t)(nbase + r) * C + kk : 0;
-                const float2 a = *(const float2*)(SG + o), t = *(const float2*)(TH + o);
-                ga[k] = ok ? a : make_float2(0.f, 0.f); gt[k] = t;
+                const float2 t = *(const float2*)(TH + o);
+                gt[k] = ok ? t : make_float2(0.f, 0.f);
             }
         };
         const bool fits = gper <= NG * 512;
@@ -533,19 +532,14 @@ __global__ __launch_bounds__(512) void k_post_fwd(TrainParams p) {
 #pragma unroll
                 for (int k = 0; k < NG; ++k) {
                     const int idx = tid + k * 512;
-                    if (idx < gper) { const int r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2; *(float2*)(G + (size_t)r * ldg + kk) = make_float2(ga[k].x * gt[k].x, ga[k].y * gt[k].y); }
+                    if (idx < gper) { const int r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2; *(float2*)(G + (size_t)r * ldg + kk) = gt[k]; }
                 }
             } else {
-                const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
                 const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
                 for (int idx = tid; idx < gper; idx += 512) {
                     const int r = idx / (C / 2), k = (idx - r * (C / 2)) * 2;
                     float2 g = make_float2(0.f, 0.f);
-                    if (t0 + r < p.BL) {
-                        const float2 a = *(const float2*)(SG + (size_t)(nbase + r) * C + k);
-                        const float2 t = *(const float2*)(TH + (size_t)(nbase + r) * C + k);
-                        g = make_float2(a.x * t.x, a.y * t.y);
-                    }
+                    if (t0 + r < p.BL) g = *(const float2*)(TH + (size_t)(nbase + r) * C + k);
                     *(float2*)(G + (size_t)r * ldg + k) = g;
                 }
             }

@@ -38,24 +38,23 @@ __device__ __forceinline__ void post_fwd_w_tile(const TrainParams& p, float* sm,
                 bp20 = p.bp[p.bias_p2 + c0], bp21 = p.bp[p.bias_p2 + c1];
     const float4* Ws = p.wp + p.ws_f4; const float4* P1 = p.wp + p.p1_f4; const float4* P2 = p.wp + p.p2_f4;
     bq[0] = Ws[(size_t)nt0 * 64 + lane]; bq[1] = Ws[(size_t)(nt0 + 1) * 64 + lane];
-    // ---- gate rows of one layer: thread -> NG (row, column pair) items; sigma and tanh halves multiplied on the way into LDS
-    float2 ga[NG], gt[NG];
+    // ---- gate rows of one layer: thread -> NG (row, column pair) items of the layer's gate product (p.TH holds sigma * tanh: train_common.h)
+    float2 gt[NG];
     auto gfetch = [&](int l) {
-        const float* SG = p.SG + ((size_t)(l * p.B + b) * p.N1) * C;
         const float* TH = p.TH + ((size_t)(l * p.B + b) * p.N1) * C;
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
             const bool ok = idx < TM * (C / 2) && t0 + r < p.BL;
             const size_t o = ok ? (size_t)(nbase + r) * C + kk : 0;
-            ga[k] = *(const float2*)(SG + o); gt[k] = *(const float2*)(TH + o);
+            gt[k] = *(const float2*)(TH + o);
         }
     };
     auto gstore = [&](float* G) {
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
             const int idx = tid + k * 512, r = idx / (C / 2), kk = (idx - r * (C / 2)) * 2;
-            if (idx < TM * (C / 2)) *(float2*)(G + (size_t)r * ldg + kk) = t0 + r < p.BL ? make_float2(ga[k].x * gt[k].x, ga[k].y * gt[k].y) : make_float2(0.f, 0.f);
+            if (idx < TM * (C / 2)) *(float2*)(G + (size_t)r * ldg + kk) = t0 + r < p.BL ? gt[k] : make_float2(0.f, 0.f);
         }
     };
     // a finished stage: rectified outputs into T (in place: every wave has passed the barrier that ends the stage's reads) ...

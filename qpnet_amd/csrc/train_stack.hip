@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         for (int i = 0; i < 4; ++i) {
             const int o = (4 * (lane >> 4) + i) * ldg + c;
             const float sg = sq_sigmoid(a0[i] + bs), th = sq_tanh(a1[i] + bt);
-            Gs[o] = sg * th; SGs[o] = sg; THs[o] = th;
+            Gs[o] = sg * th; SGs[o] = sg;
         }
         SQ_STAMP(4);
         if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd(TrainParams p, StackQ q) {
         asm volatile("" ::: "memory");
 #if !(SQ_EXP & 64)
         store_out(SGs, SG, cur.n0);
-        store_out(THs, TH, cur.n0);
+        store_out(Gs, TH, cur.n0);                                 // the gate product (p.TH: train_common.h)
 #endif
         if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
         TR_LDS_BARRIER();                                          // B3
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_stack_bwd(TrainParams p, TrainBwd bw
             const int r = 4 * (lane >> 4) + i;
             const float dg = (a0[i] + a1[i]) + Dg[(size_t)r * ldx + c];
             const float sg = Sg[(size_t)r * ldx + c], th = Th[(size_t)r * ldx + c];
-            dzs[i] = dg * th * sg * (1.0f - sg); dzt[i] = dg * sg * (1.0f - th * th);
+            tr_gate_bwd(dg, sg, th, dzs[i], dzt[i]);              // (th: the gate product the Th tile holds)
             Dz[(size_t)r * ldz + c] = dzs[i];
             Dz[(size_t)r * ldz + C + c] = dzt[i];
         }

@@ -33,11 +33,12 @@ BUDGET = {
     "k_post_fwdILi1E": ("train_fwd.hip", 0, 5),
     "k_layer_bwdILi1E": ("train_bwd.hip", 0, 5),
     "k_wgrad3ILi1ELi4ELi4ELb0ELi2EE": ("train_bwd.hip", 0, 2),      # post-net weight gradients (both in one launch: 512 workgroups, two per CU)
-    "k_wgrad3ILi2ELi4ELi4ELb0ELi2EE": ("train_bwd.hip", 0, 2),      # skip 1x1
+    "k_wgrad3ILi0ELi4ELi4ELb0ELi2EE": ("train_bwd.hip", 0, 2),      # skip 1x1 (B = the gate product)
     "k_wgrad3ILi3ELi2ELi11ELb0ELi1EE": ("train_bwd.hip", 0, 2),     # dW1: 159 VGPRs + 88 accumulators, two workgroups per CU
     "k_wgrad3ILi3ELi2ELi8ELb0ELi1EE": ("train_bwd.hip", 0, 2),      # dW1 at K = 128 (aux 1x1 at frame rate)
     "k_aux_tail": ("train_bwd.hip", 0, 2),                             # 64 accumulator rows in registers at once, nothing in scratch
-    "k_wgrad3ILi2ELi1ELi4ELb1ELi1EE": ("train_bwd.hip", 0, 4),      # residual 1x1 (memory-bound: occupancy is what it lives on)
+    "k_wgrad3ILi0ELi1ELi4ELb0ELi1EE": ("train_bwd.hip", 0, 4),      # residual 1x1: one A array (dXout summed in place), one B array (the gate product); memory-bound: occupancy is what it lives on
+    "k_wgrad3ILi0ELi1ELi4ELb1ELi1EE": ("train_bwd.hip", 0, 4),      # ... with the two-part dXout of the per-layer backward launches
     "k_up_bwd": ("train_bwd.hip", 0, 2),                               # a row's 16 float4 words in registers at once, still nothing in scratch
     "k_gemm_nnILi0ELi1E": ("train_gemm.hip", 0, 3),
     "k_gemm_nnILi1ELi4E": ("train_gemm.hip", 0, 3),
