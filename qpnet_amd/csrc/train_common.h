@@ -41,7 +41,7 @@ struct TrainParams {
     float* bp;                // packed biases (hoist: k_aux_proj adds b_up * sum_a Va[n][a] to the gate biases)
     const int64_t* x; const float* h; const float* d;
     float* X;                 // [L+1][B][N1][C]
-    float* SG; float* TH;     // [L][B][N1][C]
+    float* SG; float* TH;     // [L][B][N1][C]: sigma, and -- on the tile path -- the gate PRODUCT sigma * tanh (tr_gate_bwd below; the GEMM path of the wide stacks keeps tanh here and the product in TrainGemm::G)
     float* HUP;               // [B][N1][Ap]
     // Auxiliary 1x1 at FRAME rate (hoist != 0; n_resch 64, upsampling_factor >= 16).  The upsampling deconvolution is rank 1
     // (h_up[a][U f + j] = h[a][f] w_up[j] + b_up, reference src/nets/qpnet.py:134-158), so the aux 1x1 of a gated block (qpnet.py:215-216,
