@@ -463,7 +463,7 @@ def run_train(args, rank, local, world):
                         "mfma_busy": pmc.get(kname), "hbm_bytes": tr_meas.get("train", {}).get("hbm_bytes_by_kernel", {}).get(kname)})
     kernels.sort(key=lambda k: -k["us"])
     dom = kernels[0]                               # the single longest kernel of the step (per-launch HIP events on the launch stream)
-    low = min((k_ for k_ in kernels if k_["gflop"] > 0 and k_["us"] >= 50.0), key=lambda k_: k_["frac"])      # ... and, of the kernels of 50 us and more, the one furthest below the roofline
+    low = min((k_ for k_ in kernels if k_["gflop"] > 0 and k_["us"] >= 50.0), key=lambda k_: k_["frac"], default=dom)      # ... and, of the kernels of 50 us and more, the one furthest below the roofline
     wg_ms = sum(ms[i] for i in PG_WGRAD); wg_fl = sum(fl[i] for i in PG_WGRAD)
     total_flops, total_algo = sum(fl), sum(fl_algo)
     value = args.steps * world / dt
