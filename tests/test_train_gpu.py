@@ -336,6 +336,49 @@ def test_wide_post_net_train_vs_oracle(geo, cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-5, a_rel=0.0)
 
 
+def test_backward_follows_flag_contract_over_the_c_abi(cuda):
+    """qpn_train_forward_loss(want_logits | QPN_FWD_BACKWARD_FOLLOWS): the post-net's backward may run inside the forward's launches -- and only a backward of THAT
+    dL/dlogits buffer, once, may use it.  Through the C ABI: (a) flag + the same buffer == no flag; (b) flag, then a backward with ANOTHER buffer (2 x dL/dlogits): the
+    gradient doubles, i.e. the separate kernel ran on what it was given; (c) a repeated backward of the same forward gives the same gradient again; (d) want_logits bit 0
+    still decides whether the logits are written."""
+    import ctypes as C
+    import torch
+    from qpnet_amd import _lib
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.train import ensure_flat
+    cfg = PAPER
+    m = util.build_model(cfg, synth.make_weights(cfg, 29), cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, 900, 78, 3900)
+    xt, ht, tt, dt = _to(cuda, x, h, t, d)
+    L, hd = m._native(cuda)
+    flat = ensure_flat(m, cuda)
+    B, T = xt.shape; BL = int(b[0]); Q = cfg.n_quantize
+    maxd = int(np.ceil(d).max())
+    stream = torch.cuda.current_stream(cuda).cuda_stream
+    args = (hd, flat.data_ptr(), B, T, ht.shape[2], dt.shape[1], BL, maxd, xt.data_ptr(), ht.data_ptr(), dt.data_ptr(), tt.data_ptr(), tt.shape[1])
+    lg = torch.full((B, BL, Q), 7.0, device=cuda)
+    dl = torch.empty((B, BL, Q), device=cuda)
+    n = flat.numel()
+    g_plain, g_flag, g_other, g_again = (torch.empty(n, device=cuda) for _ in range(4))
+    _lib.check(L.qpn_train_forward_loss(*args, lg.data_ptr(), 0, dl.data_ptr(), stream))
+    _lib.check(L.qpn_train_backward(hd, dl.data_ptr(), g_plain.data_ptr(), stream))
+    assert bool((lg == 7.0).all())                                        # bit 0 clear: the logits buffer is left alone
+    dl_ref = dl.clone()
+    _lib.check(L.qpn_train_forward_loss(*args, lg.data_ptr(), 2, dl.data_ptr(), stream))
+    assert torch.equal(dl, dl_ref) and bool((lg == 7.0).all())
+    _lib.check(L.qpn_train_backward(hd, dl.data_ptr(), g_flag.data_ptr(), stream))
+    _lib.check(L.qpn_train_backward(hd, dl.data_ptr(), g_again.data_ptr(), stream))          # (c)
+    _lib.check(L.qpn_train_forward_loss(*args, lg.data_ptr(), 3, dl.data_ptr(), stream))
+    assert not bool((lg == 7.0).any())                                    # (d) bit 0 set: logits written
+    dl2 = dl * 2.0
+    _lib.check(L.qpn_train_backward(hd, dl2.data_ptr(), g_other.data_ptr(), stream))         # (b)
+    _lib.check(L.qpn_train_status(hd, stream))
+    tol = 2e-6 * float(g_plain.abs().max())
+    assert float((g_flag - g_plain).abs().max()) <= tol
+    assert float((g_again - g_plain).abs().max()) <= tol
+    assert float((g_other - 2.0 * g_plain).abs().max()) <= 2 * tol
+
+
 def test_post_net_tile_kernel_fused_equals_separate(cuda, monkeypatch):
     """qpn_train_step runs the post-net's forward, the cross entropy and the backward of a row tile as ONE kernel (k_post_fb_w: dL/dlogits handed over in LDS, the ReLU
     masks as sign bits in registers); QPN_POST_FUSE=0 keeps k_post_fwd_w + k_post_bwd_w.  Same tile arithmetic: loss identical, gradients equal up to the float-atomics
