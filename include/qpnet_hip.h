@@ -134,8 +134,10 @@ int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad,
 
 /* Same with the data-parallel hooks of the one gradient exchange per step (replaces the reference's dead DataParallel wrapper,
  * src/bin/qpnet_train.py:416-423): the flat gradient is multiplied by grad_scale (the rank's row count B*BL) inside the
- * reduction kernel; with append_scale != 0, d_flatgrad must hold n_params + 4 floats and receives {grad_scale, 0, 0, 0} behind
- * the gradient, so ONE all-reduce(SUM) carries both sum_r n_r g_r and sum_r n_r. */
+ * reduction kernel; with append_scale != 0, d_flatgrad must hold n_params + 4 floats and receives {grad_scale, flagged, 0, 0} behind
+ * the gradient, so ONE all-reduce(SUM) carries sum_r n_r g_r, sum_r n_r and the number of ranks whose device-side status word is set
+ * (flagged = 1.0 then: qpn_adam_step_ex skips the update on EVERY rank).  append_scale = 1: the backward's last launch writes the flag (it then covers the
+ * backward's own status bits too); 2: the trailer leaves with the early exchange bucket (qpn_train_early_bucket) and carries the forward's bits only. */
 int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, float grad_scale, int append_scale, void* stream);
 
 /* Number of qpn_train_forward calls on this handle so far.  The activations backward needs live in the handle's workspace
@@ -195,10 +197,17 @@ int qpn_adam_step(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m,
                   int step, float lr, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* Same, reading the gradient as d_grad[i] / d_grad_denominator[0] (device scalar, e.g. the summed row count behind an
- * all-reduced gradient; NULL = 1): no host read-back and no extra elementwise launch in a data-parallel step. */
+ * all-reduced gradient; NULL = 1): no host read-back and no extra elementwise launch in a data-parallel step.  Non-NULL: d_grad_denominator[1] is the
+ * exchanged trailer's flag count (qpn_train_backward_ex): > 0 skips the update, as the handle's own status word does. */
 int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_grad, float* d_m, float* d_v, int64_t n,
                      int step, float lr, float beta1, float beta2, float eps, float weight_decay,
                      const float* d_grad_denominator, void* stream);
+
+/* Adam updates APPLIED on this handle so far, counted on the device: a k_adam launch that finds the sticky status word set -- or, behind a data-parallel
+ * exchange, a peer rank's flag in the trailer (d_grad_denominator[1] > 0) -- applies nothing (every rank skips a step ANY rank flagged; the others report
+ * "a peer rank flagged ..." with QPN_ERANGE).  Drains `stream`.  A caller that keeps the bias correction's step number on the host (the reference:
+ * torch.optim.Adam's state["step"], src/bin/qpnet_train.py:531) re-bases it on this count after a status error. */
+int qpn_train_applied_updates(qpn_handle* h, int64_t* applied, void* stream);
 
 /* One optimisation step of the reference's training loop (src/bin/qpnet_train.py:517-531: forward, CrossEntropyLoss, backward, Adam.step, loss.item())
  * behind ONE call: qpn_train_forward_loss + qpn_train_backward + qpn_adam_step and the loss / status bookkeeping, in that order, so that the host side of

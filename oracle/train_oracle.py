@@ -7,10 +7,27 @@ A from-scratch float32 restatement (time-major, hand-derived backward) of
   CE(mean) + Adam(lr 1e-4, betas .9/.999) ... reference src/bin/qpnet_train.py:426-430,526-531
 Pinned by tests/golden/train.npz (loss per step, grads of step 0 and final weights produced by
 the imported reference + torch autograd).  Never imported by the product package.
+
+`with precision(np.float64):` runs the SAME code with float64 arithmetic (weights, activations, contractions; the tap positions keep the
+reference's float32 rounding, which is part of the algorithm: qpnet.py:592-604) -- the yardstick tests/test_train_gpu.py measures both the
+float32 oracle and the GPU gradient against, so that the full-size tolerances are a measured multiple of fp32 reassociation error.
 """
+import contextlib
+
 import numpy as np
 
-f32 = np.float32
+f32 = np.float32            # the working precision (see precision())
+_idx32 = np.float32         # the tap arithmetic's precision: fixed by the reference
+
+
+@contextlib.contextmanager
+def precision(dtype):
+    global f32
+    old, f32 = f32, dtype
+    try:
+        yield
+    finally:
+        f32 = old
 
 
 def unpack(cfg, flat):
@@ -31,8 +48,8 @@ def _sigmoid(z):
 
 def dilated_index(d_tail, dil):
     L = d_tail.shape[0]
-    s = (-(d_tail.astype(f32)) * f32(dil)).astype(f32) + np.arange(-L, 0).astype(f32)
-    return np.rint(s.astype(f32)).astype(np.int64)          # negative index from the end of the layer input
+    s = (-(d_tail.astype(_idx32)) * _idx32(dil)).astype(_idx32) + np.arange(-L, 0).astype(_idx32)
+    return np.rint(s.astype(_idx32)).astype(np.int64)          # negative index from the end of the layer input
 
 
 def forward_row(cfg, W, x, h, d, BL, maxd):

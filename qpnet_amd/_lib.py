@@ -53,6 +53,7 @@ SYMBOLS = [
     ("qpn_adam_step_ex", _i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp, _vp]),
     ("qpn_train_step", _i, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
                             _i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, C.POINTER(C.c_double), C.POINTER(C.c_int), _vp]),
+    ("qpn_train_applied_updates", _i, [_vp, C.POINTER(C.c_int64), _vp]),
     ("qpn_train_stack_stats", _i, [_vp, C.POINTER(C.c_uint), _i, _vp]),
     ("qpn_train_early_bucket", _i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
     ("qpn_train_early_first", _i64, [_vp]),

@@ -1089,8 +1089,13 @@ static bool wgrad2_any(const Wg2& w, int nch, bool generic, hipStream_t stream) 
 // [s0, s1): the slab elements this launch reduces (the early range runs on the side stream under the layer backward); `tail`: this launch
 // also zeroes the unfed entries and appends the trailer
 __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __restrict__ gdst, const int* __restrict__ gdst_list, const int* __restrict__ gzero, int n_gzero,
-                                int nch, int gstage, int64_t n, float* __restrict__ g, float scale, int append_scale, int s0, int s1, int skip0, int skip1, int tail) {
+                                int nch, int gstage, int64_t n, float* __restrict__ g, float scale, int append_scale, int s0, int s1, int skip0, int skip1, int tail,
+                                const int* __restrict__ status, int flag_again) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + s0;
+    // trailer word 1 = "this rank's step is flagged" (the sticky status word, as a float): summed by the gradient exchange, so that EVERY rank's Adam kernel
+    // skips the update of a step one rank flagged (k_adam).  flag_again: the backward's LAST launch writes it once more -- the trailer itself may have been appended
+    // by the early launch on the side stream, before the stack backward could set its own bit -- unless the trailer has left with an early exchange bucket already
+    if (flag_again && append_scale && i == s0) g[n + 1] = (status && *status) ? 1.f : 0.f;
     if (i < s1) {
         if (i >= skip0 && i < skip1) return;                 // (already reduced by the early launch)
         const int k0 = gdst[i], k1 = gdst[i + 1];
@@ -1113,7 +1118,7 @@ __global__ void k_reduce_grad_s(const float* __restrict__ slab, const int* __res
     if (!tail) return;
     const int64_t j = i - s1;
     if (j < n_gzero) g[gzero[j]] = 0.f;
-    else if (append_scale && j < n_gzero + 4) g[n + (j - n_gzero)] = j == n_gzero ? scale : 0.f;
+    else if (append_scale && j < n_gzero + 4 && !(flag_again && j == n_gzero + 1)) g[n + (j - n_gzero)] = j == n_gzero ? scale : (j == n_gzero + 1 && status && *status) ? 1.f : 0.f;
 }
 
 // causal conv weight grad: dW[c][q][tap] = sum over rows whose sample == q; LDS table per channel block
@@ -1239,17 +1244,25 @@ __global__ __launch_bounds__(128) void k_aux_tail(AuxArgs p) {
 // the status word and, when asked for, the 64 partial sums of the loss (qpn_train_step)
 struct AdamReports { int* h_status; double* h_loss; const double* d_loss; };
 __global__ void k_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
-                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den, const int* __restrict__ status, AdamReports rep) {
+                       float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ den, int* __restrict__ status, AdamReports rep) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x == 0) {
-        if (rep.h_loss && threadIdx.x < 64) rep.h_loss[threadIdx.x] = rep.d_loss[threadIdx.x];
-        if (rep.h_status && threadIdx.x == 0) *rep.h_status = *status;
-    }
-    if (i >= n) return;
     // The device-side status word (sticky until the host reads it: a tap / target out of range, an abandoned stack launch) flags results that must not
     // reach the parameters: the update of a flagged step -- and of the steps enqueued behind it until the host has collected the word, two steps later
     // at most -- is skipped; weights and both moments stay what the last clean step left (the host raises; the caller may drop the chunk and go on).
-    if (status && *status) return;
+    // Data-parallel (den = the exchanged trailer {summed row count, summed flags}): a step ANY rank flagged is skipped by EVERY rank -- the replicas stay
+    // identical -- and a rank that was not flagged itself sets bit 8 of its own word, so that its host raises too.
+    const bool peer = den && den[1] > 0.f;
+    const bool skip = peer || (status && *status);
+    if (blockIdx.x == 0) {
+        if (rep.h_loss && threadIdx.x < 64) rep.h_loss[threadIdx.x] = rep.d_loss[threadIdx.x];
+        if (threadIdx.x == 0 && status) {
+            int st = *status;
+            if (peer && !st) { st = 8; atomicOr(status, 8); }
+            if (rep.h_status) *rep.h_status = st;
+            if (!skip) atomicAdd((unsigned long long*)(status + 2), 1ull);      // updates APPLIED on this handle (qpn_train_applied_updates)
+        }
+    }
+    if (i >= n || skip) return;
     float gi = g[i];
     if (den) gi = gi / den[0];                                  // data-parallel: summed row-weighted gradients / summed row count
     if (wd != 0.f) gi += wd * w[i];
@@ -1307,7 +1320,7 @@ static void launch_reduce_early(const TrainBwd& bw, hipStream_t st, int tail, in
     const TrainSlabs& sl = *bw.sl;
     const int64_t n = (int64_t)(sl.g_early1 - sl.g_early0) + (tail ? bw.n_gzero + 4 : 0);
     hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                       nch_side, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, sl.g_early0, sl.g_early1, 0, 0, tail);
+                       nch_side, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, sl.g_early0, sl.g_early1, 0, 0, tail, bw.status, 0);
 }
 static void launch_up_bwd(const TrainParams& p, const TrainBwd& bw, hipStream_t st) {
     const UpArgs u = up_args(p, bw);
@@ -1324,7 +1337,7 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom
     const int C = p.C, Q = p.Q, B = p.B, N1 = p.N1;
     const TrainSlabs& sl = *bw.sl;
     hipLaunchKernelGGL(k_reduce_grad_s, dim3((unsigned)(((int64_t)bw.gstage + (up_done ? 0 : bw.n_gzero + 4) + 255) / 256)), dim3(256), 0, stream, bw.slab, bw.gdst, bw.gdst_list, bw.gzero, bw.n_gzero,
-                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? sl.g_early0 : 0, early_done ? sl.g_early1 : 0, up_done ? 0 : 1);
+                       bw.nch, bw.gstage, bw.n_params, bw.gflat, bw.gscale, bw.append_scale, 0, bw.gstage, early_done ? sl.g_early0 : 0, early_done ? sl.g_early1 : 0, up_done ? 0 : 1, bw.status, bw.append_scale == 1 ? 1 : 0);
     {
         const int64_t total = (int64_t)B * N1;
         const int nwg = 128, rpw = (int)((total + nwg - 1) / nwg);
@@ -1536,7 +1549,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }
 
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status,
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, int* status,
                     int* h_status, double* h_loss, const double* d_loss, hipStream_t stream) {
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     AdamReports rep; rep.h_status = status ? h_status : nullptr; rep.h_loss = d_loss ? h_loss : nullptr; rep.d_loss = d_loss;

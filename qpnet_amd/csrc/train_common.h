@@ -99,7 +99,8 @@ struct TrainBwd {            // backward-only buffers / maps (see train_bwd.hip)
     int64_t n_params;
     const struct TrainSlabs* sl;      // HOST pointer (launchers only): slab offsets of every weight-grad block -- kept out of the kernel arguments (4 KB budget at 48 layers)
     float gscale;                     // the flat gradient is multiplied by this (data-parallel: the rank's row count)
-    int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, 0, 0, 0} (rides in the all-reduce)
+    int append_scale;                 // ... and gflat[n_params .. n_params+3] = {gscale, flagged ? 1 : 0, 0, 0} (rides in the all-reduce); 2: the trailer leaves with an early exchange bucket (never rewritten by the last launch)
+    const int* status;                // the handle's sticky status word (read for the trailer's flag)
     hipStream_t side; hipEvent_t ev_fork, ev_join, ev_mid;   // side stream of the weight gradients that run under the layer backward (owned by TrainState)
     hipEvent_t ev_early; int* early_recorded;                // recorded on the side stream behind the early reduction when it also wrote the trailer (qpn_train_early_bucket)
 };

@@ -13,7 +13,7 @@ int qpn_launch_ce(const float* logits, const int64_t* tgt, int64_t tgt_stride, i
 int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k, const AuxGeom& ag, const StackQ* sq, hipStream_t stream, bool post_done);
 int qpn_launch_fwd_gemm(const TrainParams& p, const TrainGemm& w, hipStream_t stream);
 int qpn_launch_bwd_gemm(const TrainParams& p, const TrainBwd& bw, const TrainGemm& w, hipStream_t stream);
-int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, const int* status,
+int qpn_launch_adam(float* w, const float* g, float* m, float* v, int64_t n, int step, float lr, float b1, float b2, float eps, float wd, const float* den, int* status,
                     int* h_status, double* h_loss, const double* d_loss, hipStream_t stream);
 
 
@@ -32,7 +32,8 @@ struct TrainState {
     // workspaces (grow only)
     float* d_ws; size_t ws_cap;               // one arena, carved per call
     int* d_tap; size_t tap_cap;
-    int* d_status; double* d_loss;
+    int* d_status; double* d_loss;            // d_status: 16 words -- [0] the sticky status word, [2..3] the count of Adam updates applied (k_adam)
+    hipStream_t last_stream;                  // the stream of the latest training call (where a collected status word is cleared)
     int* h_status_pinned; hipEvent_t ev_status[2]; bool status_pending[2]; int status_newest;      // qpn_train_status_enqueue / _collect: the deferred check, two slots
     double* h_loss_pinned; hipEvent_t ev_loss[2]; bool loss_pending[2]; int loss_newest;            // qpn_train_loss_enqueue / _collect: the loss read one step late, two slots of 64 partial sums
     bool fwd_valid;
@@ -340,6 +341,7 @@ static int train_init(qpn_handle* h) {
     QPN_HIP(hipMalloc(&t->d_bp, (size_t)t->n_bias * sizeof(float)));
     QPN_HIP(hipMalloc(&t->d_status, 64));
     QPN_HIP(hipMemset(t->d_status, 0, 64));
+    t->last_stream = nullptr;
     t->h_status_pinned = nullptr; t->ev_status[0] = t->ev_status[1] = nullptr; t->status_pending[0] = t->status_pending[1] = false; t->status_newest = 0;
     QPN_HIP(hipHostMalloc((void**)&t->h_status_pinned, 64, hipHostMallocDefault));
     t->h_loss_pinned = nullptr; t->ev_loss[0] = t->ev_loss[1] = nullptr; t->loss_pending[0] = t->loss_pending[1] = false; t->loss_newest = 0;
@@ -487,6 +489,7 @@ static int train_forward_impl(qpn_handle* h, const float* d_flat, int B, int64_t
     bw.EB = nullptr;
     if (t->hoist) { p.PA = carve(nPA); bw.DPA = carve(nPA + (size_t)L * TR_EB_SLOTS * 2 * C); bw.EB = bw.DPA + nPA; p.WJ = (float2*)carve(nWJ); bw.GW = carve(nGW); }
     p.TAP = t->d_tap; p.status = t->d_status;
+    t->last_stream = stream;
     {   // stack work queues (train_stack.hip): a flag word per (layer, batch item, 16-row tile) and direction, compared with a per-forward epoch
         // (zeroed only when (re)allocated), and the tile tables k_train_prep writes.  The regions keep their places for the life of an
         // allocation (sized for 1.5x the positions that forced it): a table word of an earlier step must never be read as a flag
@@ -609,7 +612,8 @@ extern "C" int qpn_train_status(qpn_handle* h, void* stream_) {
     QPN_HIP(hipStreamSynchronize((hipStream_t)stream_));
     int st = 0;
     QPN_HIP(hipMemcpy(&st, h->train->d_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (st) QPN_HIP(hipMemset(h->train->d_status, 0, sizeof(int)));          // sticky until read: reported once
+    if (st) QPN_HIP(hipMemsetAsync(h->train->d_status, 0, sizeof(int), (hipStream_t)stream_));          // sticky until read: reported once
+    h->train->last_stream = (hipStream_t)stream_;
     if (st & 4) h->train->stack_disabled = true;
     h->train->status_pending[0] = h->train->status_pending[1] = false;
     return status_to_rc(st);
@@ -619,6 +623,7 @@ static int status_to_rc(int st) {
     if (st & 1) { qpn_set_error("pitch-dependent tap outside the layer input (dilated factor > maxd or < 0; reference assert qpnet.py:294)"); return QPN_ERANGE; }
     if (st & 4) { qpn_set_error("the one-launch residual stack gave up waiting for a peer workgroup: the flagged step's results are invalid (its Adam update, and that of the steps enqueued behind it until this report, were skipped on the device: parameters and moments are those of the last clean step); the handle runs a launch per layer from here on (QPN_STACK_QUEUE=0 selects that from the start)"); return QPN_ENODEV; }
     if (st & 2) { qpn_set_error("target class outside [0, n_quantize) (reference assert qpnet_train.py:525)"); return QPN_ERANGE; }
+    if (st & 8) { qpn_set_error("a peer rank flagged its chunk of this data-parallel step (a tap or target out of range, or an abandoned stack launch there): every rank skipped the update, the replicas are unchanged"); return QPN_ERANGE; }
     return QPN_OK;
 }
 
@@ -633,7 +638,10 @@ static int status_collect_slot(TrainState* t, int slot) {
     const int st = t->h_status_pinned[slot];
     if (st & 4) t->stack_disabled = true;
     if (st) {
-        QPN_HIP(hipMemset(t->d_status, 0, sizeof(int)));              // sticky until read: reported once ...
+        // sticky until read: reported once.  Cleared ON the stream the training calls run on, i.e. behind every step enqueued so far (their Adam kernels all see
+        // the word set and skip) and in front of the next one -- a null-stream memset is not ordered against a non-blocking stream and could land in the middle
+        // of a k_adam launch, whose blocks each read the word
+        QPN_HIP(hipMemsetAsync(t->d_status, 0, sizeof(int), t->last_stream));
         const int other = slot ^ 1;                                   // ... also where the other slot copied the same sticky bits before this clear
         if (t->status_pending[other]) {
             QPN_HIP(hipEventSynchronize(t->ev_status[other]));
@@ -648,6 +656,7 @@ extern "C" int qpn_train_status_enqueue(qpn_handle* h, void* stream_) {
     if (!h->train) { qpn_set_error("no training call yet"); return QPN_ESTATE; }
     TrainState* t = h->train;
     const int slot = t->status_newest ^ 1;
+    t->last_stream = (hipStream_t)stream_;
     rc = status_collect_slot(t, slot); if (rc) return rc;            // (two enqueues old: long done)
     QPN_HIP(hipMemcpyAsync(t->h_status_pinned + slot, t->d_status, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     QPN_HIP(hipEventRecord(t->ev_status[slot], (hipStream_t)stream_));
@@ -709,6 +718,34 @@ extern "C" int qpn_train_stack_stats(qpn_handle* h, unsigned* h_out, int n, void
     return QPN_OK;
 }
 
+// Adam updates APPLIED on this handle so far (k_adam counts on the device: a launch that found the status word set -- its own rank's or, data-parallel, a peer's --
+// applies nothing).  Drains `stream`.  A caller that counts steps on the host (the bias correction's step number) re-bases its count on this after a status error.
+extern "C" int qpn_train_applied_updates(qpn_handle* h, int64_t* applied, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!applied) { qpn_set_error("bad applied_updates arguments"); return QPN_EINVAL; }
+    *applied = 0;
+    if (!h->train) return QPN_OK;
+    QPN_HIP(hipStreamSynchronize((hipStream_t)stream_));
+    unsigned long long v = 0;
+    QPN_HIP(hipMemcpy(&v, h->train->d_status + 2, sizeof(v), hipMemcpyDeviceToHost));
+    *applied = (int64_t)v;
+    return QPN_OK;
+}
+
+#ifdef QPN_TESTING
+// test hook (a -DQPN_TESTING build only; tests/f64_child.py): the rectified post-net activations relu(s0), relu(y0) of the last forward ([B][BL][S] floats each) --
+// their signs are the ReLU sides this forward took, which a float64 yardstick of the gradient must be given (a unit within rounding of zero falls on either side)
+extern "C" int qpn_test_postnet_activations(qpn_handle* h, float* d_s0, float* d_y0, int64_t n, void* stream_) {
+    int rc = need_dev(h); if (rc) return rc;
+    if (!h->train || !h->train->fwd_valid || !d_s0 || !d_y0) { qpn_set_error("no forward to read"); return QPN_ESTATE; }
+    const TrainParams& p = h->train->tp;
+    if (n != (int64_t)p.B * p.BL * p.S) { qpn_set_error("postnet_activations: n != B * BL * S"); return QPN_EINVAL; }
+    QPN_HIP(hipMemcpyAsync(d_s0, p.S0, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    QPN_HIP(hipMemcpyAsync(d_y0, p.Y0, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream_));
+    return QPN_OK;
+}
+#endif
+
 extern "C" int64_t qpn_train_generation(qpn_handle* h) { return (h && h->train) ? h->train->generation : 0; }
 
 extern "C" int qpn_train_backward(qpn_handle* h, const float* d_dlogits, float* d_flatgrad, void* stream_) {
@@ -722,7 +759,7 @@ extern "C" int qpn_train_backward_ex(qpn_handle* h, const float* d_dlogits, floa
     TrainState* t = h->train;
     TrainBwd& bw = t->bw;
     bw.dlogits = d_dlogits; bw.gflat = d_flatgrad; bw.gdst = t->d_gdst; bw.gdst_list = t->d_gdst_list; bw.gzero = t->d_gzero; bw.n_gzero = t->n_gzero;
-    bw.gscale = grad_scale; bw.append_scale = append_scale;
+    bw.gscale = grad_scale; bw.append_scale = append_scale; bw.status = h->train->d_status;
     bw.side = t->side; bw.ev_fork = t->ev_fork; bw.ev_join = t->ev_join; bw.ev_mid = t->ev_mid;
     t->early_recorded = 0; bw.ev_early = t->ev_early; bw.early_recorded = (append_scale && t->early_first >= 0) ? &t->early_recorded : nullptr;
     // (the backward queue's heads and flags belong to ONE backward per forward: a repeated backward of the same forward runs a launch per layer)
@@ -759,6 +796,7 @@ extern "C" int qpn_adam_step_ex(qpn_handle* h, float* d_flat, const float* d_gra
                                 const float* d_grad_denominator, void* stream_) {
     int rc = need_dev(h); if (rc) return rc;
     if (!d_flat || !d_grad || !d_m || !d_v || n < 1 || step < 1) { qpn_set_error("bad adam_step arguments"); return QPN_EINVAL; }
+    if (h->train) h->train->last_stream = (hipStream_t)stream_;
     return qpn_launch_adam(d_flat, d_grad, d_m, d_v, n, step, lr, beta1, beta2, eps, weight_decay, d_grad_denominator, h->train ? h->train->d_status : nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream_);
 }
 

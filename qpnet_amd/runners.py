@@ -122,7 +122,7 @@ class PinnedStager:
         ev.record(cs if cs is not None else torch.cuda.current_stream(self.device))
         self.events[k] = ev
         if cs is not None:
-            # whoever consumes the batch joins the copy: FusedTrainer.step / QPNet.forward look at their FIRST input (train.join_staged)
+            # whoever consumes the batch joins the copy: FusedTrainer.step / forward_loss and QPNet.forward look at ALL their inputs (train.join_staged)
             for t in out.values():
                 t.__dict__["_qpn_staged"] = (ev, dbuf)
         self.i = (self.i + 1) % self.depth

@@ -108,10 +108,15 @@ def _adam_bind_state(opt, a, ps):
 
 
 def _adam_release(opt, a, ps):
-    """hand the state back to torch's own implementation (fused=True wants a step counter per parameter, on the device)."""
+    """hand the state back to torch's own implementation (fused=True wants a step counter per parameter, on the device).  Only state the hooks themselves
+    own is rewritten -- entries whose step counter IS the adopter's shared host scalar.  A state that `load_state_dict()` has put in their place (a rollback to
+    an earlier checkpoint, or an empty state) is left exactly as loaded: its own step counts drive the bias correction from here on, and the next step adopts
+    it afresh (the adopter's old count used to overwrite the loaded one, and an empty loaded state got a lone 'step' key)."""
     if a.steps > 0:
         for p in ps:
-            opt.state[p]["step"] = torch.tensor(float(a.steps), dtype=torch.float32, device=p.device)
+            st = opt.state.get(p)                         # (.get: the state is a defaultdict -- indexing would create an entry)
+            if st and st.get("step") is a.step_t:
+                st["step"] = torch.tensor(float(a.steps), dtype=torch.float32, device=p.device)
     opt.__dict__["_qpn_adopt"] = None                     # looked at again at the next step
 
 
@@ -223,16 +228,23 @@ _register_optimizer_step_pre_hook(_adam_prehook)
 _register_optimizer_step_post_hook(_adam_posthook)
 
 
-def join_staged(x, dev):
+def join_staged(x, dev, *more):
     """Inputs copied to the device on a stream of their own (runners.PinnedStager: the copy must not sit between the step's kernels on the compute stream) carry
     {ready event, device buffer}: the consumer's stream waits for the copy -- long done when a prefetch thread is ahead, so the wait is a queue packet, not a
     stall -- and the buffer is marked as used on that stream (the caching allocator will not hand it out again before the step that reads it has run)."""
-    st = x.__dict__.get("_qpn_staged") if isinstance(x, torch.Tensor) else None
-    if st is not None:
-        cur = torch.cuda.current_stream(dev)
-        cur.wait_event(st[0])
-        st[1].record_stream(cur)
-        del x.__dict__["_qpn_staged"]                  # (once per batch)
+    Every consumer of loader batches calls this on ALL its inputs (FusedTrainer.step / forward_loss, QPNet.forward): a tensor that never
+    went through a stager costs one dictionary look-up."""
+    done = None
+    for t in (x,) + more:
+        st = t.__dict__.get("_qpn_staged") if isinstance(t, torch.Tensor) else None
+        if st is None:
+            continue
+        if st[0] is not done:                          # (the tensors of one batch share one copy: one wait, one record_stream)
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(st[0])
+            st[1].record_stream(cur)
+            done = st[0]
+        del t.__dict__["_qpn_staged"]                  # (once per batch)
 
 
 def model_params(model):
@@ -254,22 +266,31 @@ def ensure_flat(model, dev):
     flat = getattr(model, "_flat", None)
     ok = flat is not None and flat.device == dev
     if ok:
-        # 120 data_ptr() calls cost ~60 us of interpreter time per step: the full walk runs when the parameter list was rebuilt and every 64th call,
-        # the first and the last view are looked at every time (.to() / .cuda() / load into new storage replace ALL of them)
+        # 120 data_ptr() calls cost ~60 us of interpreter time per step: the full walk runs when the parameter list was rebuilt and every 32nd call; every
+        # call looks at the first and the last view (.to() / .cuda() / load into new storage replace ALL of them) and at FOUR more in rotation, with their
+        # dtype -- a single interior `p.data = ...` (pruning, re-parametrisation, a partial load with assign=True) is seen within 30 calls at the latest
         c = model.__dict__.get("_qpn_flat_chk")
         base = flat.data_ptr()
-        if c is not None and c[0] is params and c[1] < 64:
+        if c is not None and c[0] is params and c[1] < 32:
             c[1] += 1
             last = params[-1]
-            ok = params[0].data_ptr() == base and last.data_ptr() == base + 4 * (flat.numel() - last.numel())
+            ok = params[0].data_ptr() == base and last.data_ptr() == base + 4 * (flat.numel() - last.numel()) and last.dtype == torch.float32
+            offs, k, n = c[2], c[3], len(params)
+            for _ in range(4):
+                k = k + 1 if k + 1 < n else 0
+                q = params[k]
+                if q.data_ptr() != base + 4 * offs[k] or q.dtype != torch.float32:
+                    ok = False
+            c[3] = k
         else:
-            o = 0
+            o, offs = 0, []
             for p in params:
                 if p.data_ptr() != base + 4 * o or p.dtype != torch.float32:
                     ok = False
                     break
+                offs.append(o)
                 o += p.numel()
-            model.__dict__["_qpn_flat_chk"] = [params, 0]
+            model.__dict__["_qpn_flat_chk"] = [params, 0, offs, 0] if ok else None
     if not ok:
         flat = torch.cat([p.detach().reshape(-1).to(dev, torch.float32) for p in params]).contiguous()
         o = 0
@@ -437,7 +458,7 @@ def qpnet_forward(model, x, h, dilated_factors, blength):
     bl_host = blength.tolist() if hasattr(blength, "tolist") else list(blength)
     assert all(v == bl_host[0] for v in bl_host)
     BL = int(bl_host[0])
-    join_staged(x, dev)
+    join_staged(x, dev, h, dilated_factors)
     maxd = forward_maxd(model, x.shape[1], h.shape[2], dilated_factors.shape[1], BL, dilated_factors)
     x = x.to(dev, torch.int64).contiguous()
     h = h.to(dev, torch.float32).contiguous()
@@ -585,6 +606,7 @@ class FusedTrainer:
         self.pg, self.world = process_group, world_size
         self._logits = None
         self.last_buckets = (0, 0)
+        self._applied_base = None     # (step_count, the handle's applied-update count) at this trainer's first step / after a re-base (see _rebase_step_count)
         self._early = None            # the stream the early bucket of the gradient exchange runs on (world_size > 1)
         self._two_buckets = None      # agreed over the process group at the first data-parallel step (every rank must issue the same collectives)
 
@@ -612,7 +634,7 @@ class FusedTrainer:
         L, hd = model._native(dev)
         flat = ensure_flat(model, dev)
         self._buffers(flat)
-        join_staged(x, dev)
+        join_staged(x, dev, h, t, d)
         x = self._norm(x, torch.int64, dev); t = self._norm(t, torch.int64, dev)
         h = self._norm(h, torch.float32, dev); d = self._norm(d, torch.float32, dev)
         assert x.dim() == 2 and t.shape[0] == x.shape[0] and h.dim() == 3 and h.shape[1] == model.n_aux and d.dim() == 2
@@ -626,6 +648,11 @@ class FusedTrainer:
         stream = torch.cuda.current_stream(dev).cuda_stream
         loss = C.c_double(0.0)
         multi = self.world > 1
+        if self._applied_base is None and not torch.cuda.is_current_stream_capturing():
+            n = C.c_int64(0)
+            with torch.cuda.device(dev):
+                _lib.check(L.qpn_train_applied_updates(hd, C.byref(n), stream))      # (once per trainer: drains the stream before its first step)
+            self._applied_base = (self.step_count, int(n.value))
         # (a step being captured into a hipGraph -- torch.cuda.graph -- may not wait for events or read anything back: no status bookkeeping, the
         #  caller checks with check_status() outside the graph; the library runs the stack as a launch per layer while a stream is capturing)
         capturing = torch.cuda.is_current_stream_capturing()
@@ -641,9 +668,29 @@ class FusedTrainer:
                                       self.m.data_ptr(), self.v.data_ptr(), flat.numel(), self.step_count, self.lr, self.betas[0], self.betas[1],
                                       self.eps, self.wd, mode, C.byref(loss), C.byref(valid), stream)
             if rc:
-                self.step_count -= 1                 # (nothing was applied: an argument error, or an earlier step's device-side status raised before this one started)
-                _lib.check(rc)
+                self._rebase_step_count(L, hd, dev, stream, rc)
             return loss.value if valid.value else None
+        try:
+            return self._step_calls(L, hd, dev, flat, stream, x, h, t, d, B, T, BL, maxd, want_loss, multi, capturing, loss)
+        except _lib.QpnError as e:
+            if e.code in (-4, -2):                     # (QPN_ERANGE / QPN_ENODEV: what the device-side status word raises)
+                self._rebase_step_count(L, hd, dev, stream, 0)
+            raise
+
+    def _rebase_step_count(self, L, hd, dev, stream, rc):
+        """A device-side status error: the Adam kernel skipped the flagged step's update and that of every step enqueued behind it until the host collected the
+        word (k_adam), so the host's step count -- the bias correction's exponent, and what checkpoints store -- has run ahead of the updates applied.  It is set back
+        to (count at the base) + (updates the device applied since): one stream drain, on the error path only.  rc != 0: raise it afterwards."""
+        msg = L.qpn_last_error()                       # (the call below would replace it)
+        if self._applied_base is not None:
+            n = C.c_int64(0)
+            with torch.cuda.device(dev):
+                if L.qpn_train_applied_updates(hd, C.byref(n), stream) == 0:
+                    self.step_count = self._applied_base[0] + int(n.value) - self._applied_base[1]
+        if rc:
+            raise _lib.QpnError(rc, msg.decode("utf-8", "replace"))
+
+    def _step_calls(self, L, hd, dev, flat, stream, x, h, t, d, B, T, BL, maxd, want_loss, multi, capturing, loss):
         with torch.cuda.device(dev):
             if not capturing:
                 _lib.check(L.qpn_train_status_collect_lagged(hd))   # the check of the step before the previous one (never waits for queued work)
@@ -652,9 +699,6 @@ class FusedTrainer:
                                                 x.data_ptr(), h.data_ptr(), d.data_ptr(), t.data_ptr(), t.shape[1],
                                                 self._logits.data_ptr(), 2, self._dlogits.data_ptr(), stream))      # (2: the backward of this forward follows, same dL/dlogits)
             if multi:
-                # g <- n_r * grad_r with n_r appended; SUM over ranks; Adam divides by the summed row count on the device
-                _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 1, stream))
-                # two buckets: the tail the side stream has finished already can go out under the layer backward (qpn_train_early_bucket)
                 from .parallel import exchange_two_buckets
                 first, count = C.c_int64(0), C.c_int64(0)
                 if self._early is None:
@@ -667,6 +711,10 @@ class FusedTrainer:
                     # minimum over the ranks of "this rank wants and can do two buckets"; thereafter every rank issues two all-reduces over the SAME
                     # ranges in every step, whether or not its early range happened to be ready early in that step.
                     self._two_buckets = self._agree_two_buckets(L, hd, flat)
+                # g <- n_r * grad_r with {n_r, flagged_r} appended; SUM over ranks; Adam divides by the summed row count on the device and skips the update on
+                # EVERY rank when any rank's status word was set (2: the trailer leaves with the early bucket, before the backward's last launch could rewrite it)
+                _lib.check(L.qpn_train_backward_ex(hd, self._dlogits.data_ptr(), self.g.data_ptr(), float(B * BL), 2 if self._two_buckets else 1, stream))
+                # two buckets: the tail the side stream has finished already can go out under the layer backward (qpn_train_early_bucket)
                 if self._two_buckets:
                     _lib.check(L.qpn_train_early_bucket(hd, C.byref(first), C.byref(count), self._early.cuda_stream))
                     if count.value == 0:      # nothing was finished early in this step (one stream: a profile is being taken): same two ranges, after the backward
@@ -716,8 +764,16 @@ class FusedTrainer:
         return loss.value if valid.value else None
 
     def check_status(self):
-        """Raise what the device-side check of the last step(want_loss=False) found (see QPNet.check_status)."""
-        self.model.check_status()
+        """Raise what the device-side check of the last step(want_loss=False) found (see QPNet.check_status); the step count is set back to the
+        updates the device actually applied (_rebase_step_count)."""
+        try:
+            self.model.check_status()
+        except _lib.QpnError as e:
+            flat = getattr(self.model, "_flat", None)
+            if e.code in (-4, -2) and flat is not None and flat.is_cuda:
+                L, hd = self.model._native(flat.device)
+                self._rebase_step_count(L, hd, flat.device, torch.cuda.current_stream(flat.device).cuda_stream, 0)
+            raise
 
     def forward_loss(self, x, h, t, d, blength, maxd=None):
         """forward + mean CE only (validation, reference qpnet_validate.py:409-430)."""
@@ -725,6 +781,7 @@ class FusedTrainer:
         dev = x.device
         L, hd = model._native(dev)
         flat = ensure_flat(model, dev)
+        join_staged(x, dev, h, t, d)                 # (run_validate feeds staged batches: the copy stream must be joined before anything reads them)
         x = self._norm(x, torch.int64, dev); t = self._norm(t, torch.int64, dev)
         h = self._norm(h, torch.float32, dev); d = self._norm(d, torch.float32, dev)
         BL = int(blength[0])

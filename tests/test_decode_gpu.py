@@ -155,6 +155,40 @@ def test_full_size_decode_properties(cuda, oracle):
         np.testing.assert_array_equal(ys[i], refs[i], err_msg="full 10 s stream of row %d vs the oracle" % i)
 
 
+def test_headline_decode_batch_rows_full_length_vs_oracle(cuda, oracle):
+    """the batch bench.py's `decode` object times -- BASELINE config[3], 20 utterances x 2005 frames (220 549 samples each, the reference's
+    decode_batch_size, runQP.py:66; the same feature seeds 100..119) through the five-role pipelined kernel, 20 groups resident at once -- with rows 0, 7, 13 and
+    19 compared with the C oracle over their FULL length, bit for bit (reference src/nets/qpnet.py:446-557), every row's range and length checked, and
+    the launch repeated once (identical streams)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda)
+    F, B = 2005, 20
+    utts = [(100 + b, F, 1.0) for b in range(B)]
+    x, h, d, ns = synth.decode_batch(cfg, utts)
+    xt, ht = torch.from_numpy(x).to(cuda), torch.from_numpy(h).to(cuda)
+    ys = m.batch_fast_generate(xt, ht, list(ns), d, mode="argmax")
+    assert "pipe" in getattr(m, "last_decode_plan", "pipe")
+    assert [len(y) for y in ys] == [F * cfg.upsampling_factor - 1] * B
+    assert all(y.min() >= 0 and y.max() < cfg.n_quantize for y in ys)
+    maxd = int(np.nanmax(np.ceil(d)))                       # the batch's receptive field (reference qpnet.py:347-350)
+    rows = (0, 7, 13, 19)
+
+    def full(i):
+        xs, hs, ds, n = synth.decode_inputs(cfg, F, utts[i][0], 1.0)
+        return oracle.decode(cfg, flat, hs, ds, xs, n, maxd=maxd)["samples"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        refs = list(ex.map(full, rows))
+    for i, ref in zip(rows, refs):                          # (equal lengths: completion order = input order)
+        np.testing.assert_array_equal(ys[i], ref, err_msg="full 10 s stream of row %d of the 20-row batch vs the oracle" % i)
+    ys2 = m.batch_fast_generate(xt, ht, list(ns), d, mode="argmax")
+    for a, b2 in zip(ys, ys2):
+        np.testing.assert_array_equal(a, b2)
+
+
 @pytest.mark.parametrize("geo", [(128, 128, 2, 1, 2, 1), (96, 256, 2, 1, 1, 1), (64, 128, 3, 2, 2, 1)], ids=["C128", "C96", "F3x2"])
 def test_other_geometries_bitwise_vs_oracle(geo, cuda, oracle):
     """Depth/repeat/width combinations outside the BASELINE configs (the repo default uses repeat 3): interpreter kernel for

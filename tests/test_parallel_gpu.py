@@ -150,3 +150,61 @@ def test_two_ranks_on_one_gpu_equal_union_batch_oracle(cfgname, buckets, cuda, t
     #  the kernels sum their partial slabs shows at the 1e-6 level -- one element of 504 495 at 2.09e-6 with 48 instead of 64 slabs;
     #  north_star's tolerance, 1e-4 on the losses, is the assert above)
     np.testing.assert_allclose(r0["w"], flat, atol=4e-6, rtol=0)
+
+
+_FLAG_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+rank = int(sys.argv[1]); world = int(sys.argv[2]); out = sys.argv[3]
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from qpnet_amd import synth, parallel, _lib
+from qpnet_amd.config import TINY
+from qpnet_amd.train import FusedTrainer, ensure_flat
+import util
+cfg = TINY
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+m = util.build_model(cfg, synth.make_weights(cfg, 3), dev).train()
+parallel.broadcast_parameters(ensure_flat(m, dev), 0)
+tr = FusedTrainer(m, lr=1e-3, world_size=world)
+ws, codes, msgs = [], [], []
+for step in range(3):
+    x, h, t, d, b = synth.train_inputs(cfg, 300 + 40 * rank, 900 + 2 * step + rank, 30000)
+    if step == 1 and rank == 1:
+        t = t.copy(); t[0, -7] = cfg.n_quantize + 5                      # rank 1's chunk of step 1 is bad; rank 0's is clean
+    xs = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, h, t, d, b)]
+    try:
+        tr.step(*xs)                                                     # (want_loss=True: the status is read in the step, like the reference's asserts)
+        codes.append(0); msgs.append("")
+    except _lib.QpnError as e:
+        codes.append(e.code); msgs.append(str(e))
+    ws.append(m.flat_parameters().cpu().numpy().copy())
+np.savez(out, w=np.stack(ws), codes=np.array(codes), steps=np.array([tr.step_count]), peer=np.array(["peer rank" in s for s in msgs]))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_a_step_flagged_on_one_rank_is_skipped_by_every_rank(cuda, tmp_path):
+    """the Adam kernel skips a step whose device-side status word is set -- but on the flagged rank only, while its peers applied the summed
+    gradient: the replicas diverged.  The flag now rides in the exchanged trailer (word 1, summed like the row count), every rank's Adam kernel skips the
+    step, the flagged rank raises its own error and the others "a peer rank flagged ...": weights bit-identical across the ranks after every step, unchanged
+    by the flagged one, the step counts set back to the two updates applied."""
+    port = 29500 + (os.getpid() + 11) % 2000
+    script = tmp_path / "flag.py"
+    script.write_text(_FLAG_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = [str(tmp_path / ("f%d.npz" % r)) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", outs[r]], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=420) == 0
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    np.testing.assert_array_equal(r0["w"], r1["w"])                              # after every step, flagged or not
+    assert list(r0["codes"]) == [0, -4, 0] and list(r1["codes"]) == [0, -4, 0]
+    assert bool(r0["peer"][1]) and not bool(r1["peer"][1])                       # rank 0 learns it from the trailer, rank 1 from its own word
+    np.testing.assert_array_equal(r0["w"][1], r0["w"][0])                        # the flagged step moved nothing ...
+    assert np.abs(r0["w"][2] - r0["w"][1]).max() > 1e-4                          # ... and training goes on
+    assert int(r0["steps"][0]) == 2 and int(r1["steps"][0]) == 2

@@ -80,6 +80,9 @@ def test_train_update_validate_decode_entry_points(fmt, cuda, tmp_path, oracle):
                                           "--batch_length", "1500", "--max_length", "4000", "--verbose", "0"]) == 0
     val = yaml.safe_load(open(res + "/validation_result.yml"))
     assert list(val) == ["checkpoint-final.pkl"] and 0 < val["checkpoint-final.pkl"] < 10
+    # ... and the number itself: the same batches through the numpy oracle (the staged batches reach forward_loss on a copy stream; an
+    # un-joined copy would show as a loss computed on stale inputs)
+    assert abs(val["checkpoint-final.pkl"] - _oracle_validation_loss(root, fmt, stats, conf, exp + "/checkpoint-final.pkl", 1500, 4000)) < 1e-4
     # decode (greedy so the oracle can check it), wav files named by feature id
     out = str(tmp_path / "wav_out")
     assert runners.run_decode(["--feats", root + "/feat", "--stats", stats, "--config", conf, "--checkpoint",
@@ -105,6 +108,32 @@ def test_train_update_validate_decode_entry_points(fmt, cuda, tmp_path, oracle):
     hn = sc.transform(h).astype(np.float32)
     ref = oracle.decode(TINY, flat, np.ascontiguousarray(hn.T), d, np.array([128], dtype=np.int64), h.shape[0] * 110 - 1, maxd=maxd)["samples"]
     np.testing.assert_array_equal(wavfile.read(out + "/u00.wav")[1], loaders.samples_to_int16(ref))
+
+
+def _oracle_validation_loss(root, fmt, stats, conf_path, ckpt, batch_length, max_length):
+    """run_validate's number restated on the host: the reference's validation pass (qpnet_validate.py:409-437) = mean over the un-shuffled generator's
+    batches of the mean CE of each, here through oracle/train_oracle.py on the checkpoint's weights."""
+    import torch
+    from oracle import train_oracle as TO
+    conf = loaders.load_model_conf(conf_path)
+    wavs, feats = loaders.file_lists(root + "/wav", root + "/feat", fmt)
+    scaler = loaders.read_scaler_stats(stats, conf.feature_type)
+    fs = loaders.read_wav(wavs[0])[0]
+    items = [(lambda w=w, f=f: (loaders.read_wav(w)[1], loaders.read_features(f, conf.feature_type))) for w, f in zip(wavs, feats)]
+    gen = loaders.train_generator(items, TINY.receptiveCausal_field, TINY.receptiveF_field, TINY.receptiveA_field, fs,
+                                  wav_transform=loaders.mu_law_transform(conf.n_quantize), feat_transform=scaler, dense_factor=conf.dense_factor,
+                                  batch_length=batch_length, batch_size=1, max_length=max_length, f0_threshold=0,
+                                  upsampling_factor=conf.upsampling_factor, shuffle=False, epochs=1)
+    sd = torch.load(ckpt, map_location="cpu")["model"]
+    flat = np.concatenate([v.numpy().ravel() for v in sd.values()]).astype(np.float32)
+    losses = []
+    for bx, bh, bt, bd, bb in gen:
+        x, h, t, d = (np.asarray(a) for a in (bx, bh, bt, bd))
+        lg, _ = TO.forward(TINY, flat, x, h.astype(np.float32), d.astype(np.float32), np.asarray(bb))
+        BL = int(np.asarray(bb)[0])
+        losses.append(TO.ce_loss(lg, t[:, -BL:])[0])
+    assert losses
+    return float(np.mean(losses))
 
 
 def _small_geo(fmt="npy"):
@@ -188,5 +217,15 @@ def test_staged_chunks_arrive_on_a_copy_stream_and_are_joined_by_their_first_use
             assert "_qpn_staged" not in dv["x"].__dict__
         tr.check_status()
         ws.append(m.flat_parameters().detach().cpu().numpy())
+        if mode == "1":
+            # forward_loss (what run_validate calls) joins the copy too, whichever of its inputs carries the tag, and gives the oracle's loss
+            from oracle import train_oracle as TO
+            w_now = ws[-1]
+            dv = stage(host)
+            del dv["x"].__dict__["_qpn_staged"]                                  # (a consumer that looked at x alone would miss the copy)
+            v = tr.forward_loss(dv["x"], dv["h"], dv["t"], dv["d"], b, maxd=int(np.ceil(d.max())))
+            assert all("_qpn_staged" not in dv[k].__dict__ for k in host)
+            lg, _ = TO.forward(cfg, w_now, x, h, d, b)
+            assert abs(v - TO.ce_loss(lg, t[:, -int(b[0]):])[0]) < 1e-4
     np.testing.assert_array_equal(outs[0], outs[1])
     np.testing.assert_allclose(ws[0], ws[1], rtol=0, atol=2e-6)                    # (float-atomics order inside a step)

@@ -254,6 +254,88 @@ def test_bench_shape_step_vs_oracle(cuda):
     util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-4, a_rel=2e-3)
 
 
+def _bench_chunk(i=0):
+    """bench.py's chunk i on rank 0 of 1 (run_train: seeds 5000 + 17 i): BASELINE config[1] / SURVEY 8d -- 20 900 samples, RF 946, 19 954 output rows."""
+    from qpnet_amd.config import PAPER
+    x, h, t, d, b = synth.train_inputs(PAPER, 20000, 5000 + 17 * i, 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True)
+    assert x.shape[1] == 20900 and int(b[0]) == 19954 and int(np.ceil(d).max()) == 62
+    return x, h, t, d, b
+
+
+def test_the_fused_step_bench_times_vs_oracle(cuda):
+    """the path bench.py TIMES -- FusedTrainer.step -> qpn_train_step -> k_post_fb_w<5> (forward, cross entropy and backward of a post-net
+    tile as one kernel), both stack work queues, the side stream, the library's Adam -- on the exact bench chunk with default knobs: the loss within the
+    north_star tolerance, every tensor of the step's gradient (tr.g) against the numpy oracle's hand-derived backward, the parameters after the step
+    against the oracle's Adam (reference loop body: src/bin/qpnet_train.py:517-531)."""
+    from oracle import train_oracle as TO
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.train import FusedTrainer
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    x, h, t, d, b = _bench_chunk(0)
+    BL = int(b[0])
+    m = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    xt, ht, tt, dt = _to(cuda, x, h, t, d)
+    assert tr.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=62) is None      # (bench.py: want_loss=False; "lagged" runs the same kernels and keeps the loss)
+    loss = tr.flush_loss()
+    tr.check_status()
+    grad = tr.g[:flat.size].cpu().numpy()
+    lg, caches = TO.forward(cfg, flat, x, h, d, b)
+    oloss, dl = TO.ce_loss(lg, t[:, -BL:])
+    assert abs(loss - float(oloss)) < 1e-4
+    og = util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-4, a_rel=2e-3)
+    wo = flat.copy()
+    TO.Adam(flat.size).step(wo, og)
+    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), wo, 1e-4, 1)
+    # ... and with the loss read inside the step (mode 2 of qpn_train_step: the reference's literal order) the same loss from the same weights
+    m2 = util.build_model(cfg, flat, cuda).train()
+    assert abs(FusedTrainer(m2, lr=1e-4).step(xt, ht, tt, dt, b, want_loss=True, maxd=62) - loss) < 1e-6
+
+
+def test_three_fused_steps_at_the_bench_shape_vs_the_torch_port(cuda):
+    """three consecutive fused steps on bench.py's first three chunks against oracle/train_torch.py (torch autograd + torch.optim.Adam on
+    the CPU, pinned to the reference's fixture): every step's loss within 1e-4 (north_star), the weights after the three Adam steps."""
+    from oracle import train_torch as TT
+    from qpnet_amd.config import PAPER
+    from qpnet_amd.train import FusedTrainer
+    cfg = PAPER
+    flat = synth.make_weights(cfg, 13)
+    m = util.build_model(cfg, flat, cuda).train()
+    tr = FusedTrainer(m, lr=1e-4)
+    ref = TT.Trainer(cfg, flat, lr=1e-4)
+    got, want = [], []
+    for i in range(3):
+        x, h, t, d, b = _bench_chunk(i)
+        v = tr.step(*_to(cuda, x, h, t, d), b, want_loss="lagged", maxd=62)
+        if v is not None:
+            got.append(v)
+        want.append(ref.step(x, h, t, d, b))
+    got.append(tr.flush_loss())
+    tr.check_status()
+    np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
+    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), ref.flat.detach().numpy(), 1e-4, 3)
+
+
+def test_full_size_gradient_error_is_fp32_reassociation_vs_a_float64_oracle(cuda):
+    """the full-size gradient tolerances (a_scale 2e-4, a_rel 2e-3, an allowance for ReLU kinks) are loose -- shown here by measurement to be
+    about the KINKS, not about the kernels' arithmetic: the oracle run in float64 (train_oracle.precision) is the yardstick, evaluated on the ReLU sides each
+    float32 forward actually took (the GPU's are read through the -DQPN_TESTING build's qpn_test_postnet_activations, hence the child process:
+    tests/f64_child.py), and per parameter tensor the GPU's gradient -- the fused step bench.py times AND the autograd path -- is no further from it than
+    4 x the float32 numpy oracle's own distance (+ 1e-6 of the largest gradient); every unit whose side differs from the float64 run's has a float64
+    pre-activation below 1e-5, i.e. the sides differ by rounding alone."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "qpnet_amd", "libqpnet_hip_testing.so")
+    assert os.path.exists(lib), "build the testing library first: python -c 'import __graft_entry__ as g; g.build()'"
+    env = dict(os.environ, QPN_LIB=lib, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "f64_child.py"), "bench"], env=env, capture_output=True, text=True, timeout=900)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "F64_CHILD_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-4000:]
+
+
 def test_a_flagged_step_leaves_parameters_and_moments_alone(cuda):
     """the device-side status word (here: a target outside [0, n_quantize)) reaches the host up to two steps late in the lagged loop.  The
     Adam kernel reads the word itself and skips the update while it is set: the flagged step and the steps enqueued behind it change neither the
@@ -279,9 +361,29 @@ def test_a_flagged_step_leaves_parameters_and_moments_alone(cuda):
         tr.check_status()                                               # (what run_train does before every report / checkpoint / the final model)
     assert e.value.code == -4
     assert torch.equal(m.flat_parameters(), w0) and torch.equal(tr.m, m0) and torch.equal(tr.v, v0)
+    # the host's step count (the bias correction's exponent, what checkpoints store) is set back to the updates the device applied
+    assert tr.step_count == 1 and tr.state_dict()["state"][0]["step"] == 1
     tr.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)           # the word has been read: training goes on
     tr.flush_loss(); tr.check_status()
-    assert not torch.equal(m.flat_parameters(), w0)
+    assert not torch.equal(m.flat_parameters(), w0) and tr.step_count == 2
+    # ... exactly as if the two skipped steps had never been issued: a second trainer that runs the two clean steps alone ends bit-identical
+    # (same kernels, same step numbers; the stack's float atomics are the only source of run-to-run noise)
+    m2 = util.build_model(cfg, synth.make_weights(cfg, 11), cuda).train()
+    tr2 = FusedTrainer(m2, lr=1e-3)
+    for _ in range(2):
+        tr2.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)
+    tr2.flush_loss(); tr2.check_status()
+    np.testing.assert_allclose(m.flat_parameters().cpu().numpy(), m2.flat_parameters().cpu().numpy(), rtol=0, atol=2e-6)
+    # the same through step()'s own raise (the lagged collect at the start of a step) and through the in-step check (want_loss=True)
+    tr2.step(xt, ht, bad, dt, b, want_loss="lagged", maxd=maxd)
+    tr2.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)
+    with pytest.raises(_lib.QpnError):
+        tr2.step(xt, ht, tt, dt, b, want_loss="lagged", maxd=maxd)     # raised before anything of this step is enqueued
+    assert tr2.step_count == 2
+    with pytest.raises(_lib.QpnError):
+        tr2.step(xt, ht, bad, dt, b, want_loss=True, maxd=maxd)        # flagged and checked in the call: its Adam launch applied nothing
+    assert tr2.step_count == 2
+    assert tr2.step(xt, ht, tt, dt, b, want_loss=True, maxd=maxd) > 0 and tr2.step_count == 3
 
 
 @pytest.mark.parametrize("geo", [(64, 128, 3, 2, 2, 1), (128, 128, 2, 1, 2, 1), (96, 256, 2, 1, 1, 1)], ids=["C64-F3x2", "C128", "C96"])
@@ -520,6 +622,50 @@ def test_stock_adam_stepped_by_the_library_equals_torchs_own(cuda, monkeypatch):
     assert [float(s5["state"][i]["step"]) for i in s5["state"]] == [float(s4["state"][i]["step"]) for i in s4["state"]]
 
 
+def test_stock_adam_rollback_keeps_the_loaded_step_counts(cuda, monkeypatch):
+    """`opt.load_state_dict()` on an optimizer the step hooks have adopted -- a rollback to an earlier checkpoint after stepping on, or an empty
+    state -- must continue from the LOADED state (its step counts drive the bias correction), not from the adopter's old count: 2 steps, checkpoint,
+    2 more steps, rollback, 2 steps == 4 steps straight through, the counters read 4, and a freshly made (empty) state loads and steps without a KeyError."""
+    import copy
+    import torch
+    from qpnet_amd.config import TINY
+    cfg = TINY
+    flat = synth.make_weights(cfg, 12)
+    monkeypatch.setenv("QPN_DROPIN_FUSED_ADAM", "1")
+
+    def weights(m):
+        return torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu().numpy()
+
+    m = util.build_model(cfg, flat, cuda).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    empty = copy.deepcopy(opt.state_dict())
+    for step in range(4):
+        _ref_loop_step(m, opt, cfg, cuda, 90 + step)
+    w_straight = weights(m)
+    m = util.build_model(cfg, flat, cuda).train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for step in range(2):
+        _ref_loop_step(m, opt, cfg, cuda, 90 + step)
+    ckpt = {"model": {k: v.clone() for k, v in m.state_dict().items()}, "opt": copy.deepcopy(opt.state_dict())}
+    for step in range(2, 4):
+        _ref_loop_step(m, opt, cfg, cuda, 90 + step)
+    assert opt.__dict__["_qpn_adopt"] and opt.__dict__["_qpn_adopt"].steps == 4
+    m.load_state_dict(ckpt["model"]); opt.load_state_dict(ckpt["opt"])            # roll back to step 2
+    for step in range(2, 4):
+        _ref_loop_step(m, opt, cfg, cuda, 90 + step)
+    np.testing.assert_allclose(weights(m), w_straight, atol=3e-6, rtol=0)
+    sd = opt.state_dict()
+    assert [float(st["step"]) for st in sd["state"].values()] == [4.0] * len(sd["state"])
+    assert opt.__dict__["_qpn_adopt"]                                             # (adopted again after the step torch ran itself)
+    # an empty state (a fresh optimizer's) over a stepped one: starts over from step 0
+    m.load_state_dict(ckpt["model"]); opt.load_state_dict(empty)
+    for step in range(2):
+        _ref_loop_step(m, opt, cfg, cuda, 90 + step)
+    sd = opt.state_dict()
+    assert [float(st["step"]) for st in sd["state"].values()] == [2.0] * len(sd["state"])
+    assert all(set(st) == {"step", "exp_avg", "exp_avg_sq"} for st in sd["state"].values())
+
+
 def test_stock_adam_left_alone_when_not_this_modules(cuda, monkeypatch):
     """two groups, or a closure: torch's own step runs (with fused=True on eligible groups), results as before."""
     import torch
@@ -545,6 +691,33 @@ def test_stock_adam_left_alone_when_not_this_modules(cuda, monkeypatch):
     loss = opt2.step(closure)
     assert float(loss.detach()) > 0 and float((m.flat_parameters().detach() - w_before).abs().max()) > 1e-5
     assert not opt2.__dict__.get("_qpn_adopt")
+
+
+def test_an_interior_parameter_replaced_is_picked_up_within_a_few_forwards(cuda):
+    """ensure_flat's per-call check looks at the first, the last and four rotating parameter views (the full walk runs every 32nd call).  One interior
+    `p.data = ...` -- which leaves the flat buffer the kernels read stale -- is noticed within 30 calls: the buffer is rebuilt from the parameters and the
+    logits are those of the new value."""
+    import torch
+    from qpnet_amd.config import TINY
+    from qpnet_amd.train import ensure_flat
+    cfg = TINY
+    flat = synth.make_weights(cfg, 4)
+    m = util.build_model(cfg, flat, cuda)
+    x, h, t, d, b = synth.train_inputs(cfg, 300, 17, 30000)
+    xt, ht, dt, bt = _to(cuda, x, h, d, b)
+    with torch.no_grad():
+        m(xt, ht, dt, bt); m(xt, ht, dt, bt)
+        params = list(m.parameters())
+        q = params[len(params) // 2]
+        q.data = torch.zeros_like(q.data)                                 # a new storage for ONE interior parameter
+        for calls in range(1, 40):
+            out = m(xt, ht, dt, bt)
+            f = m._flat
+            if f.data_ptr() <= q.data_ptr() < f.data_ptr() + 4 * f.numel():
+                break
+        assert calls <= 31
+        m2 = util.build_model(cfg, ensure_flat(m, cuda).cpu().numpy(), cuda)
+        assert float(q.abs().max()) == 0.0 and torch.equal(out, m2(xt, ht, dt, bt))
 
 
 def test_grad_accumulation_and_zero_grad_in_place(cuda):
