@@ -231,7 +231,7 @@ _register_optimizer_step_post_hook(_adam_posthook)
 def join_staged(x, dev, *more):
     """Inputs copied to the device on a stream of their own (runners.PinnedStager: the copy must not sit between the step's kernels on the compute stream) carry
     {ready event, device buffer}: the consumer's stream waits for the copy -- long done when a prefetch thread is ahead, so the wait is a queue packet, not a
-    stall -- and the buffer is marked as used on that stream (the caching allocator will not hand it out again before the step that reads it has run)."""
+    stall -- and the buffer is marked as used on that stream (the caching allocator will not hand it out again before the step that reads it has run).
     Every consumer of loader batches calls this on ALL its inputs (FusedTrainer.step / forward_loss, QPNet.forward): a tensor that never
     went through a stager costs one dictionary look-up."""
     done = None
