@@ -86,7 +86,17 @@ def test_fused_train_steps_vs_reference(case, cuda, golden_dir):
         losses.append(tr.step(xt, ht, tt, dt, bt))
     np.testing.assert_allclose(losses, g[name + "_losses"], atol=1e-4, rtol=0)
     w = m.flat_parameters().cpu().numpy()
-    util.assert_weights_after_adam(w[::97], g[name + "_wfinal_sample"], 1e-4, nsteps)
+    # final weights vs the reference run's (fixture): elements whose gradient is significant at every step (numpy oracle on the same chunks) to 2e-6 -- the
+    # original fixture bound -- and the noise-level rest statistically
+    sig = util.significant_elements(cfg, _oracle_step_grads(cfg, flat, dseed, bl, nsteps))
+    util.assert_weights_after_adam(w[::97], g[name + "_wfinal_sample"], 1e-4, nsteps, significant=sig[::97])
+
+
+def _oracle_step_grads(cfg, flat, dseed, bl, nsteps, ml=30000):
+    from oracle import train_oracle as TO
+    w = flat.copy()
+    opt = TO.Adam(w.size)
+    return [TO.train_step(cfg, w, opt, *synth.train_inputs(cfg, bl, dseed + step, ml))[1] for step in range(nsteps)]
 
 
 def test_lagged_loss_is_every_steps_loss_one_step_late(cuda, golden_dir):
@@ -111,7 +121,8 @@ def test_lagged_loss_is_every_steps_loss_one_step_late(cuda, golden_dir):
     assert len(got) == nsteps
     np.testing.assert_allclose(got, g[name + "_losses"], atol=1e-4, rtol=0)
     w = m.flat_parameters().cpu().numpy()
-    util.assert_weights_after_adam(w[::97], g[name + "_wfinal_sample"], 1e-4, nsteps)
+    sig = util.significant_elements(cfg, _oracle_step_grads(cfg, synth.make_weights(cfg, wseed), dseed, bl, nsteps))
+    util.assert_weights_after_adam(w[::97], g[name + "_wfinal_sample"], 1e-4, nsteps, significant=sig[::97])
 
 
 def test_torch_adam_on_views_matches(cuda, golden_dir):
@@ -287,7 +298,9 @@ def test_the_fused_step_bench_times_vs_oracle(cuda):
     og = util.assert_grads_match_oracle(TO, cfg, flat, caches, dl, grad, a_scale=2e-4, a_rel=2e-3)
     wo = flat.copy()
     TO.Adam(flat.size).step(wo, og)
-    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), wo, 1e-4, 1)
+    # (first Adam step: every element moves by lr * g / (|g| + eps) = +-lr -- the sign of a noise-level gradient is noise, hence far = 2; an element
+    #  whose gradient is significant moves identically)
+    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), wo, 1e-4, 1, far=2.0, significant=util.significant_elements(cfg, [og]), sig_max=1e-6)
     # ... and with the loss read inside the step (mode 2 of qpn_train_step: the reference's literal order) the same loss from the same weights
     m2 = util.build_model(cfg, flat, cuda).train()
     assert abs(FusedTrainer(m2, lr=1e-4).step(xt, ht, tt, dt, b, want_loss=True, maxd=62) - loss) < 1e-6
@@ -304,17 +317,23 @@ def test_three_fused_steps_at_the_bench_shape_vs_the_torch_port(cuda):
     m = util.build_model(cfg, flat, cuda).train()
     tr = FusedTrainer(m, lr=1e-4)
     ref = TT.Trainer(cfg, flat, lr=1e-4)
-    got, want = [], []
+    got, want, grads = [], [], []
     for i in range(3):
         x, h, t, d, b = _bench_chunk(i)
         v = tr.step(*_to(cuda, x, h, t, d), b, want_loss="lagged", maxd=62)
         if v is not None:
             got.append(v)
-        want.append(ref.step(x, h, t, d, b))
+        loss, grad = ref.loss_and_grad(x, h, t, d, b)
+        want.append(loss); grads.append(grad.copy())
+        ref.opt.step()
     got.append(tr.flush_loss())
     tr.check_status()
     np.testing.assert_allclose(got, want, atol=1e-4, rtol=0)
-    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), ref.flat.detach().numpy(), 1e-4, 3)
+    # Measured (tools/adam_parity_stats.py, this shape): the elements with a significant gradient at all three steps (78 % of the model) end within 1.3e-5
+    # (0.04 of the 3e-4 travelled), 0.5 % of them beyond 2e-6 -- at this chunk size a post-net unit or two fall on the other side of a ReLU kink
+    # (tests/f64_child.py), which moves every upstream gradient by ~1e-4 of its size; noise-level elements may go the other way for whole steps
+    util.assert_weights_after_adam(m.flat_parameters().cpu().numpy(), ref.flat.detach().numpy(), 1e-4, 3, far=2.0,
+                                   significant=util.significant_elements(cfg, grads), sig_max=3e-5, sig_frac=0.02)
 
 
 def test_full_size_gradient_error_is_fp32_reassociation_vs_a_float64_oracle(cuda):

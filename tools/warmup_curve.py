@@ -10,6 +10,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=80)
 ap.add_argument("--spin-ms", type=float, default=0.0)
 ap.add_argument("--chunks", type=int, default=4)
+ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--prewarm", type=int, default=0, help="steps on ANOTHER model + trainer (its own native handle) before the measured run")
+ap.add_argument("--sleep-ms", type=float, default=0.0, help="idle time between the prewarm and the measured run")
 args = ap.parse_args()
 import torch
 from qpnet_amd import synth
@@ -22,7 +25,7 @@ flat = synth.make_weights(cfg, 13)
 m = QPNet(**cfg.kwargs())
 m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
 m = m.to(dev).train()
-tr = FusedTrainer(m, lr=1e-4)
+tr = FusedTrainer(m, lr=args.lr)
 hb = [synth.train_inputs(cfg, 20000, 5000 + 17 * i, 30000, f0_lo=45.0, f0_hi=300.0, pin_f0_floor=True) for i in range(args.chunks)]
 bt = [[torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in b] for b in hb]
 torch.cuda.synchronize()
@@ -32,6 +35,17 @@ if args.spin_ms > 0:
     while (time.perf_counter() - t0) * 1e3 < args.spin_ms:
         a = a @ a * 1e-4
         torch.cuda.synchronize()
+if args.prewarm > 0:
+    m0 = QPNet(**cfg.kwargs())
+    m0.load_state_dict({k: torch.from_numpy(v) for k, v in synth.weights_to_state_dict(cfg, flat).items()})
+    m0 = m0.to(dev).train()
+    tr0 = FusedTrainer(m0, lr=1e-4)
+    for i in range(args.prewarm):
+        x, h, t, d, _ = bt[i % args.chunks]
+        tr0.step(x, h, t, d, hb[i % args.chunks][4], want_loss=False, maxd=62)
+    torch.cuda.synchronize()
+    if args.sleep_ms > 0:
+        time.sleep(args.sleep_ms * 1e-3)
 N = args.steps
 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(N)]
 host = []
@@ -47,7 +61,7 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t_all) * 1e3
 devms = [a.elapsed_time(b) for a, b in evs]
 gap = [evs[i][1].elapsed_time(evs[i + 1][0]) for i in range(N - 1)]
-print("spin %.0f ms; %d steps wall %.2f ms (%.1f steps/s)" % (args.spin_ms, N, wall, N / wall * 1e3))
+print("lr %g prewarm %d sleep %.0f |" % (args.lr, args.prewarm, args.sleep_ms), "spin %.0f ms; %d steps wall %.2f ms (%.1f steps/s)" % (args.spin_ms, N, wall, N / wall * 1e3))
 for lo in range(0, N, 10):
     hi = min(lo + 10, N)
     print("steps %3d-%3d: device ms/step %s | host enqueue ms %s | gaps %s" % (
