@@ -255,6 +255,10 @@ int qpn_train_early_bucket(qpn_handle* h, int64_t* first, int64_t* count, void* 
  * agree on it ONCE before they split the exchange, so that every rank issues the same collectives in every step. */
 int64_t qpn_train_early_first(qpn_handle* h);
 int qpn_train_profile_begin(qpn_handle* h, void* stream);
+/* The same with the step left as the timed loop runs it (the skip / post-net weight gradients, the early slab reduction, the aux tail and dWr on the
+ * handle's side stream next to the stack backward and dW1): every launch is timed on the stream it runs on -- what a kernel costs INSIDE the
+ * overlapped step (bench.py: roofline.overlapped, and the kernel the headline fraction is quoted for). */
+int qpn_train_profile_begin_overlapped(qpn_handle* h, void* stream);
 int qpn_train_profile_mark(qpn_handle* h, int group, void* stream);   /* attribute the work enqueued since the previous mark to `group` */
 int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream);
 

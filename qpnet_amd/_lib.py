@@ -58,6 +58,7 @@ SYMBOLS = [
     ("qpn_train_early_bucket", _i, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _vp]),
     ("qpn_train_early_first", _i64, [_vp]),
     ("qpn_train_profile_begin", _i, [_vp, _vp]),
+    ("qpn_train_profile_begin_overlapped", _i, [_vp, _vp]),
     ("qpn_train_profile_mark", _i, [_vp, _i, _vp]),
     ("qpn_train_profile_end", _i, [_vp, C.POINTER(C.c_float), _i, _vp]),
     ("qpn_dilated_index_train", _i, [_vp, _i, _i64, _i, _vp, _vp]),

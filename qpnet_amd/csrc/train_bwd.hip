@@ -1385,7 +1385,7 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     // grads wrt layer outputs: DXA/DXB[l] for l = 0..L (index l = grad wrt X[l]); zero (scatter targets / unwritten rows)
     // only the rows a consumer reads but no producer writes (see k_zero_dx): 4 adaptive scatter targets instead of 2(L+1) full arrays
     hipStream_t side = bw.side; hipEvent_t ev_fork = bw.ev_fork, ev_join = bw.ev_join;   // created with the handle's TrainState, on its device
-    const bool overlap = side && !qpn_prof_active() && !k.serial;
+    const bool overlap = side && !qpn_prof_serial() && !k.serial;
     const bool post_wide = S == 256 && Q == 256 && C == 64 && (p.LC == 256 || p.LC == 512) && k.post_wide;
     const bool zero_in_post = post_wide && k.zero_in_post;
     if (post_done) { }
@@ -1483,8 +1483,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     if (overlap) {
         QPN_HIP(hipEventRecord(ev_fork, stream));
         QPN_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        qpn_prof_mark(-1, side);
         launch_skip_post(side);
-        if (early_reduce) launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_);
+        if (early_reduce) { launch_reduce_early(bw, side, up_side ? 1 : 0, nch_side_); qpn_prof_mark(PG_GRAD_TAIL, side); }
         // the post-net block of the flat gradient (and, with up_side, the zeroing and the row-count trailer behind it) is final from here on:
         // a data-parallel caller exchanges that bucket while the layer backward still runs (qpn_train_early_bucket)
         if (early_reduce && up_side && bw.ev_early && bw.early_recorded) { QPN_HIP(hipEventRecord(bw.ev_early, side)); *bw.early_recorded = 1; }
@@ -1533,8 +1534,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     if (wr_side || up_side) {
         QPN_HIP(hipEventRecord(bw.ev_mid, stream));
         QPN_HIP(hipStreamWaitEvent(side, bw.ev_mid, 0));
-        if (up_side) { if (p.hoist) launch_aux_tail(p, bw, ag, side); else launch_up_bwd(p, bw, side); }      // (behind the early reduction's zeroing, on the same stream)
-        if (wr_side) ok = ok && wgrad2_any(build_wr(), nch, gen, side);
+        qpn_prof_mark(-1, side);
+        if (up_side) { if (p.hoist) launch_aux_tail(p, bw, ag, side); else launch_up_bwd(p, bw, side); qpn_prof_mark(PG_GRAD_TAIL, side); }      // (behind the early reduction's zeroing, on the same stream)
+        if (wr_side) { ok = ok && wgrad2_any(build_wr(), nch, gen, side); qpn_prof_mark(PG_WGRAD_WR, side); }
     }
     if (overlap) QPN_HIP(hipEventRecord(ev_join, side));
     qpn_prof_mark(PG_LAYER_BWD, stream);
@@ -1543,9 +1545,9 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     if (!wr_side) { ok = ok && wgrad2_any(build_wr(), nch, gen, stream); qpn_prof_mark(PG_WGRAD_WR, stream); }
     if (!overlap) launch_skip_post(stream);
     if (sl.g_cw >= 0) ok = ok && wgrad2_any(build_causal(), nch, gen, stream);
-    if (overlap) QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0));      // joined BEFORE any early return: the caller's stream must own everything enqueued here
-    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128 on this path; wider stacks take the GEMM path)"); return QPN_EINVAL; }
     qpn_prof_mark(PG_WGRAD_CAUSAL, stream);
+    if (overlap) { QPN_HIP(hipStreamWaitEvent(stream, ev_join, 0)); qpn_prof_mark(-1, stream); }      // joined BEFORE any early return: the caller's stream must own everything enqueued here
+    if (!ok) { qpn_set_error("weight-gradient tiles: unsupported geometry (n_resch <= 128 on this path; wider stacks take the GEMM path)"); return QPN_EINVAL; }
     return qpn_launch_grad_tail(p, bw, &ag, stream, early_reduce, up_side);
 }
 

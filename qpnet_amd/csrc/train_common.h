@@ -242,6 +242,7 @@ int qpn_num_cus();                                   // compute units of the cur
 enum { PG_PREP = 0, PG_LAYER_FWD, PG_POST_FWD, PG_CE, PG_POST_BWD, PG_WGRAD, PG_LAYER_BWD, PG_GRAD_TAIL, PG_ADAM, PG_ALLREDUCE,
        PG_WGRAD_WR, PG_WGRAD_SKIP, PG_WGRAD_POST, PG_WGRAD_CAUSAL, PG_COUNT };
 void qpn_prof_mark(int group, hipStream_t stream);
+bool qpn_prof_serial();                              // a SERIAL per-group timing is in progress (keeps the step on one stream; the overlapped mode does not)
 bool qpn_prof_active();                              // per-group timing in progress (keeps a step on one stream)   // attributes the work enqueued since the previous mark to `group`
 
 // XCD-aware tile index: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2); remapped so that the

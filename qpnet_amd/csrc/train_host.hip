@@ -92,18 +92,29 @@ int qpn_num_cus() {
 }
 
 // ---- per-group timing
-struct Prof { bool on = false; std::vector<hipEvent_t> ev; std::vector<int> grp; size_t used = 0; };
+// Marks are HIP events on the stream a launch went to; a group's time is the sum, over its marks, of the time since the PREVIOUS mark on the same stream
+// (group -1: a baseline only -- behind a cross-stream wait, so that the wait is nobody's time).  Serial mode (qpn_train_profile_begin) puts the whole
+// step on one stream: a kernel's time alone.  Overlapped mode (qpn_train_profile_begin_overlapped) leaves the step as the timed loop runs it -- the skip /
+// post-net weight gradients, the early reduction, the aux tail and dWr on the side stream next to the stack backward and dW1 -- and times every launch
+// where it runs: what a kernel costs in the step, which is what the bench line's roofline.kernel is chosen by.
+struct Prof { bool on = false; bool overlapped = false; std::vector<hipEvent_t> ev; std::vector<int> grp; std::vector<hipStream_t> st; size_t used = 0; };
 static thread_local Prof g_prof;
 bool qpn_prof_active() { return g_prof.on; }
+bool qpn_prof_serial() { return g_prof.on && !g_prof.overlapped; }
 void qpn_prof_mark(int group, hipStream_t stream) {
     Prof& P = g_prof;
     if (!P.on) return;
-    if (P.used == P.ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; P.ev.push_back(e); P.grp.push_back(0); }
-    P.grp[P.used] = group;
+    if (P.used == P.ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; P.ev.push_back(e); P.grp.push_back(0); P.st.push_back(nullptr); }
+    P.grp[P.used] = group; P.st[P.used] = stream;
     (void)hipEventRecord(P.ev[P.used++], stream);
 }
 extern "C" int qpn_train_profile_begin(qpn_handle* h, void* stream) {
-    (void)h; g_prof.on = true; g_prof.used = 0;
+    (void)h; g_prof.on = true; g_prof.overlapped = false; g_prof.used = 0;
+    qpn_prof_mark(-1, (hipStream_t)stream);
+    return QPN_OK;
+}
+extern "C" int qpn_train_profile_begin_overlapped(qpn_handle* h, void* stream) {
+    (void)h; g_prof.on = true; g_prof.overlapped = true; g_prof.used = 0;
     qpn_prof_mark(-1, (hipStream_t)stream);
     return QPN_OK;
 }
@@ -111,14 +122,18 @@ extern "C" int qpn_train_profile_mark(qpn_handle* h, int group, void* stream) {
     (void)h; qpn_prof_mark(group, (hipStream_t)stream); return QPN_OK;
 }
 extern "C" int qpn_train_profile_end(qpn_handle* h, float* h_ms, int n, void* stream) {
-    (void)h;
     Prof& P = g_prof;
     QPN_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (h && h->train && h->train->side) QPN_HIP(hipStreamSynchronize(h->train->side));
     for (int i = 0; i < n; ++i) h_ms[i] = 0.f;
     for (size_t i = 1; i < P.used; ++i) {
+        if (P.grp[i] < 0 || P.grp[i] >= n) continue;
+        size_t j = i;
+        while (j > 0 && P.st[j - 1] != P.st[i]) --j;              // the previous mark on the same stream
+        if (j == 0) continue;
         float ms = 0.f;
-        QPN_HIP(hipEventElapsedTime(&ms, P.ev[i - 1], P.ev[i]));
-        if (P.grp[i] >= 0 && P.grp[i] < n) h_ms[P.grp[i]] += ms;
+        QPN_HIP(hipEventElapsedTime(&ms, P.ev[j - 1], P.ev[i]));
+        h_ms[P.grp[i]] += ms;
     }
     P.on = false;
     return QPN_OK;

@@ -11,6 +11,7 @@ ap.add_argument("--steps", type=int, default=80)
 ap.add_argument("--spin-ms", type=float, default=0.0)
 ap.add_argument("--chunks", type=int, default=4)
 ap.add_argument("--lr", type=float, default=1e-4)
+ap.add_argument("--spin-after-first", type=float, default=0.0, help="ms of a dummy torch matmul loop BETWEEN the first (initialising) step and the rest")
 ap.add_argument("--prewarm", type=int, default=0, help="steps on ANOTHER model + trainer (its own native handle) before the measured run")
 ap.add_argument("--sleep-ms", type=float, default=0.0, help="idle time between the prewarm and the measured run")
 args = ap.parse_args()
@@ -57,6 +58,13 @@ for i in range(N):
     tr.step(x, h, t, d, hb[i % args.chunks][4], want_loss=False, maxd=62)
     evs[i][1].record()
     host.append((time.perf_counter() - t0) * 1e3)
+    if i == 0 and args.spin_after_first > 0:
+        a = torch.randn(4096, 4096, device=dev)
+        ts = time.perf_counter()
+        while (time.perf_counter() - ts) * 1e3 < args.spin_after_first:
+            a = a @ a * 1e-4
+            torch.cuda.synchronize()
+        del a
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t_all) * 1e3
 devms = [a.elapsed_time(b) for a, b in evs]
