@@ -66,7 +66,7 @@ class _SampleWindow:
     def __init__(self, n_feat, feat_dtype, U):
         import collections
         self.U = int(U)
-        self.segs = collections.deque()                 # [x (F*U,) f32, d (F,) f64, sufmax (F,) f64, h (F, D)]
+        self.segs = collections.deque()                 # [x (F*U,) f32 | None, d (F,) f64, sufmax (F,) f64, h (F, D) | None, load, part]
         self.f0 = 0                                     # frames of the first segment already consumed
         self.n_frames = 0                               # live frames / samples in the window
         self.h_dtype = np.result_type(np.float32, feat_dtype)
@@ -76,13 +76,21 @@ class _SampleWindow:
     def n_samples(self):
         return self.n_frames * self.U
 
-    def append(self, x, h, d_frames):
+    def append(self, x, h, d_frames, sufmax=None, load=None, part=None):
+        """One utterance.  x / h may be None with `load` a callable returning the (validated) pair: the PLAN of the stream -- where chunks begin and end,
+        which receptive field each has -- needs only the frame count and the dilated factors; samples and features are fetched when a chunk
+        that is actually cut (`front`) reaches into the utterance (a data-parallel rank cuts every world-th chunk only).  `part(s0, s1, f0, f1)`, when the
+        utterance's source has it, returns just samples [s0, s1) and feature rows [f0, f1): a rank whose chunks are a world-th of the stream then reads a
+        world-th of the BYTES, however long the utterances are (its consecutive chunks lie `world` chunks apart: nothing of a whole-utterance load is reused)."""
         d = np.asarray(d_frames, dtype=np.float64)      # float32 buffer + float64 factors promote to float64 upstream too
-        assert len(x) == len(d) * self.U == h.shape[0] * self.U
+        if x is not None:
+            assert len(x) == len(d) * self.U == h.shape[0] * self.U
         if len(d) == 0:
             return
-        sufmax = np.fmax.accumulate(d[::-1])[::-1]      # (fmax: a NaN factor is ignored, as by the reference's np.nanmax; all-NaN tails stay NaN)
-        self.segs.append((np.asarray(x, dtype=np.float32), d, sufmax, h.astype(self.h_dtype, copy=False)))
+        if sufmax is None:
+            sufmax = np.fmax.accumulate(d[::-1])[::-1]  # (fmax: a NaN factor is ignored, as by the reference's np.nanmax; all-NaN tails stay NaN)
+        self.segs.append([None if x is None else np.asarray(x, dtype=np.float32), d, sufmax,
+                          None if h is None else h.astype(self.h_dtype, copy=False), load, part])
         self.n_frames += len(d)
 
     def max_factor(self):
@@ -97,16 +105,29 @@ class _SampleWindow:
         U = self.U
         xs, ds, hs = [], [], []
         need_s, need_f, off = samples, frames, self.f0
-        for x, d, _, h in self.segs:
+        for seg in self.segs:
             if need_s <= 0:
                 break
-            take_s = min(need_s, len(x) - off * U)
+            d = seg[1]
+            take_s = min(need_s, len(d) * U - off * U)
             take_fd = -(-take_s // U)                   # frames whose factors those samples repeat
-            xs.append(x[off * U:off * U + take_s])
+            take_f = min(need_f, len(d) - off) if need_f > 0 else 0
+            if seg[0] is None and seg[5] is not None:   # planned only, and its source can hand out a slice: exactly what this chunk needs of it
+                xp, hp = seg[5](off * U, off * U + take_s, off, off + take_f)
+                assert len(xp) == take_s and hp.shape[0] == take_f, "an utterance changed between the plan and the load"
+                xs.append(np.asarray(xp, dtype=np.float32))
+                if take_f > 0:
+                    hs.append(hp.astype(self.h_dtype, copy=False))
+            else:
+                if seg[0] is None:                      # planned only so far: fetch the utterance now (kept until the window has moved past it)
+                    x, h = seg[4]()
+                    assert len(x) == len(d) * U == h.shape[0] * U, "an utterance changed between the plan and the load"
+                    seg[0], seg[3] = np.asarray(x, dtype=np.float32), h.astype(self.h_dtype, copy=False)
+                xs.append(seg[0][off * U:off * U + take_s])
+                if take_f > 0:
+                    hs.append(seg[3][off:off + take_f])
             ds.append(np.repeat(d[off:off + take_fd], U)[:take_s])
-            if need_f > 0:
-                take_f = min(need_f, len(d) - off)
-                hs.append(h[off:off + take_f]); need_f -= take_f
+            need_f -= take_f
             need_s -= take_s
             off = 0
         cat = lambda parts: parts[0] if len(parts) == 1 else np.concatenate(parts)      # noqa: E731
@@ -119,6 +140,60 @@ class _SampleWindow:
         while self.segs and self.f0 >= len(self.segs[0][1]):
             self.f0 -= len(self.segs[0][1])
             self.segs.popleft()
+
+
+class _UtterancePlan:
+    """What the chunk plan needs of every utterance -- frame count after validate_length, per-frame dilated factors and their suffix maxima, the feature
+    dtype / width -- computed ONCE per utterance and kept for the later epochs (a few KB each).  Source, cheapest first: the item's own `plan()` hook
+    (runners' file-backed loaders: the wav header and the feature file, no waveform), else one full load of the item."""
+
+    def __init__(self, utterances, U, f0_threshold, fs, dense_factor):
+        self.utts, self.U, self.f0_threshold, self.fs, self.dense = utterances, int(U), f0_threshold, fs, dense_factor
+        self.meta = {}
+        self.loads = 0                                  # full loads of an utterance (samples + features) so far: what a sharded rank should need few of
+        self.parts = 0                                  # partial loads (the item's `part` hook)
+
+    def load(self, i):
+        item = self.utts[i]
+        x, h = item() if callable(item) else item
+        if callable(item):
+            self.loads += 1
+        return harness.validate_length(np.array(x, dtype=np.float32), np.asarray(h), self.U)
+
+    def _entry(self, n_wav, h):
+        frames = h.shape[0]
+        shortfall = frames * self.U - n_wav             # (harness.validate_length on the lengths alone)
+        if shortfall > 0:
+            frames = max(frames - (shortfall // self.U + 1), 0)
+        d = np.asarray(harness.dilated_factor(harness.batch_f0(h[:frames], self.f0_threshold), self.fs, self.dense), dtype=np.float64)
+        return (frames, d, np.fmax.accumulate(d[::-1])[::-1] if frames else d, h.shape[1], h.dtype)
+
+    def part_hook(self, i):
+        item = self.utts[i]
+        hook = getattr(item, "part", None) if callable(item) else None
+        if hook is None:
+            return None
+
+        def part(s0, s1, f0, f1):
+            self.parts += 1
+            return hook(s0, s1, f0, f1)
+        return part
+
+    def get(self, i):
+        """-> (entry, loaded pair or None)"""
+        e = self.meta.get(i)
+        if e is not None:
+            return e, None
+        item = self.utts[i]
+        hook = getattr(item, "plan", None) if callable(item) else None
+        if hook is not None:
+            n_wav, h = hook()
+            e, pair = self._entry(int(n_wav), np.asarray(h)), None
+        else:
+            pair = self.load(i)
+            e = self._entry(len(pair[0]), pair[1])
+        self.meta[i] = e
+        return e, pair
 
 
 def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_receptiveA, fs, wav_transform=None,
@@ -137,8 +212,13 @@ def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_r
 
     shard = (rank, world): data-parallel ranks walk the SAME stream (same seed, same chunk boundaries) but only batch
     numbers rank, rank + world, ... are materialised and yielded; for the others the window just advances -- no mu-law
-    encoding, scaling or tensor is made for a chunk another rank consumes (no counterpart in the reference, whose only
-    multi-GPU path is a dead DataParallel wrapper, qpnet_train.py:416-423)."""
+    encoding, scaling or tensor is made for a chunk another rank consumes, and the stream is laid out from per-utterance
+    metadata (frames + dilated factors, computed once per utterance -- through the item's `plan()` hook when it has one --
+    and cached over the epochs): an utterance's samples and features are loaded only when one of this rank's own chunks
+    reaches into it (no counterpart in the reference, whose only multi-GPU path is a dead DataParallel wrapper,
+    qpnet_train.py:416-423).  An item with a `part(s0, s1, f0, f1)` hook (runners' file-backed
+    loaders) is read in slices: exactly the samples / feature rows a chunk needs.  `train_generator.last_stats` counts the full ("loads") and
+    partial ("parts") loads of the most recent generator."""
     U = int(upsampling_factor)
     rank, world = (0, 1) if shard is None else (int(shard[0]), int(shard[1]))
     n_batches = 0                                       # batches cut so far, over all ranks
@@ -146,17 +226,39 @@ def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_r
     order = np.random.permutation(n_files) if shuffle else np.arange(n_files)
     win = None
     epoch = 0
+    # With world > 1 the stream is PLANNED from per-utterance metadata (frames, dilated factors: _UtterancePlan, cached across epochs) and an utterance's
+    # samples / features are loaded only when one of THIS rank's chunks reaches into it (every rank used to load, validate and take the
+    # factors of every utterance, so a rank's host work per step grew with the world size).  world == 1 touches every utterance anyway: loaded on append.
+    plan = _UtterancePlan(utterances, U, f0_threshold, fs, dense_factor) if world > 1 else None
+    stats = {"loads": 0, "parts": 0}                    # (train_generator.last_stats: full / partial utterance loads of the most recent generator, for tests / tools)
+    train_generator.last_stats = stats
     while epochs is None or epoch < epochs:
         rows = []                                       # (x, h, t, d, bl) of the batch being filled
         slots_left = batch_size
         for i in order:
-            item = utterances[int(i)]
-            x, h = item() if callable(item) else item
-            x, h = harness.validate_length(np.array(x, dtype=np.float32), np.asarray(h), U)
-            d = harness.dilated_factor(harness.batch_f0(h, f0_threshold), fs, dense_factor)
-            if win is None:
-                win = _SampleWindow(h.shape[1], h.dtype, U)
-            win.append(x, h, d)
+            if plan is None:
+                item = utterances[int(i)]
+                x, h = item() if callable(item) else item
+                stats["loads"] += 1
+                x, h = harness.validate_length(np.array(x, dtype=np.float32), np.asarray(h), U)
+                d = harness.dilated_factor(harness.batch_f0(h, f0_threshold), fs, dense_factor)
+                if win is None:
+                    win = _SampleWindow(h.shape[1], h.dtype, U)
+                win.append(x, h, d)
+            else:
+                (nfr, d, sufmax, n_feat, h_dtype), pair = plan.get(int(i))
+                if win is None:
+                    win = _SampleWindow(n_feat, h_dtype, U)
+
+                def load(i=int(i)):
+                    out = plan.load(i)
+                    stats["loads"] = plan.loads
+                    return out
+                if pair is not None:                    # (the plan had to load it: keep what was loaded)
+                    stats["loads"] = plan.loads
+                    win.append(pair[0], pair[1], d, sufmax)
+                else:
+                    win.append(None, None, d, sufmax, load, plan.part_hook(int(i)))
             rf = harness.receptive_field(model_receptiveCausal, model_receptiveF, model_receptiveA, win.max_factor())
             bl, frames, samples = harness.chunk_plan(rf, batch_length, max_length, U)
             hop_frames = bl // U
@@ -164,6 +266,8 @@ def train_generator(utterances, model_receptiveCausal, model_receptiveF, model_r
                 mine = n_batches % world == rank
                 if mine:
                     xs, hs, ds = win.front(frames, samples)
+                    if plan is not None:
+                        stats["parts"] = plan.parts
                     if wav_transform is not None:
                         xs = wav_transform(xs)
                     if feat_transform is not None:

@@ -161,11 +161,43 @@ class Prefetcher:
         return item
 
 
+class _FileUtterance:
+    """One (wav, feature file) pair of the corpus: called, it reads both (waveform in [-1, 1), features); `plan()` is what the sharded generator needs to lay
+    the chunk stream out WITHOUT the waveform -- its length from the wav header (a memory map: no sample is read) and the features (the f0 column sets the
+    dilated factors) -- so that a data-parallel rank reads the samples of the utterances its own chunks reach into only (loaders.train_generator)."""
+
+    def __init__(self, wav, feat, feature_type):
+        self.wav, self.feat, self.feature_type = wav, feat, feature_type
+        self._x = self._h = None                       # memory maps of the wav samples / .npy features, opened by the first plan() / part() and kept
+
+    def __call__(self):
+        return loaders.read_wav(self.wav)[1], loaders.read_features(self.feat, self.feature_type)
+
+    def _maps(self):
+        if self._x is None:
+            from scipy.io import wavfile
+            self._x = wavfile.read(self.wav, mmap=True)[1]
+            if self.feat.endswith(".npy"):
+                self._h = np.load(self.feat, mmap_mode="r")
+        return self._x, self._h
+
+    def plan(self):
+        x, h = self._maps()
+        return int(x.shape[0]), (np.array(h) if h is not None else loaders.read_features(self.feat, self.feature_type))
+
+    def part(self, s0, s1, f0, f1):
+        """samples [s0, s1) as read_wav scales them and feature rows [f0, f1): the wav through a memory map (only the pages of the slice are read), .npy
+        features likewise; an .h5 dataset is read whole (150 KB at 39 features x 5 ms frames) and sliced."""
+        x, h = self._maps()
+        xs = np.array(x[s0:s1], dtype=np.float32) / 32768
+        if f1 <= f0:
+            return xs, np.zeros((0, 0), dtype=np.float32)
+        return xs, (np.array(h[f0:f1]) if h is not None else loaders.read_features(self.feat, self.feature_type)[f0:f1])
+
+
 def _utterance_loaders(wav_list, feat_list, feature_type):
-    """zero-argument loaders (waveform in [-1,1), features) per utterance: files are read when the generator reaches them."""
-    def make(w, f):
-        return lambda: (loaders.read_wav(w)[1], loaders.read_features(f, feature_type))
-    return [make(w, f) for w, f in zip(wav_list, feat_list)]
+    """loaders (waveform in [-1,1), features) per utterance: files are read when the generator reaches them."""
+    return [_FileUtterance(w, f, feature_type) for w, f in zip(wav_list, feat_list)]
 
 
 def _batches(args, conf, model, shuffle, epochs, device, rank=0, world=1):

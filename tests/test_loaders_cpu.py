@@ -141,6 +141,68 @@ def test_train_generator_shards_are_the_round_robin_of_the_full_stream():
         assert total == len(full)
 
 
+def test_sharded_generator_loads_only_the_utterances_its_chunks_reach(golden_dir):
+    """with world 8 a rank used to load (and validate, and take the dilated factors of) EVERY utterance of the stream.  Now the chunk
+    plan comes from per-utterance metadata -- the `plan()` hook of runners' file-backed loaders (wav header + features, no waveform), cached over the epochs --
+    and an utterance is loaded when one of the rank's own chunks reaches into it: paper-size receptive fields, 48 short utterances, 3 epochs (144 loads at
+    world 1): each of the 8 ranks loads no more than a world-th of that plus what its chunks' overlap brings in, the shards are still the round robin of
+    the full stream, and without the hook only the FIRST epoch loads everything (the metadata is cached)."""
+    from qpnet_amd.config import PAPER
+    cfg = PAPER
+    U = cfg.upsampling_factor
+    rs = np.random.RandomState(3)
+    N, EPOCHS = 48, 3
+    data = [(rs.uniform(-1, 1, nf * U + 3).astype(np.float32), synth.make_features(nf, 300 + i, 45.0, 300.0)) for i, nf in enumerate(rs.randint(40, 90, size=N))]
+
+    class Utt:
+        def __init__(self, i):
+            self.i, self.calls, self.plans = i, 0, 0
+
+        def __call__(self):
+            self.calls += 1
+            return data[self.i]
+
+    class UttWithPlan(Utt):
+        def plan(self):
+            self.plans += 1
+            return len(data[self.i][0]), data[self.i][1]
+
+    class UttWithPart(UttWithPlan):                              # ... and a source that hands out slices (runners._FileUtterance: memory maps)
+        def part(self, s0, s1, f0, f1):
+            self.parts = getattr(self, "parts", 0) + 1
+            return data[self.i][0][s0:s1], data[self.i][1][f0:f1]
+
+    def run(cls, shard):
+        utts = [cls(i) for i in range(N)]
+        np.random.seed(7)
+        gen = loaders.train_generator(utts, cfg.receptiveCausal_field, cfg.receptiveF_field, cfg.receptiveA_field, 22050,
+                                      wav_transform=loaders.mu_law_transform(256), batch_length=20000, max_length=30000,
+                                      upsampling_factor=U, shuffle=True, epochs=EPOCHS, shard=shard)
+        out = list(gen)
+        assert loaders.train_generator.last_stats["loads"] == sum(u.calls for u in utts)
+        return out, sum(u.calls for u in utts), sum(u.plans for u in utts)
+    full, loads1, _ = run(Utt, None)
+    assert loads1 == N * EPOCHS and len(full) >= 40
+    frames_per_chunk = full[0][1].shape[2]
+    reach = int(np.ceil(frames_per_chunk / 40.0)) + 1            # utterances a chunk can reach into (shortest utterance: 40 frames)
+    for cls in (UttWithPart, UttWithPlan, Utt):
+        total = 0
+        for rank in range(8):
+            part, loads, plans = run(cls, (rank, 8))
+            want = full[rank::8]
+            assert len(part) == len(want) and all(all(torch.equal(u, v) for u, v in zip(a, b)) for a, b in zip(part, want))
+            total += len(part)
+            if cls is UttWithPart:
+                st = loaders.train_generator.last_stats
+                assert plans == N and loads == 0 and 0 < st["parts"] <= len(part) * reach      # slices only: a world-th of the bytes
+            elif cls is UttWithPlan:
+                assert plans == N                                # the plan of every utterance, once (not once per epoch)
+                assert loads <= len(part) * reach and loads <= loads1 // 8 + len(part) * 2, (rank, loads, len(part))
+            else:
+                assert loads <= N + len(part) * reach            # first epoch: everything once (that IS the plan); later epochs: its own only
+        assert total == len(full)
+
+
 # ---------------------------------------------------------------- pinned to the reference's own generators (generators.npz)
 def _sk_scaler(mean, scale):
     from sklearn.preprocessing import StandardScaler

@@ -23,6 +23,7 @@ from qpnet_amd.config import PAPER            # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=200)
+    ap.add_argument("--files", action="store_true", help="file-backed corpus (int16 .wav + .npy features in a temporary directory) through runners._utterance_loaders")
     args = ap.parse_args()
     import torch
     cfg = PAPER
@@ -32,6 +33,16 @@ def main():
     for i in range(24):
         nf = int(rs.randint(600, 1200))
         utts.append((rs.uniform(-1, 1, nf * U + 5).astype(np.float32), synth.make_features(nf, 400 + i)))
+    if args.files:
+        import tempfile
+        from scipy.io import wavfile
+        from qpnet_amd import runners
+        root = tempfile.mkdtemp(prefix="qpn_loader_rate_")
+        wavs, feats = [], []
+        for i, (x, h) in enumerate(utts):
+            wavs.append("%s/u%03d.wav" % (root, i)); feats.append("%s/u%03d.npy" % (root, i))
+            wavfile.write(wavs[-1], 22050, (x * 32767).astype(np.int16)); np.save(feats[-1], h)
+        utts = runners._utterance_loaders(wavs, feats, "world")
     mean, scale = synth.scaler_stats()
     scaler = lambda h: (h - mean) / scale      # noqa: E731
     dev = torch.device("cuda:0") if torch.cuda.is_available() else None
@@ -55,11 +66,15 @@ def main():
                 out = [t.to(dev, non_blocking=True) for t in (bx, bh, bt, bd)]
         if to_dev:
             torch.cuda.synchronize()
-        return args.chunks / (time.time() - t0)
+        r = args.chunks / (time.time() - t0)
+        rate.loads = loaders.train_generator.last_stats["loads"]
+        return r
 
+    print("corpus: %s" % ("24 utterances as .wav + .npy files (runners._FileUtterance: plan() = wav header + features)" if args.files else "24 utterances in memory"))
     print("train_generator, paper-size, batch_length 20000 (one host thread):")
     for shard in (None, (0, 2), (0, 4), (0, 8)):
-        print("  shard %-8s %8.1f chunks/s delivered to this rank (host only)" % (shard, rate(shard, False)))
+        r = rate(shard, False)
+        print("  shard %-8s %8.1f chunks/s delivered to this rank (host only); %d full utterance loads for %d chunks" % (shard, r, rate.loads, args.chunks + 1))
     if dev is not None:
         print("  shard None     %8.1f chunks/s incl. host-to-device copies from pageable memory (tensor.to)" % rate(None, True))
         print("  shard (0, 8)   %8.1f chunks/s incl. host-to-device copies from pageable memory" % rate((0, 8), True))
