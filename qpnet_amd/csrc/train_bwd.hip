@@ -1359,6 +1359,8 @@ int qpn_launch_grad_tail(const TrainParams& p, const TrainBwd& bw, const AuxGeom
 
 bool qpn_stack_bwd_fits(const TrainParams& p);
 int qpn_launch_stack_bwd(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
+bool qpn_stack_bwd_w_fits(const TrainParams& p);
+int qpn_launch_stack_bwd_w(const TrainParams& p, const TrainBwd& bw, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
 void qpn_launch_post_fb(const TrainParams& p, const TrainBwd& bw, hipStream_t stream) {
     constexpr int MTW = 5;
@@ -1492,7 +1494,10 @@ int qpn_launch_bwd(const TrainParams& p, const TrainBwd& bw, const TrainKnobs& k
     }
     const int swz = k.xcd_swizzle ? 1 : 0;
     if (p.hoist && !persist) { qpn_set_error("internal: the frame-rate aux term needs the register-resident layer kernels"); return QPN_EINVAL; }
-    if (stack_q) { const int rcq = qpn_launch_stack_bwd(p, bw, *sq, k, stream); if (rcq) return rcq; }
+    if (stack_q) {      // one wave per tile where that form exists (train_stackw.hip), else one workgroup per tile
+        const int rcq = (k.stack_wave_bwd && qpn_stack_bwd_w_fits(p)) ? qpn_launch_stack_bwd_w(p, bw, *sq, k, stream) : qpn_launch_stack_bwd(p, bw, *sq, k, stream);
+        if (rcq) return rcq;
+    }
     for (int l = L - 1; l >= 0 && !stack_q; --l) {
         const TrLayer& ly = p.layers[l];
         const int rows = N1 - ly.s_out;

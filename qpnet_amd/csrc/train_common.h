@@ -71,6 +71,10 @@ struct TrainParams {
     int wst_f4, p1t_f4, p2t_f4;       // bwd: [S x LC], [S x S], [Q x S]
     int bias_s, bias_p1, bias_p2;     // packed bias offsets (bias_s = sum over layers of skip biases)
     int64_t causal_w, causal_b, up_w, up_b;
+    // wave-per-tile stack kernels (train_stackw.hip; hoist form): per-layer weight images in A-operand order with the permuted k of fragA_pack, layer l at
+    // offset l * 4096 (w1q: the backward's 128 x 128 block d[x_cur | x_past] = dZ . W1^T; w1p: the forward's gate block) / l * 1024 (wrq / wrp: the 64 x 64 residual 1x1)
+    // float4 words behind these; -1: not packed
+    int w1q_f4, wrq_f4, w1p_f4, wrp_f4;
     TrLayer layers[TR_MAXL];
 };
 
@@ -136,6 +140,8 @@ struct TrainKnobs {
     bool ce_separate;                 // QPN_CE_SEPARATE=1: cross entropy as its own kernel behind the forward
     bool event_fence;                 // QPN_EVENT_FENCE=1: system-scope fence at the fork / join events
     bool aux_hoist;                   // QPN_AUX_HOIST=0: the auxiliary 1x1 contracted at sample rate (K = 176) even where the frame-rate form applies
+    bool stack_wave_fwd, stack_wave_bwd;   // QPN_STACK_WAVE_FWD=1 / QPN_STACK_WAVE_BWD=1: the transposed-product queue kernels of train_stackw.hip (opt-in experiments) instead of k_stack_fwd / k_stack_bwd
+    int stack_waves;                  // waves per workgroup (= per CU) of the wave-per-tile kernels: 4, one per SIMD
     bool test_stack_gives_up;         // -DQPN_TESTING builds only (QPN_TEST_STACK_GIVES_UP=1): the queue launches' published flags are made unrecognisable
 };
 void qpn_train_knobs_parse(TrainKnobs& k);

@@ -733,6 +733,8 @@ void qpn_launch_prep(const TrainParams& p, const AuxGeom& ag, hipStream_t stream
 
 bool qpn_stack_fwd_fits(const TrainParams& p);
 int qpn_launch_stack_fwd(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
+bool qpn_stack_fwd_t_fits(const TrainParams& p);
+int qpn_launch_stack_fwd_t(const TrainParams& p, const StackQ& q, const TrainKnobs& k, hipStream_t stream);
 
 void qpn_launch_post_fb(const TrainParams& p, const TrainBwd& bw, hipStream_t stream);      // train_bwd.hip: k_post_fb_w
 
@@ -755,7 +757,10 @@ int qpn_launch_fwd(const TrainParams& p, const TrainKnobs& k, const AuxGeom& ag,
         if (p.hoist && !persist) { qpn_set_error("internal: the frame-rate aux term needs the register-resident layer kernels"); return QPN_EINVAL; }
         // the whole stack as ONE persistent launch over a (layer, tile) work queue (train_stack.hip); QPN_STACK_QUEUE=0 keeps a launch per layer
         const bool stack_q = persist && k.stack_q_fwd && sq && sq->flags && p.qctl && qpn_stack_fwd_fits(p);
-        if (stack_q) { const int rcq = qpn_launch_stack_fwd(p, *sq, k, stream); if (rcq) return rcq; }
+        if (stack_q) {      // the transposed-product tile body where that form exists (train_stackw.hip), else the LDS-staged one
+            const int rcq = (k.stack_wave_fwd && qpn_stack_fwd_t_fits(p)) ? qpn_launch_stack_fwd_t(p, *sq, k, stream) : qpn_launch_stack_fwd(p, *sq, k, stream);
+            if (rcq) return rcq;
+        }
         for (int l = 0; l < p.L && !stack_q; ++l) {
             const int rows = p.N1 - p.layers[l].s_out;
             const int tiles = (rows + 15) / 16;

@@ -77,6 +77,10 @@ void qpn_train_knobs_parse(TrainKnobs& k) {
     k.ce_separate = getenv("QPN_CE_SEPARATE") != nullptr;
     k.event_fence = env_int("QPN_EVENT_FENCE", 0) == 1;
     k.aux_hoist = env_int("QPN_AUX_HOIST", 1) != 0;
+    // (both opt-in: correct, measured slower than k_stack_fwd / k_stack_bwd on the batch-1 chunk -- MEASUREMENTS R6.2)
+    k.stack_wave_fwd = env_int("QPN_STACK_WAVE_FWD", 0) != 0;
+    k.stack_wave_bwd = env_int("QPN_STACK_WAVE_BWD", 0) != 0;
+    k.stack_waves = 4;
     k.test_stack_gives_up = false;
 #ifdef QPN_TESTING
     k.test_stack_gives_up = env_int("QPN_TEST_STACK_GIVES_UP", 0) == 1;
@@ -189,6 +193,24 @@ static int frag_pack(std::vector<int>& map, int K, int N, F src) {
     return off4;
 }
 
+// W[m][k] (M x K, both multiples of 16) as the A operand of the TRANSPOSED products of train_stackw.hip: word ((s4 * M/16 + mt) * 64 + lane), element e
+// = W[16 mt + (lane & 15)][16 s4 + 4 (lane >> 4) + e] -- the k order in which a lane of the tile's B operand holds its row (four consecutive
+// channels of every sixteen per lane group).  Returns the float4 offset.
+template <class F>
+static int fragA_pack(std::vector<int>& map, int M, int K, F src) {
+    const int MT = M / 16, off4 = (int)(map.size() / 4);
+    map.resize(map.size() + (size_t)M * K);
+    int* mp = map.data() + (size_t)off4 * 4;
+    for (int s4 = 0; s4 < K / 16; ++s4)
+        for (int mt = 0; mt < MT; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e) {
+                    const int m = 16 * mt + (lane & 15), k = 16 * s4 + 4 * (lane >> 4) + e;
+                    mp[(((size_t)s4 * MT + mt) * 64 + lane) * 4 + e] = (int)src(m, k);
+                }
+    return off4;
+}
+
 static int train_init(qpn_handle* h) {
     if (h->train) return QPN_OK;
     const Geom& g = h->g;
@@ -242,6 +264,34 @@ static int train_init(qpn_handle* h) {
             if (y.adaptive) v.push_back((int)((half ? y.bTP : y.bSP) + r));
             return v; });
         ly.biasr = add_bias(C, [&](int n) { return std::vector<int>{(int)(y.resb + n)}; });
+    }
+    p.w1q_f4 = p.wrq_f4 = p.w1p_f4 = p.wrp_f4 = -1;
+    if (t->hoist) {      // images of the wave-per-tile stack kernels (train_stackw.hip): all layers of a kind contiguous, 4096 / 1024 float4 words each
+        auto w1of = [&](const LayerGeom& y, int k, int n) -> int64_t {      // the same B[k][n] of z = [x_cur | x_past] . W1 as w1src above (k < 2C)
+            const int half = n / C, r = n % C;
+            if (k < C) return y.adaptive ? (half ? y.wT : y.wS) + (int64_t)r * C + k : (half ? y.wT : y.wS) + ((int64_t)r * C + k) * 2 + 1;
+            const int kk = k - C; return y.adaptive ? (half ? y.wTP : y.wSP) + (int64_t)r * C + kk : (half ? y.wT : y.wS) + ((int64_t)r * C + kk) * 2;
+        };
+        for (int l = 0; l < L; ++l) {      // backward: out^T[n_in][row] = sum_kz W1[n_in][kz] dZ[row][kz]  -> A'[m = n_in][k = kz]
+            const LayerGeom y = g.layers[l];
+            const int o = fragA_pack(map, 2 * C, 2 * C, [&](int m, int k) { return w1of(y, m, k); });
+            if (l == 0) p.w1q_f4 = o;
+        }
+        for (int l = 0; l < L; ++l) {      // backward: dg^T[c][row] = sum_j res[j][c] dXout[row][j]  -> A'[m = c][k = j]
+            const LayerGeom y = g.layers[l];
+            const int o = fragA_pack(map, C, C, [&](int m, int k) { return y.res + (int64_t)k * C + m; });
+            if (l == 0) p.wrq_f4 = o;
+        }
+        for (int l = 0; l < L; ++l) {      // forward: z^T[nz][row] = sum_k W1[k][nz] [x_cur | x_past][row][k]  -> A'[m = nz][k = k_in]
+            const LayerGeom y = g.layers[l];
+            const int o = fragA_pack(map, 2 * C, 2 * C, [&](int m, int k) { return w1of(y, k, m); });
+            if (l == 0) p.w1p_f4 = o;
+        }
+        for (int l = 0; l < L; ++l) {      // forward: out^T[o][row] = sum_c res[o][c] g[row][c]  -> A'[m = o][k = c]
+            const LayerGeom y = g.layers[l];
+            const int o = fragA_pack(map, C, C, [&](int m, int k) { return y.res + (int64_t)m * C + k; });
+            if (l == 0) p.wrp_f4 = o;
+        }
     }
     p.ws_f4 = frag_pack(map, L * C, S, [&](int k, int n) { return g.layers[k / C].skip + (int64_t)n * C + (k % C); });
     p.wst_f4 = frag_pack(map, S, L * C, [&](int k, int n) { return g.layers[n / C].skip + (int64_t)k * C + (n % C); });
