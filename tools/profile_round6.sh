@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-5 rocprofv3 evidence on the GPU box:  QPN_COMMIT=<hash> bash tools/profile_round5.sh
+# round-6 rocprofv3 evidence on the GPU box:  QPN_COMMIT=<hash> bash tools/profile_round5.sh
 # kernel-trace stats and the PMC passes are separate runs (FETCH_SIZE / WRITE_SIZE cannot share a pass; no --pmc with trace domains).
-TAG=r05
+TAG=r06
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
