@@ -140,7 +140,7 @@ struct TrainKnobs {
     bool ce_separate;                 // QPN_CE_SEPARATE=1: cross entropy as its own kernel behind the forward
     bool event_fence;                 // QPN_EVENT_FENCE=1: system-scope fence at the fork / join events
     bool aux_hoist;                   // QPN_AUX_HOIST=0: the auxiliary 1x1 contracted at sample rate (K = 176) even where the frame-rate form applies
-    bool stack_wave_fwd, stack_wave_bwd;   // QPN_STACK_WAVE_FWD=1 / QPN_STACK_WAVE_BWD=1: the transposed-product queue kernels of train_stackw.hip (opt-in experiments) instead of k_stack_fwd / k_stack_bwd
+    int stack_wave_fwd; bool stack_wave_bwd;   // QPN_STACK_WAVE_FWD=1 / QPN_STACK_WAVE_BWD=1: the transposed-product queue kernels of train_stackw.hip (opt-in experiments) instead of k_stack_fwd / k_stack_bwd
     int stack_waves;                  // waves per workgroup (= per CU) of the wave-per-tile kernels: 4, one per SIMD
     bool test_stack_gives_up;         // -DQPN_TESTING builds only (QPN_TEST_STACK_GIVES_UP=1): the queue launches' published flags are made unrecognisable
 };

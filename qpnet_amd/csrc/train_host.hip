@@ -78,7 +78,7 @@ void qpn_train_knobs_parse(TrainKnobs& k) {
     k.event_fence = env_int("QPN_EVENT_FENCE", 0) == 1;
     k.aux_hoist = env_int("QPN_AUX_HOIST", 1) != 0;
     // (both opt-in: correct, measured slower than k_stack_fwd / k_stack_bwd on the batch-1 chunk -- MEASUREMENTS R6.2)
-    k.stack_wave_fwd = env_int("QPN_STACK_WAVE_FWD", 0) != 0;
+    k.stack_wave_fwd = env_int("QPN_STACK_WAVE_FWD", 0);      // 1: k_stack_fwd_t, 2: k_stack_fwd_h
     k.stack_wave_bwd = env_int("QPN_STACK_WAVE_BWD", 0) != 0;
     k.stack_waves = 4;
     k.test_stack_gives_up = false;

@@ -483,6 +483,209 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd_t(TrainParams p, StackQ q)
     if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
 }
 
+// ------------------------------------------------------------------------------------------------ forward: k_stack_fwd's skeleton, transposed products
+// k_stack_fwd<8> with the tile body of k_stack_fwd_t: the tile's rows are still requested ONCE per workgroup as whole 256-byte rows and staged in LDS
+// (k_stack_fwd_t's per-wave 64-byte pieces quadruple the row requests and cost it 60 % -- profiles/r06_stackw_probe.txt), but they are read back as the B
+// operand (eight ds_read_b128 a wave instead of thirty-two ds_read_b32), the gate epilogue works on registers in the row layout, sigma / gate product / block
+// output leave from registers, and the only other LDS traffic is the 4 KB gate tile every wave's residual 1x1 contracts over: two barriers and ~15 LDS
+// instructions a wave and tile instead of three and ~90.  Ticket ring, flag look, publish point and hand-over exactly as in k_stack_fwd.
+// dynamic LDS: As[2][16][136] | Gs[2][16][72] | control words
+__global__ __launch_bounds__(256, 2) void k_stack_fwd_h(TrainParams p, StackQ q) {
+    constexpr int C = 64, LDA = 136, GLD = 72;
+    extern __shared__ float smh[];
+    float* const Gs = smh + 2 * 16 * LDA;
+    int* const ctl = (int*)(Gs + 2 * 16 * GLD);       // [0..3] position ring, [4..7] / [12..15] per wave: flags missing, [8] arrivals at the publish point
+    const int N1 = p.N1, U = p.U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = sq_rfl(tid >> 6);
+    const int srow = tid >> 4, sc4 = tid & 15;                    // staging: thread -> (row, 16-byte piece) of the tile
+    const int row = lane & 15, g = lane >> 4, cw = 16 * wave + 4 * g;      // arithmetic: lane -> row `row`, channels cw .. cw + 3 of its wave's sixteen
+    const unsigned xbytes = (unsigned)N1 * C * 4u;
+    const size_t xlayer = (size_t)p.B * N1 * C;
+    auto xrsrc = [&](const float* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, xbytes, 0x00020000); };
+
+    float4 w1s[8], w1t[8], wra[4], bs4, bt4, bb4;
+    auto load_weights = [&](int l) {
+        const TrLayer ly = p.layers[l];
+        const float4* W1 = p.wp + p.w1p_f4 + (size_t)l * SW_W1F4 + lane; const float4* Wr = p.wp + p.wrp_f4 + (size_t)l * SW_WRF4 + lane;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) { w1s[s4] = W1[(s4 * 8 + wave) * 64]; w1t[s4] = W1[(s4 * 8 + 4 + wave) * 64]; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) wra[s4] = Wr[(s4 * 4 + wave) * 64];
+        bs4 = *(const float4*)(p.bp + ly.bias1 + cw); bt4 = *(const float4*)(p.bp + ly.bias1 + C + cw); bb4 = *(const float4*)(p.bp + ly.biasr + cw);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): waited for on the layer change's own path (see k_stack_fwd)
+    };
+    int tp = 0; float4 rc, rp, rpas, rpat; float rwjx = 0.f;                 // the next tile's rows (this thread's pieces) and aux operands (this lane's): requested at the end of a trip, used in the next
+    auto load_tap = [&](const SqTile& d, int& out) { const int n = d.n0 + srow; out = (p.TAP + d.tapb)[n < N1 ? n : N1 - 1]; };
+    auto load_rows = [&](const SqTile& d) {
+        const int n = d.n0 + srow, nn = n < N1 ? n : N1 - 1;
+        const auto rs = xrsrc(p.X + (size_t)d.xrow * C);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((unsigned)nn * C + 4u * sc4) * 4u), 0, SQ_SC1);
+        const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((unsigned)tp * C + 4u * sc4) * 4u), 0, SQ_SC1);
+        rc = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+        rp = make_float4(__uint_as_float(b4.x), __uint_as_float(b4.y), __uint_as_float(b4.z), __uint_as_float(b4.w));
+        // the frame slot and the upsampling weight of this LANE's row: j(n) = (F U - N1 + n) mod U, consecutive over the tile's rows (U >= 16: at most one wrap)
+        const int j0 = (int)((unsigned)(p.F * U - N1 + d.n0) % (unsigned)U), jr = j0 + row;
+        const float* pq = p.PA + d.hrow + (jr >= U ? 2 * C : 0) + cw;
+        rpas = *(const float4*)pq; rpat = *(const float4*)(pq + C);
+        rwjx = p.flat[p.up_w + (jr >= U ? jr - U : jr)];
+        __builtin_amdgcn_sched_barrier(0);                       // (all requests before anything waits for one of them)
+    };
+    auto store_rows = [&](const SqTile& d, float* As) {
+        asm volatile("" : "+v"(rpas.w), "+v"(rpat.w), "+v"(rwjx));      // (every request of the group is taken up here: see k_stack_fwd)
+        const bool in = d.n0 + srow < N1;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* dd = As + (size_t)srow * LDA + 4 * sc4;
+        *(float4*)dd = in ? rc : z; *(float4*)(dd + C) = in ? rp : z;
+    };
+    u32x4 xkeep = {0u, 0u, 0u, 0u};
+    auto publishes = [&](const SqTile& d) { return sq_valid(d) && !sq_last(d); };
+
+    int zero_v; asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
+    const int NQ = q.nq, sub = (blockIdx.x / 8) % NQ;
+    unsigned* const head = q.head + sub * TR_QHEAD_STRIDE + zero_v;
+    if (tid == 0) {
+        ctl[8] = 0;
+        const unsigned k0 = atomicAdd(head, 1u); ctl[0] = (int)(k0 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k1 = atomicAdd(head, 1u); ctl[1] = (int)(k1 * NQ + sub);
+        asm volatile("" ::: "memory");
+        const unsigned k2 = atomicAdd(head, 1u); ctl[2] = (int)(k2 * NQ + sub);
+    }
+    __syncthreads();
+    SqTile cur = sq_take(sq_fetch(q, sq_rfl(ctl[0]))), next = sq_take(sq_fetch(q, sq_rfl(ctl[1]))), nn = sq_take(sq_fetch(q, sq_rfl(ctl[2])));
+    if (!sq_valid(cur)) return;
+    SqTile prev = cur; prev.meta = 0;
+    int lw = sq_layer(cur);
+    load_weights(lw);
+    load_tap(cur, tp);
+    sq_wait(q, cur.dfirst, cur.dn, lane, p.status, 0u);
+    load_rows(cur);
+    store_rows(cur, smh);
+    load_tap(next, tp);
+    bool cur_published = false;
+    for (int it = 0;; ++it) {
+        const float* As = smh + (it & 1) * 16 * LDA;
+        float* const G = Gs + (it & 1) * 16 * GLD;
+        const bool last = sq_last(cur);
+        const int n = cur.n0 + row;
+        const bool in = n < N1;
+        unsigned rtk = 0;                                         // the position three tiles ahead (the raw ticket: see k_stack_fwd)
+        if (tid == 0) rtk = atomicAdd(head, 1u);
+        if (sq_layer(cur) != lw) { lw = sq_layer(cur); load_weights(lw); }
+        int tpn; load_tap(nn, tpn);
+        TR_LDS_BARRIER();                                          // B1: the tile's staged rows are complete
+        const bool pub_prev = publishes(prev) && !cur_published;
+        float4 xb[8];
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) xb[s4] = *(const float4*)(As + (size_t)row * LDA + 16 * s4 + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        SQ_PRIO(0);
+        f32x4 zs = (f32x4){0, 0, 0, 0}, zt = (f32x4){0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            zs = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[s4].x, xb[s4].x, zs, 0, 0, 0); zt = __builtin_amdgcn_mfma_f32_16x16x4f32(w1t[s4].x, xb[s4].x, zt, 0, 0, 0);
+            zs = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[s4].y, xb[s4].y, zs, 0, 0, 0); zt = __builtin_amdgcn_mfma_f32_16x16x4f32(w1t[s4].y, xb[s4].y, zt, 0, 0, 0);
+            zs = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[s4].z, xb[s4].z, zs, 0, 0, 0); zt = __builtin_amdgcn_mfma_f32_16x16x4f32(w1t[s4].z, xb[s4].z, zt, 0, 0, 0);
+            zs = __builtin_amdgcn_mfma_f32_16x16x4f32(w1s[s4].w, xb[s4].w, zs, 0, 0, 0); zt = __builtin_amdgcn_mfma_f32_16x16x4f32(w1t[s4].w, xb[s4].w, zt, 0, 0, 0);
+        }
+        SQ_PRIO(2);
+        __builtin_amdgcn_sched_barrier(0);
+        // publish point: younger than the previous tile's row stores are only this trip's tap load and, in wave 0, the ticket
+        __builtin_amdgcn_s_waitcnt(0x0F71);                        // vmcnt(1)
+        asm volatile("" :: "v"(xkeep));
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(ctl + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 xres = wave == 0 ? xb[0] : wave == 1 ? xb[1] : wave == 2 ? xb[2] : xb[3];      // x_cur of this lane's own channels: the residual path
+        const float bsv[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, btv[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+        const float psv[4] = {rpas.x, rpas.y, rpas.z, rpas.w}, ptv[4] = {rpat.x, rpat.y, rpat.z, rpat.w};
+        const float wjx = rwjx;
+        float sgv[4], gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float sg = sq_sigmoid((zs[i] + bsv[i]) + wjx * psv[i]), th = sq_tanh((zt[i] + btv[i]) + wjx * ptv[i]);
+            sgv[i] = sg; gv[i] = sg * th;
+        }
+        *(float4*)(G + row * GLD + cw) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        if (tid == 0) ctl[(it + 3) & 3] = (int)(rtk * NQ + sub);
+        TR_LDS_BARRIER();                                          // B2: the gate tile is complete
+        const SqRaw raw3 = sq_fetch(q, sq_rfl(ctl[(it + 3) & 3]));
+        const int fn = next.dn, fnm1 = fn > 0 ? fn - 1 : 0, fbase = fn > 0 ? next.dfirst : cur.pos;
+        unsigned fv0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), fv1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+        asm volatile("" ::: "memory");
+        f32x4 ar = (f32x4){0, 0, 0, 0};
+        if (!last) {
+            float4 gb[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) gb[s4] = *(const float4*)(G + row * GLD + 16 * s4 + 4 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            SQ_PRIO(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wra[s4].x, gb[s4].x, ar, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wra[s4].y, gb[s4].y, ar, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wra[s4].z, gb[s4].z, ar, 0, 0, 0);
+                ar = __builtin_amdgcn_mfma_f32_16x16x4f32(wra[s4].w, gb[s4].w, ar, 0, 0, 0);
+            }
+            SQ_PRIO(2);
+        }
+        asm volatile("" : "+v"(fv0), "+v"(fv1));                   // (the flag words are looked at HERE)
+        bool ready = fn == 0 || (fn <= 128 && __all(fv0 == q.epoch && fv1 == q.epoch));
+        // sigma / the gate product leave BEHIND the look at the flags (vmcnt counts in order); plain stores: later kernels read them
+        asm volatile("" ::: "memory");
+        {
+            float* const scr = p.scratch_rows + (size_t)blockIdx.x * 256 + 4 * lane;
+            float* sgp = in ? p.SG + (size_t)cur.xrow * C + (size_t)n * C + cw : scr;
+            float* thp = in ? p.TH + (size_t)cur.xrow * C + (size_t)n * C + cw : scr;
+#if !(SQ_EXP & 64)
+            *(float4*)sgp = make_float4(sgv[0], sgv[1], sgv[2], sgv[3]);
+            *(float4*)thp = make_float4(gv[0], gv[1], gv[2], gv[3]);
+#endif
+        }
+        if (lane == 0) ctl[4 + wave] = ready ? 0 : 1;
+        TR_LDS_BARRIER();                                          // B3: every wave knows whether all four found their flags
+        int any_slow = sq_rfl(ctl[4] | ctl[5] | ctl[6] | ctl[7]);
+        cur_published = false;
+        const u32x4 xo = {__float_as_uint((ar[0] + bb4.x) + xres.x), __float_as_uint((ar[1] + bb4.y) + xres.y), __float_as_uint((ar[2] + bb4.z) + xres.z), __float_as_uint((ar[3] + bb4.w) + xres.w)};
+        auto store_x = [&](bool go) {                             // the block output of cur -> X[l + 1], write-through, from the registers it was computed in
+            const unsigned o = (go && in && !(SQ_EXP & 128)) ? ((unsigned)n * C + (unsigned)cw) * 4u : SQ_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(xo, xrsrc(p.X + (size_t)cur.xrow * C + xlayer), (int)o, 0, SQ_SC1);
+            xkeep = xo;
+        };
+        if (any_slow) {
+            if (tid == 0) atomicAdd(q.stats + 2, 1u);
+            if (!ready) {
+                const unsigned g0 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane < fnm1 ? lane : fnm1)))), g1 = sq_ld(q.flags + sq_fidx((unsigned)(fbase + (lane + 64 < fnm1 ? lane + 64 : fnm1))));
+                ready = fn <= 128 && __all(g0 == q.epoch && g1 == q.epoch);
+            }
+            if (lane == 0) ctl[12 + wave] = ready ? 0 : 1;
+            TR_LDS_BARRIER();
+            any_slow = sq_rfl(ctl[12] | ctl[13] | ctl[14] | ctl[15]);
+        }
+        if (any_slow) {
+            // a producer of the next tile has not published yet: hand over everything this workgroup holds, THEN wait
+            if (tid == 0) atomicAdd(q.stats, 1u);
+            store_x(publishes(cur));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR_LDS_BARRIER();
+            if (tid == 0 && publishes(cur)) sq_st(q.flags + sq_fidx((unsigned)cur.pos), q.epoch_pub);
+            cur_published = true;
+            if (!ready) sq_wait(q, next.dfirst, next.dn, lane, p.status, 0u);
+        }
+        load_rows(next);                                           // ONE request site (see k_stack_fwd)
+        store_x(publishes(cur) && !any_slow);                     // ... and the block output leaves BEHIND them (vmcnt counts in order)
+        store_rows(next, smh + ((it + 1) & 1) * 16 * LDA);
+        tp = tpn;
+        prev = cur; cur = next; next = nn; nn = sq_take(raw3);
+        if (!sq_valid(cur)) break;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_LDS_BARRIER();
+    if (tid == 0 && publishes(prev) && !cur_published) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 bool qpn_stack_bwd_w_fits(const TrainParams& p) {
     return p.hoist && p.C == 64 && p.Ktp == 128 && p.w1q_f4 >= 0 && p.wrq_f4 >= 0 && p.U >= 16;
@@ -516,7 +719,10 @@ int qpn_launch_stack_fwd_t(const TrainParams& p, const StackQ& q, const TrainKno
 #ifdef QPN_TESTING
     if (k.test_stack_gives_up) { qq.epoch_pub = q.epoch ^ 0x55555555u; qq.spin_limit = 2000u; }
 #endif
-    hipLaunchKernelGGL(k_stack_fwd_t, dim3(G), dim3(256), lds, stream, p, qq);
+    if (k.stack_wave_fwd == 2) {
+        const size_t ldsh = (size_t)(2 * 16 * 136 + 2 * 16 * 72) * sizeof(float) + 64;
+        hipLaunchKernelGGL(k_stack_fwd_h, dim3(G), dim3(256), ldsh, stream, p, qq);
+    } else hipLaunchKernelGGL(k_stack_fwd_t, dim3(G), dim3(256), lds, stream, p, qq);
     return QPN_OK;
 }
 

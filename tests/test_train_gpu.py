@@ -188,7 +188,7 @@ def test_batch2_grads_specialised_and_generic_wgrad(cuda, monkeypatch):
                                    {"QPN_ZERO_IN_POST": "0"}, {"QPN_WR_SIDE": "0"}, {"QPN_WGRAD_CHUNKS_SIDE": "64"}, {"QPN_WGRAD_CHUNKS": "48", "QPN_WGRAD_CHUNKS_SIDE": "32"}, {"QPN_EVENT_FENCE": "1"},
                                    {"QPN_STACK_QUEUE_BWD": "0"}, {"QPN_STACK_QUEUE": "0"}, {"QPN_STACK_WGS_BWD": "512"}, {"QPN_STACK_WGS": "96", "QPN_STACK_WGS_BWD": "40"},
                                    {"QPN_AUX_HOIST": "0"}, {"QPN_AUX_HOIST": "0", "QPN_STACK_QUEUE": "0"}, {"QPN_LAYER_PERSIST": "0", "QPN_LAYER_BWD_PERSIST": "0"},
-                                   {"QPN_STACK_WAVE_BWD": "1"}, {"QPN_STACK_WAVE_FWD": "1"}, {"QPN_STACK_WAVE_FWD": "1", "QPN_STACK_WAVE_BWD": "1", "QPN_STACK_WGS": "96", "QPN_STACK_WGS_BWD": "40"}],
+                                   {"QPN_STACK_WAVE_BWD": "1"}, {"QPN_STACK_WAVE_FWD": "1"}, {"QPN_STACK_WAVE_FWD": "2"}, {"QPN_STACK_WAVE_FWD": "1", "QPN_STACK_WAVE_BWD": "1", "QPN_STACK_WGS": "96", "QPN_STACK_WGS_BWD": "40"}],
                          ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_backward_launch_arrangements_agree(knobs, cuda, monkeypatch):
     """Where the backward's launches run (side stream or not, early reduction, paired post-net contraction, zeroing inside k_post_bwd_w, the
