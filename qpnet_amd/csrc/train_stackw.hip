@@ -533,9 +533,10 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd_h(TrainParams p, StackQ q)
     auto store_rows = [&](const SqTile& d, float* As) {
         asm volatile("" : "+v"(rpas.w), "+v"(rpat.w), "+v"(rwjx));      // (every request of the group is taken up here: see k_stack_fwd)
         const bool in = d.n0 + srow < N1;
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         float* dd = As + (size_t)srow * LDA + 4 * sc4;
-        *(float4*)dd = in ? rc : z; *(float4*)(dd + C) = in ? rp : z;
+        // (component by component: a select between two float4 OBJECTS becomes a load through a selected address, i.e. both live in scratch memory)
+        *(float4*)dd = make_float4(in ? rc.x : 0.f, in ? rc.y : 0.f, in ? rc.z : 0.f, in ? rc.w : 0.f);
+        *(float4*)(dd + C) = make_float4(in ? rp.x : 0.f, in ? rp.y : 0.f, in ? rp.z : 0.f, in ? rp.w : 0.f);
     };
     u32x4 xkeep = {0u, 0u, 0u, 0u};
     auto publishes = [&](const SqTile& d) { return sq_valid(d) && !sq_last(d); };
@@ -598,7 +599,9 @@ __global__ __launch_bounds__(256, 2) void k_stack_fwd_h(TrainParams p, StackQ q)
             if ((old & 3) == 3 && pub_prev) sq_st(q.flags + sq_fidx((unsigned)prev.pos), q.epoch_pub);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const float4 xres = wave == 0 ? xb[0] : wave == 1 ? xb[1] : wave == 2 ? xb[2] : xb[3];      // x_cur of this lane's own channels: the residual path
+        // x_cur of this lane's own channels (the residual path): read again from the staged tile -- selecting xb[wave] makes the array a memory object
+        // (hipcc folds the select chain into ONE load through a selected address: the whole array went to scratch, every MFMA group behind a scratch load)
+        const float4 xres = *(const float4*)(As + (size_t)row * LDA + cw);
         const float bsv[4] = {bs4.x, bs4.y, bs4.z, bs4.w}, btv[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
         const float psv[4] = {rpas.x, rpas.y, rpas.z, rpas.w}, ptv[4] = {rpat.x, rpat.y, rpat.z, rpat.w};
         const float wjx = rwjx;
