@@ -716,6 +716,21 @@ static int pack_matrix(std::vector<int>& map, int rows, int K, int Kp, F src) {
     return off4;
 }
 
+// 16-row tiles as the MFMA's A operand (decode_coopb.hip).  ALL the fragments of one workgroup are contiguous (blocks of `per_w` float4 from `base4`: the
+// workgroup streams 1.5 MB per generated sample and should not walk a new page for every matrix); inside a block, the tile at `rel4` holds, per 16-deep
+// chunk c, word c * 64 + lane: element e = M[row m = lane & 15][16 c + 4 e + (lane >> 4)].  src(w, m, k) -> flat index, or -1 (a zero: padding rows)
+template <class F>
+static void fill_mtiles(std::vector<int>& map, size_t base4, size_t per_w, size_t rel4, int G, int R, F src) {
+    for (int w = 0; w < G; ++w) {
+        int* mm = map.data() + (base4 + (size_t)w * per_w + rel4) * 4;
+        for (int c = 0; c < R; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 4; ++e)
+                    mm[((size_t)c * 64 + lane) * 4 + e] = (int)src(w, lane & 15, 16 * c + 4 * e + (lane >> 4));
+    }
+}
+bool qpn_coopb_supported(const Geom& g);
+
 static int build_program(qpn_handle* h) {
     Geom& g = h->g;
     const int C = g.C, S = g.S, Q = g.Q, A = g.A, L = g.L;
@@ -749,6 +764,15 @@ static int build_program(qpn_handle* h) {
 
     // ---- packed weight tiles + task list
     std::vector<int>& map = h->h_map; map.clear();
+    const bool cb_ok = qpn_coopb_supported(g);
+    h->cb_ok = cb_ok; h->cb_groups = h->cb_per = 0;
+    const int cbG = C / 8, cbRC = g.Cp / 16, cbRS = g.Sp / 16;
+    const size_t cb_per_w = cb_ok ? ((size_t)3 * L * cbRC + 2 * cbRS) * 64 : 0;      // float4 per workgroup: three tiles per layer + the two post-net tiles
+    const size_t cb_base4 = map.size() / 4;
+    if (cb_ok) {
+        map.resize(map.size() + cb_per_w * cbG * 4, -1);
+        h->cb_base4 = (long long)cb_base4; h->cb_per_w = (int)cb_per_w;
+    }
     std::vector<std::vector<Task>> phases;
     auto tile_tasks = [&](std::vector<Task>& ph, int op, int off4, int rows, int Kp, int xoff, int a, int b, int c, int d, int flags) {
         const int R = Kp / 16, rpt = 64 / R, tiles = rows / rpt;
@@ -769,6 +793,16 @@ static int build_program(qpn_handle* h) {
         h->w_past_il[l] = pack_matrix(map, 2 * C, C, g.Cp, [&](int row, int k) { return srcw(row & 1, row >> 1, k, 1); });   // cooperative kernel: (sigma_c, tanh_c) rows together
         int off_res = pack_matrix(map, C, C, g.Cp, [&](int row, int k) { return y.res + (int64_t)row * C + k; });
         int off_skip = pack_matrix(map, S, C, g.Cp, [&](int row, int k) { return y.skip + (int64_t)row * C + k; });
+        if (cb_ok) {      // the batched cooperative kernel's A-operand fragments (decode_coopb.hip): workgroup w = channels 8 w .. 8 w + 7
+            const int SBc = S / cbG;
+            h->cb_zc[l] = (3 * l + 0) * cbRC * 64; h->cb_zp[l] = (3 * l + 1) * cbRC * 64; h->cb_rs[l] = (3 * l + 2) * cbRC * 64;      // (relative to the workgroup's block)
+            fill_mtiles(map, cb_base4, cb_per_w, h->cb_zc[l], cbG, cbRC, [&](int w, int m, int k) -> int64_t { return k < C ? srcw(m >> 3, 8 * w + (m & 7), k, 0) : -1; });
+            fill_mtiles(map, cb_base4, cb_per_w, h->cb_zp[l], cbG, cbRC, [&](int w, int m, int k) -> int64_t { return k < C ? srcw(m >> 3, 8 * w + (m & 7), k, 1) : -1; });
+            fill_mtiles(map, cb_base4, cb_per_w, h->cb_rs[l], cbG, cbRC, [&](int w, int m, int k) -> int64_t {
+                if (k >= C) return -1;
+                if (m < 8) return y.res + (int64_t)(8 * w + m) * C + k;
+                return m - 8 < SBc ? y.skip + (int64_t)(SBc * w + m - 8) * C + k : -1; });
+        }
         // Z phase: this step's pre-activations + the NEXT step's past-tap dots of the same layer (the
         // past rows are known one step early, so these tiles fill the waves the z tiles leave idle)
         std::vector<Task> zp, rp;
@@ -782,6 +816,12 @@ static int build_program(qpn_handle* h) {
         int other = last ? (y.adaptive ? (g.LF > 0 ? p.o_skf : -1) : -1) : 0;
         tile_tasks(rp, OP_SKIP, off_skip, S, g.Cp, p.o_g, acc, lds_bs[l], other, p.o_y1, last ? TF_LAST : 0);
         phases.push_back(zp); phases.push_back(rp);
+    }
+    if (cb_ok) {
+        const int SBc = S / cbG, QBc = Q / cbG;
+        h->cb_p1 = 3 * L * cbRC * 64; h->cb_p2 = h->cb_p1 + cbRS * 64;
+        fill_mtiles(map, cb_base4, cb_per_w, h->cb_p1, cbG, cbRS, [&](int w, int m, int k) -> int64_t { return (m < SBc && k < S) ? g.post1_w + (int64_t)(SBc * w + m) * S + k : -1; });
+        fill_mtiles(map, cb_base4, cb_per_w, h->cb_p2, cbG, cbRS, [&](int w, int m, int k) -> int64_t { return (m < QBc && k < S) ? g.post2_w + (int64_t)(QBc * w + m) * S + k : -1; });
     }
     int off_p1 = pack_matrix(map, S, S, g.Sp, [&](int row, int k) { return g.post1_w + (int64_t)row * S + k; });
     int off_p2 = pack_matrix(map, Q, S, g.Sp, [&](int row, int k) { return g.post2_w + (int64_t)row * S + k; });
@@ -836,6 +876,8 @@ int qpn_pipe_rows_resident(int n_cus);
 int qpn_launch_decode_pipe(qpn_handle* h, DecodeParams& p, int B, int groups, hipStream_t stream);
 int qpn_coop_group_size(const Geom& g, int limit);
 int qpn_launch_decode_coop(qpn_handle* h, DecodeParams& p, int B, int G, hipStream_t stream);
+bool qpn_coopb_supported(const Geom& g);
+int qpn_launch_decode_coopb(qpn_handle* h, DecodeParams& p, int B, hipStream_t stream);
 
 extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
     if (!out) { qpn_set_error("null out"); return QPN_EINVAL; }
@@ -854,6 +896,10 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
         k.generic = getenv("QPN_DECODE_GENERIC") != nullptr;
         k.no_resl = getenv("QPN_DECODE_NO_RESL") != nullptr;
         k.coop = 0; if (const char* e = getenv("QPN_DECODE_COOP")) k.coop = atoi(e) > 0 ? atoi(e) : 0;
+        // (measured on one MI355X, repo-default geometry, us per sample step of the batch, batched / per-utterance kernel: B = 4: 105 / 110, 8: 122 / 123, 16: 150 / 143,
+        //  20: 161 / 200, 32: 187 / 202, 37: 195 / 306, 64: 259 / 339 -- profiles/r06_coopb_batches.txt: above 16 rows the per-utterance groups shrink to 8 workgroups)
+        k.coopb = 17; if (const char* e = getenv("QPN_DECODE_COOPB")) k.coopb = atoi(e) > 0 ? atoi(e) : 0;
+        k.coopb_per = 0; if (const char* e = getenv("QPN_DECODE_COOPB_PER")) k.coopb_per = atoi(e);
         k.pipe = 1; if (const char* e = getenv("QPN_DECODE_PIPE")) k.pipe = atoi(e) != 0 ? 1 : 0;
         k.hybrid = getenv("QPN_DECODE_HYBRID") != nullptr;
         k.stamps = getenv("QPN_STAMPS") != nullptr;
@@ -1015,6 +1061,9 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     // (default: up to half the CUs for one utterance -- measured at C = 512, B = 1: 96.7 / 91.6 / 93.1 us per sample with 64 / 128 / 256 workgroups; QPN_DECODE_COOP=<G> asks for more)
     if (!h->single_cu_ok && coopG == 0) coopG = h->n_cus >= 128 ? h->n_cus / 2 : h->n_cus;
     if (force_one_cu && h->single_cu_ok) coopG = 0;
+    // wide geometries, batches: the utterances batched into the contractions (decode_coopb.hip) -- up to 16 per group of n_resch / 8 workgroups
+    const bool coopb = coopG > 0 && !force_one_cu && coop_limit == 0 && h->cb_ok && h->dk.coopb > 0 && B >= h->dk.coopb &&
+                       B <= 16 * (h->n_cus / (g.C / 8) > 0 ? h->n_cus / (g.C / 8) : 1) && h->n_cus >= g.C / 8;
     if (coopG > 0) {
         int cap = coopG; if (B < h->n_cus && h->n_cus / B < cap) cap = h->n_cus / B;       // the whole batch in one launch when it fits the chip
         if (coop_limit > 0 && cap > coop_limit) cap = coop_limit;                          // retry with fewer workgroups per utterance
@@ -1085,7 +1134,12 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
     char plan[160];
-    if (coopG) {
+    rc = coopb ? qpn_launch_decode_coopb(h, p, B, stream) : 1;      // (1: does not apply to this call)
+    if (rc < 0) return rc;
+    if (rc == 0) {
+        snprintf(plan, sizeof(plan), "coopb G=%d groups=%d x %d rows=%d", g.C / 8, h->cb_groups, h->cb_per, B);
+        h->call.multi_wg = 2; h->call.coopG = coopG > 2 ? coopG : 2;      // (a launch that gives up is re-run per utterance: decode_coop.hip)
+    } else if (coopG) {
         rc = qpn_launch_decode_coop(h, p, B, coopG, stream); if (rc) return rc;
         snprintf(plan, sizeof(plan), "coop G=%d rows=%d", coopG, B);
         h->call.multi_wg = coopG > 1 ? 2 : 0; h->call.coopG = coopG;

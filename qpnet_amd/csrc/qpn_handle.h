@@ -11,6 +11,8 @@ struct DecodeKnobs {
     bool generic;          // QPN_DECODE_GENERIC: the interpreter kernel k_decode instead of the straight-line k_decode_fast
     bool no_resl;          // QPN_DECODE_NO_RESL: no LDS-resident residual tiles in the one-CU kernel
     int coop;              // QPN_DECODE_COOP=<G>: cooperative decode with up to G workgroups per utterance (0: only where one CU cannot hold the state)
+    int coopb;             // QPN_DECODE_COOPB: smallest batch that takes the utterance-batched cooperative kernel (decode_coopb.hip) where it applies (default 17; 0 = never)
+    int coopb_per;         // QPN_DECODE_COOPB_PER (dev): utterances per group of that kernel (default: the batch spread over as many groups as fit the chip)
     int pipe;              // QPN_DECODE_PIPE: 0 = one-CU kernels, 1 / unset = the five-role pipelined kernel where it applies
     bool hybrid;           // QPN_DECODE_HYBRID (dev): rows beyond the pipelined capacity on one-CU kernels beside the launch
     bool stamps;           // QPN_STAMPS (dev, -DQPN_ENABLE_STAMPS builds)
@@ -56,7 +58,11 @@ struct qpn_handle {
     std::string plan;                // human-readable launch plan of the last decode (qpn_last_decode_plan)
     bool single_cu_ok;               // the step state fits one CU's LDS (decode.hip kernels); otherwise decode_coop.hip only
     int w_past_il[QPN_MAX_LAYERS];   // channel-interleaved past-tap tiles (cooperative kernel)
-    unsigned long long* d_xch; size_t xch_cap;   // exchange granules of the cooperative kernel
+    unsigned long long* d_xch; size_t xch_cap;   // exchange granules of the cooperative kernels
+    // batched cooperative kernel (decode_coopb.hip): workgroup w's A-operand fragments are the cb_per_w float4 from cb_base4 + w * cb_per_w of the packed weights;
+    // cb_zc.. = float4 offsets of the tiles inside that block; or cb_ok = false
+    bool cb_ok; int cb_zc[QPN_MAX_LAYERS], cb_zp[QPN_MAX_LAYERS], cb_rs[QPN_MAX_LAYERS], cb_p1, cb_p2; long long cb_base4; int cb_per_w;
+    int cb_groups, cb_per;                       // plan of the last batched launch
     bool decode_ok; std::string decode_err;   // geometries the decode kernels do not cover still train (and report why on decode calls)
     struct TrainState* train;        // lazily created by the training entry points (train_host.hip)
 };

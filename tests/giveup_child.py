@@ -1,6 +1,6 @@
 """Child process of the two give-up tests: runs with QPN_LIB = the -DQPN_TESTING build (qpnet_amd/libqpnet_hip_testing.so), the only
 build that contains the fault-injection hooks, and the hook's environment variable set by the parent.
-    python tests/giveup_child.py stack|pipe"""
+    python tests/giveup_child.py stack|pipe|coopb"""
 import os
 import sys
 
@@ -62,10 +62,32 @@ def pipe(cuda):
         np.testing.assert_array_equal(outs[k], oracle.decode(cfg, flat, h, d, x, n, maxd=maxd)["samples"])
 
 
+def coopb(cuda):
+    """The utterance-batched cooperative launch (decode_coopb.hip) that gives up is re-run on the per-utterance cooperative kernel (half the
+    workgroups per utterance), and the samples are the oracle's."""
+    import torch
+    import util
+    from oracle import cpu_oracle as oracle
+    from qpnet_amd import synth
+    from qpnet_amd.config import DEFAULT
+    cfg = DEFAULT
+    os.environ["QPN_DECODE_COOPB"] = "2"
+    specs = [(21, 1, 1.0), (22, 2, 1.5), (23, 1, 0.5)]
+    flat = synth.make_weights(cfg, 17)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = synth.decode_batch(cfg, specs)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    plan = m.last_decode_plan
+    assert plan.startswith("coopb ") and "timed out, retried: coop G=" in plan, plan
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+
+
 if __name__ == "__main__":
     import torch
     assert torch.cuda.is_available()
     from qpnet_amd import _lib
     assert _lib.LIB_PATH.endswith("libqpnet_hip_testing.so"), _lib.LIB_PATH
-    {"stack": stack, "pipe": pipe}[sys.argv[1]](torch.device("cuda:0"))
+    {"stack": stack, "pipe": pipe, "coopb": coopb}[sys.argv[1]](torch.device("cuda:0"))
     print("GIVEUP_CHILD_OK", sys.argv[1])

@@ -415,6 +415,85 @@ def test_default_geometry_decode_matches_reference_streams(case, cuda, golden_di
         np.testing.assert_array_equal(s, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="HIP vs reference stream, row %d" % i)
 
 
+# ---------------------------------------------------------------- the utterances batched into the contractions (decode_coopb.hip)
+def test_batched_cooperative_decode_vs_oracle(cuda, oracle, monkeypatch):
+    """Repo-default geometry, the batch as the N dimension of the fp32 MFMA (weights read once per sample step for a whole group of
+    utterances): ragged lengths, three F0 factors -- greedy streams bit-exact vs the CPU oracle; then sampling mode and teacher-forced
+    logits (bitwise) through the same kernel."""
+    import torch
+    from qpnet_amd.config import DEFAULT
+    monkeypatch.setenv("QPN_DECODE_COOPB", "1")
+    cfg = DEFAULT
+    flat = synth.make_weights(cfg, 19)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(41, 2, 1.0), (42, 1, 0.5), (43, 3, 1.5), (44, 1, 1.0), (45, 2, 0.5)])
+    xb, hb = torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda)
+    outs = m.batch_fast_generate(xb, hb, list(ns), bd, mode="argmax")
+    assert m.last_decode_plan.startswith("coopb G=64 groups="), m.last_decode_plan
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
+    assert [len(o) for o in outs] == sorted(ns)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+    m.sampling_seed = 77
+    outs = m.batch_fast_generate(xb[:2], hb[:2], list(ns[:2]), bd[:2], mode="sampling")
+    o_outs = oracle.batch_fast_generate(cfg, flat, bx[:2], bh[:2], list(ns[:2]), bd[:2], mode="sampling", seed=77)
+    for a, b in zip(outs, o_outs):
+        np.testing.assert_array_equal(a, b)
+    x, h, d, n = synth.decode_inputs(cfg, 1, 46, 1.0)
+    teacher = np.random.RandomState(3).randint(0, 256, size=n).astype(np.int64)
+    out, logits = m._stream_logits(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h[None]).to(cuda), d[None], torch.from_numpy(teacher[None]), n)
+    assert m.last_decode_plan.startswith("coopb "), m.last_decode_plan
+    r = oracle.decode(cfg, flat, h, d, x, n, teacher=teacher, want_logits=True)
+    assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
+
+
+@pytest.mark.parametrize("B", [20, 37])
+def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, monkeypatch):
+    """The reference's decode batch (20, runQP.py:66) and one that needs ten utterances per group: the batched kernel (default plan above 16
+    rows) draws the same samples as the per-utterance cooperative kernel (QPN_DECODE_COOPB=0), which the tests above pin to the oracle
+    and to the reference's own streams -- sampling mode, ragged lengths, rows finishing at different steps."""
+    import torch
+    from qpnet_amd.config import DEFAULT
+    cfg = DEFAULT
+    flat = synth.make_weights(cfg, 23)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(500 + b, 4 + b % 5, 0.5 + 0.25 * (b % 5)) for b in range(B)])
+    xb, hb = torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda)
+    res = {}
+    for name, knob in (("coopb", None), ("coop", "0")):
+        if knob is None:
+            monkeypatch.delenv("QPN_DECODE_COOPB", raising=False)
+        else:
+            monkeypatch.setenv("QPN_DECODE_COOPB", knob)
+        m = util.build_model(cfg, flat, cuda)
+        m.sampling_seed = 11
+        res[name] = (m.batch_fast_generate(xb, hb, list(ns), bd, mode="sampling"), m.last_decode_plan)
+    assert res["coopb"][1].startswith("coopb ") and res["coop"][1].startswith("coop G="), (res["coopb"][1], res["coop"][1])
+    for a, b in zip(res["coopb"][0], res["coop"][0]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("case", DECODE_CASES_D, ids=[c[0] for c in DECODE_CASES_D])
+def test_batched_cooperative_decode_matches_reference_streams(case, cuda, golden_dir, monkeypatch):
+    """decode_d.npz (greedy streams made by the REFERENCE itself on the repo-default geometry) through the batched kernel, bit-exact."""
+    import torch
+    monkeypatch.setenv("QPN_DECODE_COOPB", "1")
+    name, cfg, wseed, utts, extra = case
+    g = np.load(golden_dir + "/decode_d.npz")
+    m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, utts)
+    nlist = list(ns)
+    outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, bd, mode="argmax")
+    assert m.last_decode_plan.startswith("coopb "), m.last_decode_plan
+    assert nlist == list(g[name + "_nleft"])
+    for i, s_ in enumerate(outs):
+        np.testing.assert_array_equal(s_, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="batched HIP vs reference stream, row %d" % i)
+
+
+def test_batched_cooperative_launch_that_gives_up_is_rerun_per_utterance(cuda):
+    """tests/giveup_child.py `coopb` (the -DQPN_TESTING build's injected give-up): the batch is decoded again by decode_coop.hip."""
+    util.run_giveup_child("coopb", "QPN_TEST_PIPE_GIVES_UP")
+
+
 # ---------------------------------------------------------------- four pipelined workgroups per utterance, resident weights (decode_pipe.hip)
 _PAPER_CASES = [c for c in DECODE_CASES if c[0].startswith("paper")]
 
