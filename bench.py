@@ -547,7 +547,7 @@ def run_train(args, rank, local, world):
 def run_default_geometry(local):
     """SURVEY 8d "also report D": the geometry runQP.py instantiates (n_resch 512, 12 fixed + 4 adaptive layers, 24.2 M
     parameters; src/utils/param_model.py:58-64) -- training step on the LDS-tiled GEMM path (train_gemm.hip) and decode on
-    the cooperative multi-workgroup kernel (decode_coop.hip).  A few steps / 20-frame utterances: extra keys, not `value`."""
+    the cooperative multi-workgroup kernels (decode_coop.hip; batches above 16 rows: decode_coopb.hip).  A few steps / 500-frame utterances: extra keys, not `value`."""
     import ctypes as C
     import torch
     from qpnet_amd import synth, _lib
@@ -619,22 +619,31 @@ def run_default_geometry(local):
         torch.cuda.synchronize(); dtd = time.perf_counter() - t0
         us = m.last_decode_kernel_ms * 1e3 / max(ns)
         floor = n_edges * hop_us + stream_us          # the hops are serial; at B = 1 the stream of one step has nothing else to hide behind
+        plan = getattr(m, "last_decode_plan", "")
+        batched = plan.startswith("coopb ")
+        streams = int(plan.split("groups=")[1].split()[0]) if batched else B      # weight streams per sample step: one per group of workgroups
+        if batched:
+            note = ("k_decode_coopb (decode_coopb.hip): the utterances are the N dimension of v_mfma_f32_16x16x4_f32 (four chained MFMAs = the spec's 16-term fma chain, "
+                    "bit for bit; chunk accumulators added in the spec's tree order), a group of n_resch / 8 workgroups serves up to 16 utterances and streams the "
+                    "weights once per sample step for all of them; floor = (2L+3) x 1.46 us (profiles/r04_allgather_floor.txt) + 96.6 MB / 8.6 TB/s. "
+                    "What binds: the 2L+3 publish -> visible -> gathered -> barrier edges of a step (phase times: profiles/r06_coopb_phases.txt), whose gathers "
+                    "grow with the utterances of the group; per-utterance kernel at this batch: profiles/r06_coopb_batches.txt")
+        else:
+            note = ("floor = (2L+3) x 1.46 us (the kernel's own all-gather edge with no arithmetic and no weight stream, measured: "
+                    "profiles/r04_allgather_floor.txt -- 51 us per sample, i.e. above the 45.35 us of real time before a weight is read) + "
+                    "96.6 MB / 8.6 TB/s (Infinity-Cache gather rate, whole chip)")
         dec["batch%d" % B] = {"samples_per_s": sum(ns) / dtd, "us_per_sample_per_utterance": us, "real_time_factor": (sum(ns) / dtd / B) / 22050.0,
-                              "plan": getattr(m, "last_decode_plan", ""),
+                              "plan": plan, "kernel": "k_decode_coopb" if batched else "k_decode_coop",
                               "workload": "%d x %d-frame utterances (%d samples each)" % (B, FR, ns[0]),
                               "roofline": {"bound": "latency: %d dependent all-gathers per sample + the weight stream" % n_edges,
                                            "achieved": us, "floor": floor, "peak": floor, "unit": "us/sample/utterance", "frac": floor / us,
                                            "weight_stream_floor_us": stream_us, "handoff_floor_us": n_edges * hop_us,
-                                           "weights_MB_per_sample": w_bytes / 1e6,
-                                           "weight_stream_achieved_TBps": w_bytes * B / (us * 1e-6) / 1e12,
-                                           "note": "floor = (2L+3) x 1.46 us (the kernel's own all-gather edge with no arithmetic and no weight stream, measured: "
-                                                   "profiles/r04_allgather_floor.txt -- 51 us per sample, i.e. above the 45.35 us of real time before a weight is read) + "
-                                                   "96.6 MB / 8.6 TB/s (Infinity-Cache gather rate, whole chip); at B = 20 every utterance group re-streams the weights "
-                                                   "(weight_stream_achieved_TBps is the aggregate); sharing one stream among three utterances of a group was built and "
-                                                   "measured (profiles/r04_coop_shared_stream.txt): 97.8 -> 91.8 k samples/s, so at B = 20 neither the hops nor the stream "
-                                                   "bind but the instruction work of a row (FMA chunk + DPP tree) summed over the chip"}}
+                                           "weights_MB_per_sample": w_bytes / 1e6, "weight_streams_per_step": streams,
+                                           "weight_stream_achieved_TBps": w_bytes * streams / (us * 1e-6) / 1e12,
+                                           "note": note}}
     dec["reference_cpu_samples_per_s"] = 40
-    dec["kernel"] = "k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= CUs whose row slices are whole tiles)"
+    dec["kernel"] = ("up to 16 rows: k_decode_coop (G workgroups per utterance, G = largest power of two with B*G <= CUs whose row slices are whole tiles); "
+                     "above: k_decode_coopb (the rows batched into the MFMA's N dimension, n_resch / 8 workgroups per group of <= 16 rows)")
     out["decode"] = dec
     return out
 

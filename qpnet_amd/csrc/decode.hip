@@ -896,9 +896,9 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
         k.generic = getenv("QPN_DECODE_GENERIC") != nullptr;
         k.no_resl = getenv("QPN_DECODE_NO_RESL") != nullptr;
         k.coop = 0; if (const char* e = getenv("QPN_DECODE_COOP")) k.coop = atoi(e) > 0 ? atoi(e) : 0;
-        // (measured on one MI355X, repo-default geometry, us per sample step of the batch, batched / per-utterance kernel: B = 4: 105 / 110, 8: 122 / 123, 16: 150 / 143,
-        //  20: 161 / 200, 32: 187 / 202, 37: 195 / 306, 64: 259 / 339 -- profiles/r06_coopb_batches.txt: above 16 rows the per-utterance groups shrink to 8 workgroups)
-        k.coopb = 17; if (const char* e = getenv("QPN_DECODE_COOPB")) k.coopb = atoi(e) > 0 ? atoi(e) : 0;
+        // (measured on one MI355X, repo-default geometry, us per sample step of the whole batch, batched / per-utterance kernel: B = 1: 89 / 92, 2: 90 / 97, 4: 98 / 110,
+        //  8: 115 / 123, 16: 137 / 143, 20: 147 / 200, 32: 165 / 204, 64: 216 / 357 -- profiles/r06_coopb_batches.txt)
+        k.coopb = 1; if (const char* e = getenv("QPN_DECODE_COOPB")) k.coopb = atoi(e) > 0 ? atoi(e) : 0;
         k.coopb_per = 0; if (const char* e = getenv("QPN_DECODE_COOPB_PER")) k.coopb_per = atoi(e);
         k.pipe = 1; if (const char* e = getenv("QPN_DECODE_PIPE")) k.pipe = atoi(e) != 0 ? 1 : 0;
         k.hybrid = getenv("QPN_DECODE_HYBRID") != nullptr;

@@ -64,7 +64,7 @@ __device__ __forceinline__ void gb_store1(__amdgpu_buffer_rsrc_t rs, int goff, u
 // 2 pr + 1 of utterance n: one 16-byte load; each half carries its own tag, so a torn pair is simply read again); a thread owns the items (n0 + k * per, pr),
 // k = 0 .. NK - 1 (NK compiled for the group's size), and has them all in flight.  tags[n] == 0: the utterance has nothing here (a tap before time 1, or finished) -- zeros, no load.
 // IMG: into a B-operand image, else plain [n][count].
-struct GSrc { int src0, stride; const int* soff; const unsigned* tags; int hshift; int nocheck; };      // granule offset of utterance 0's vector, utterance stride, per-utterance slots, tags, log2(pairs)
+struct GSrc { int src0, stride; const int* soff; const unsigned* tags; int hshift; int nocheck; int nlo; };      // granule offset of utterance 0's vector, utterance stride, per-utterance slots, tags, log2(pairs), (dev) no tag check, first utterance of this call's share
 template <int NK> struct GBatch { u32x4 v[NK]; unsigned want[NK]; int voff[NK]; };
 template <int NK>
 __device__ __forceinline__ void g_issue(GBatch<NK>& b, __amdgpu_buffer_rsrc_t rs, const GSrc& s, int nb, int xt, int kb) {
@@ -72,7 +72,7 @@ __device__ __forceinline__ void g_issue(GBatch<NK>& b, __amdgpu_buffer_rsrc_t rs
     const int per = CBB_XT >> s.hshift, n0 = xt >> s.hshift, pr = xt & ((1 << s.hshift) - 1);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int n = n0 + (kb + k) * per;
+        const int n = s.nlo + n0 + (kb + k) * per;
         const bool in = n < nb;
         b.want[k] = in ? s.tags[n] : 0u;
         b.voff[k] = (s.src0 + (in ? n * s.stride + (s.soff ? s.soff[n] : 0) : 0) + 2 * pr) * 8;
@@ -103,7 +103,7 @@ __device__ __forceinline__ void g_finish(GBatch<NK>& b, __amdgpu_buffer_rsrc_t r
     const int per = CBB_XT >> s.hshift, n0 = xt >> s.hshift, pr = xt & ((1 << s.hshift) - 1);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const int n = n0 + (kb + k) * per;
+        const int n = s.nlo + n0 + (kb + k) * per;
         if (n < nb) {      // (an utterance without a tag loaded nothing: its registers are the zeros of g_issue)
             const float a = __uint_as_float(b.v[k].x), c = __uint_as_float(b.v[k].z);
             if (IMG) { const int d = img_idx(2 * pr, n); dstbase[d] = a; dstbase[d + 4 * CBB_NU] = c; }      // channel 2 pr + 1: the next k-slot
@@ -130,14 +130,14 @@ __device__ __forceinline__ void gather2_n(__amdgpu_buffer_rsrc_t rs, const GSrc&
     case 5: CALL(5, kb_); break; case 6: CALL(6, kb_); break; case 7: CALL(7, kb_); break; default: CALL(8, kb_); break; } } while (0)
 template <bool IMG>
 __device__ __forceinline__ void gather1(__amdgpu_buffer_rsrc_t rs, const GSrc& sa, float* da, int count, int nb, int xt, int* abort, int* status) {
-    const int per = CBB_XT >> sa.hshift, iters = (nb + per - 1) / per;
+    const int per = CBB_XT >> sa.hshift, iters = (nb - sa.nlo + per - 1) / per;
 #define CBB_G1(NK, KB) gather1_n<NK, IMG>(rs, sa, da, count, nb, xt, KB, abort, status)
     for (int kb = 0; kb < iters; kb += 8) { const int m = iters - kb; CBB_BY_ITEMS(m, kb, CBB_G1); }
 #undef CBB_G1
 }
 // two vectors of the same length at once (the second only if `two`)
 __device__ __forceinline__ void gather2(__amdgpu_buffer_rsrc_t rs, const GSrc& sa, float* da, const GSrc& sb, float* db, bool two, int count, int nb, int xt, int* abort, int* status) {
-    const int per = CBB_XT >> sa.hshift, iters = (nb + per - 1) / per;
+    const int per = CBB_XT >> sa.hshift, iters = (nb - sa.nlo + per - 1) / per;
 #define CBB_G2(NK, KB) gather2_n<NK>(rs, sa, da, sb, db, two, count, nb, xt, KB, abort, status)
     for (int kb = 0; kb < iters; kb += 8) { const int m = iters - kb; CBB_BY_ITEMS(m, kb, CBB_G2); }
 #undef CBB_G2
@@ -285,6 +285,10 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
 #endif
             __syncthreads();      // P1
             __syncthreads();      // P2
+            {      // (idle until P3: the past rows of layers 0 and 1, beside the exchange waves' gather of layer 0's input)
+                const GSrc sa = {LT(0, 0), ustride, smi + o_so, tags + CBB_NU, hC, NOCHK, 0}, sb = {LT(1, 0), ustride, smi + o_so + CBB_NU, tags + 2 * CBB_NU, hC, NOCHK, 0};
+                gather2(rs, sa, sm + o_xp, sb, sm + o_xp + IMG, true, C, nb, tid, c.abort, p.status);
+            }
             __syncthreads();      // P3: layer 0's input and the past rows of layers 0, 1 are in LDS
             {      // layer 0's past-row dot (the other layers': a layer ahead, between A and B)
                 const f32x4 part = wave_dot(an_p, sm + o_xp, RC, j4, lane);
@@ -295,10 +299,12 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 const bool has_res = l + 1 < L;
                 {      // this layer's current-row dot
                     const f32x4 part = wave_dot(an_c, sm + o_x, RC, j4, lane);
-                    load_frags(an_c, rw, has_res ? (unsigned)LT(l + 1, 3) : p1blk, has_res ? RC : RS, j4, lane);
                     *(f32x4*)(sm + o_part + j4 * 256 + lane * 4) = part;
                 }
                 __syncthreads();      // A
+                // (the next fragments are requested AFTER the barrier the dot product's consumers wait at: with the exchange waves' gathers in the CU's memory
+                //  pipeline, issuing eight loads took 0.4 us -- measured -- and the compute waves have slack in the phases that follow)
+                load_frags(an_c, rw, has_res ? (unsigned)LT(l + 1, 3) : p1blk, has_res ? RC : RS, j4, lane);
                 if (has_res) {        // the next layer's past-row dot (its rows arrived during the previous layer)
                     const f32x4 part = wave_dot(an_p, sm + o_xp + ((l + 1) & 1) * IMG, RC, j4, lane);
                     load_frags(an_p, rw, l + 2 < L ? (unsigned)LT(l + 2, 4) : p2blk, l + 2 < L ? RC : RS, j4, lane);
@@ -309,29 +315,33 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                     CB_C0();
                     const f32x4 part = wave_dot(an_r, sm + o_gv, RC, j4, lane);
                     CB_C(11);
-                    load_frags(an_r, rw, (unsigned)LT(has_res ? l + 1 : 0, 5), RC, j4, lane);
-                    CB_C(12);
                     *(f32x4*)(sm + o_part + j4 * 256 + lane * 4) = part;
                     CB_C(13);
                 }
                 __syncthreads();      // C
                 CB_C(14);
+                load_frags(an_r, rw, (unsigned)LT(has_res ? l + 1 : 0, 5), RC, j4, lane);
+                CB_C(12);
+                if (l + 2 < L) {      // (idle until D: the past rows of layer l + 2 -- rows of earlier steps, nothing to wait for -- so that the exchange waves gather one vector per edge)
+                    const GSrc sb = {LT(l + 2, 0), ustride, smi + o_so, tags + CBB_NU, hC, NOCHK, 0};
+                    gather1<true>(rs, sb, sm + o_xp + (l & 1) * IMG, C, nb, tid, c.abort, p.status);
+                }
                 __syncthreads();      // D: the next layer's input is in LDS
             }
             __syncthreads();          // T1: relu(skip total) of every utterance is in LDS
             {
                 const f32x4 part = wave_dot(an_c, sm + o_xp, RS, j4, lane);
-                load_frags(an_c, rw, (unsigned)LT(0, 3), RC, j4, lane);
                 *(f32x4*)(sm + o_part + j4 * 256 + lane * 4) = part;
             }
             __syncthreads();          // T2
+            load_frags(an_c, rw, (unsigned)LT(0, 3), RC, j4, lane);
             __syncthreads();          // T3
             {
                 const f32x4 part = wave_dot(an_p, sm + o_gv, RS, j4, lane);
-                load_frags(an_p, rw, (unsigned)LT(0, 4), RC, j4, lane);
                 *(f32x4*)(sm + o_part + j4 * 256 + lane * 4) = part;
             }
             __syncthreads();          // T4
+            load_frags(an_p, rw, (unsigned)LT(0, 4), RC, j4, lane);
             __syncthreads();          // T5
             __syncthreads();          // T6
             if (smi[o_ctl + 1]) break;            // a peer gave up: leave together
@@ -411,9 +421,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             __syncthreads();      // P2
             CB_T(1);
             {
-                const GSrc sa = {LT(0, 0), ustride, smi + o_so, tags + CBB_NU, hC, NOCHK}, sb = {LT(1, 0), ustride, smi + o_so + CBB_NU, tags + 2 * CBB_NU, hC, NOCHK};
-                gather2(rs, sa, sm + o_xp, sb, sm + o_xp + IMG, true, C, nb, xt, c.abort, p.status);
-                const GSrc sx = {LT(0, 6), ustride, nullptr, tags, hC, NOCHK};
+                const GSrc sx = {LT(0, 6), ustride, nullptr, tags, hC, NOCHK, 0};
                 gather1<true>(rs, sx, sm + o_x, C, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // P3
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 if (l + 2 < L) past_rows(l + 2, 0);
                 __syncthreads();      // A: the partial tiles of this layer's current-row dot are in LDS
                 CB_T(3);
-                // ---------------- gate of my channels -> all-gather; beside it the past rows of layer l + 2 and the aux terms of layer l + 1
+                // ---------------- gate of my channels -> all-gather; beside it the aux terms of layer l + 1 (the past rows of layer l + 2: the compute waves, between C and D)
                 float xres = 0.0f;
                 {      // one (channel, utterance) per thread of the first two exchange waves
                     int xv = xt; CBB_FRESH(xv);
@@ -439,8 +447,8 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 CB_T(4);
                 float aux_p = 0.0f, aux_q = 0.0f;      // the next layer's aux term: requested AFTER the gather (loads return in order: in front of it they would hold it up -- the
                 {                                      // weight stream evicts those rows from L2 every step), consumed after the next gather
-                    const GSrc sa = {c.o_g + l * C, ustride, nullptr, tags, hC, NOCHK}, sb = {l + 2 < L ? LT(l + 2, 0) : 0, ustride, smi + o_so, tags + CBB_NU, hC, NOCHK};
-                    gather2(rs, sa, sm + o_gv, sb, sm + o_xp + (l & 1) * IMG, l + 2 < L, C, nb, xt, c.abort, p.status);
+                    const GSrc sa = {c.o_g + l * C, ustride, nullptr, tags, hC, NOCHK, 0};
+                    gather1<true>(rs, sa, sm + o_gv, C, nb, xt, c.abort, p.status);
                     if (has_res && ak < nb && tags[ak]) { aux_p = p.pproj[(size_t)(smi[o_fr + ak] + l + 1) * (2 * C) + anat]; aux_q = p.qb[(l + 1) * 2 * C + anat]; }
                 }
                 __syncthreads();      // B
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 }
                 CB_T(7);
                 if (has_res) {
-                    const GSrc sa = {LT(l + 1, 6), ustride, nullptr, tags, hC, NOCHK};
+                    const GSrc sa = {LT(l + 1, 6), ustride, nullptr, tags, hC, NOCHK, 0};
                     gather1<true>(rs, sa, sm + o_x, C, nb, xt, c.abort, p.status);
                     sm[o_auxz + ((l + 1) & 1) * 256 + xt] = (ak < nb && tags[ak]) ? __builtin_fmaf(wj, aux_p, aux_q) : 0.0f;
                 }
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 }
             }
             {
-                const GSrc sa = {c.o_y1, ustride, nullptr, tags, hS, NOCHK};
+                const GSrc sa = {c.o_y1, ustride, nullptr, tags, hS, NOCHK, 0};
                 gather1<true>(rs, sa, sm + o_xp, S, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T1
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 int xv = xt; CBB_FRESH(xv);
                 const int m = xv >> 4, n = xv & 15;
                 if (m < SB && n < nb && tags[n]) { const float v = close_elem(sm + o_part, m, n) + sm[o_bp1 + m]; gb_store1(rs, n * ustride + c.o_y2 + s0 + m, tag, v > 0.0f ? v : 0.0f); }
-                const GSrc sa = {c.o_y2, ustride, nullptr, tags, hS, NOCHK};
+                const GSrc sa = {c.o_y2, ustride, nullptr, tags, hS, NOCHK, 0};
                 gather1<true>(rs, sa, sm + o_gv, S, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T3
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 const int m = xv >> 4, n = xv & 15;
                 if (m < QB && n < nb && tags[n]) gb_store1(rs, n * ustride + c.o_lg + q0 + m, tag, close_elem(sm + o_part, m, n) + sm[o_bp2 + m]);
                 // all logits of all utterances -> LDS [nb][Q] (plain): every workgroup derives the same next samples
-                const GSrc sa = {c.o_lg, ustride, nullptr, tags, hQ, NOCHK};
+                const GSrc sa = {c.o_lg, ustride, nullptr, tags, hQ, NOCHK, 0};
                 gather1<false>(rs, sa, sm + o_lg, Q, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T5

@@ -71,7 +71,7 @@ def coopb(cuda):
     from qpnet_amd import synth
     from qpnet_amd.config import DEFAULT
     cfg = DEFAULT
-    os.environ["QPN_DECODE_COOPB"] = "2"
+    os.environ.pop("QPN_DECODE_COOPB", None)
     specs = [(21, 1, 1.0), (22, 2, 1.5), (23, 1, 0.5)]
     flat = synth.make_weights(cfg, 17)
     m = util.build_model(cfg, flat, cuda)

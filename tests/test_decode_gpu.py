@@ -382,16 +382,19 @@ def test_cooperative_decode_sampling_and_logits(cuda, oracle, monkeypatch):
     assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
 
 
-def test_default_geometry_decode_vs_oracle(cuda, oracle):
-    """The repo-default QPNet (n_resch 512, 12 fixed + 4 adaptive layers: what runQP.py builds) decodes on the
-    cooperative kernel: greedy streams of two utterances of unequal length, bit-exact vs the CPU oracle."""
+def test_default_geometry_decode_vs_oracle(cuda, oracle, monkeypatch):
+    """The repo-default QPNet (n_resch 512, 12 fixed + 4 adaptive layers: what runQP.py builds) decodes on the per-utterance
+    cooperative kernel (QPN_DECODE_COOPB=0; the default plan's batched kernel: the tests further down): greedy streams of two
+    utterances of unequal length, bit-exact vs the CPU oracle."""
     import torch
     from qpnet_amd.config import DEFAULT
+    monkeypatch.setenv("QPN_DECODE_COOPB", "0")
     cfg = DEFAULT
     flat = synth.make_weights(cfg, 7)
     m = util.build_model(cfg, flat, cuda)
     bx, bh, bd, ns = util.decode_batch(cfg, [(11, 2, 1.0), (12, 3, 1.5)])
     outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), list(ns), bd, mode="argmax")
+    assert m.last_decode_plan.startswith("coop G="), m.last_decode_plan
     o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
     assert [len(o) for o in outs] == sorted(ns)
     for a, b in zip(outs, o_outs):
@@ -399,10 +402,11 @@ def test_default_geometry_decode_vs_oracle(cuda, oracle):
 
 
 @pytest.mark.parametrize("case", DECODE_CASES_D, ids=[c[0] for c in DECODE_CASES_D])
-def test_default_geometry_decode_matches_reference_streams(case, cuda, golden_dir):
+def test_default_geometry_decode_matches_reference_streams(case, cuda, golden_dir, monkeypatch):
     """the repo-default geometry against greedy streams made by the REFERENCE itself (decode_d.npz: 2 199 samples at
-    B=1; B=2 of unequal lengths at F0 x 1.5), bit-exact, completion order and list consumption included."""
+    B=1; B=2 of unequal lengths at F0 x 1.5), bit-exact, completion order and list consumption included -- per-utterance kernel."""
     import torch
+    monkeypatch.setenv("QPN_DECODE_COOPB", "0")
     name, cfg, wseed, utts, extra = case
     g = np.load(golden_dir + "/decode_d.npz")
     m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
@@ -422,7 +426,7 @@ def test_batched_cooperative_decode_vs_oracle(cuda, oracle, monkeypatch):
     logits (bitwise) through the same kernel."""
     import torch
     from qpnet_amd.config import DEFAULT
-    monkeypatch.setenv("QPN_DECODE_COOPB", "1")
+    monkeypatch.delenv("QPN_DECODE_COOPB", raising=False)      # the default plan of this geometry
     cfg = DEFAULT
     flat = synth.make_weights(cfg, 19)
     m = util.build_model(cfg, flat, cuda)
@@ -449,8 +453,8 @@ def test_batched_cooperative_decode_vs_oracle(cuda, oracle, monkeypatch):
 
 @pytest.mark.parametrize("B", [20, 37])
 def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, monkeypatch):
-    """The reference's decode batch (20, runQP.py:66) and one that needs ten utterances per group: the batched kernel (default plan above 16
-    rows) draws the same samples as the per-utterance cooperative kernel (QPN_DECODE_COOPB=0), which the tests above pin to the oracle
+    """The reference's decode batch (20, runQP.py:66) and one that needs ten utterances per group: the batched kernel (the default plan)
+    draws the same samples as the per-utterance cooperative kernel (QPN_DECODE_COOPB=0), which the tests above pin to the oracle
     and to the reference's own streams -- sampling mode, ragged lengths, rows finishing at different steps."""
     import torch
     from qpnet_amd.config import DEFAULT
@@ -474,9 +478,9 @@ def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, mon
 
 @pytest.mark.parametrize("case", DECODE_CASES_D, ids=[c[0] for c in DECODE_CASES_D])
 def test_batched_cooperative_decode_matches_reference_streams(case, cuda, golden_dir, monkeypatch):
-    """decode_d.npz (greedy streams made by the REFERENCE itself on the repo-default geometry) through the batched kernel, bit-exact."""
+    """decode_d.npz (greedy streams made by the REFERENCE itself on the repo-default geometry) through the batched kernel (the default plan), bit-exact."""
     import torch
-    monkeypatch.setenv("QPN_DECODE_COOPB", "1")
+    monkeypatch.delenv("QPN_DECODE_COOPB", raising=False)
     name, cfg, wseed, utts, extra = case
     g = np.load(golden_dir + "/decode_d.npz")
     m = util.build_model(cfg, synth.make_weights(cfg, wseed), cuda)
@@ -487,6 +491,39 @@ def test_batched_cooperative_decode_matches_reference_streams(case, cuda, golden
     assert nlist == list(g[name + "_nleft"])
     for i, s_ in enumerate(outs):
         np.testing.assert_array_equal(s_, g["%s_out%d" % (name, i)].astype(np.int64), err_msg="batched HIP vs reference stream, row %d" % i)
+
+
+def test_batched_cooperative_decode_other_widths_vs_oracle(cuda, oracle, monkeypatch):
+    """n_resch 256 / n_skipch 512 (16-chunk current taps, 32-chunk post-net, 128-pair gathers, 16 skip and 8 logit rows per workgroup of 32),
+    asked for with QPN_DECODE_COOP (one CU could hold this state): three utterances, greedy and sampling, vs the oracle; and upsampling
+    factor 0 on the default widths (aux features at sample rate)."""
+    import dataclasses
+    import torch
+    from qpnet_amd.config import QPNetConfig
+    monkeypatch.setenv("QPN_DECODE_COOP", "32")
+    monkeypatch.delenv("QPN_DECODE_COOPB", raising=False)
+    cfg = QPNetConfig(n_resch=256, n_skipch=256, dilationF_depth=2, dilationF_repeat=1, dilationA_depth=2, dilationA_repeat=2)
+    flat = synth.make_weights(cfg, 29)
+    m = util.build_model(cfg, flat, cuda)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(61, 2, 1.0), (62, 3, 0.5), (63, 1, 1.5)])
+    xb, hb = torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda)
+    for mode in ("argmax", "sampling"):
+        m.sampling_seed = 5
+        outs = m.batch_fast_generate(xb, hb, list(ns), bd, mode=mode)
+        assert m.last_decode_plan.startswith("coopb G=32 "), m.last_decode_plan
+        o_outs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd, mode=mode, seed=5)
+        for a, b in zip(outs, o_outs):
+            np.testing.assert_array_equal(a, b)
+    monkeypatch.delenv("QPN_DECODE_COOP", raising=False)
+    cfg_u = QPNetConfig(dilationF_depth=2, dilationF_repeat=1, dilationA_depth=2, dilationA_repeat=1)
+    cfg0 = dataclasses.replace(cfg_u, upsampling_factor=0)
+    flat0 = synth.make_weights(cfg0, 31)
+    m0 = util.build_model(cfg0, flat0, cuda)
+    x, h, d, n = synth.decode_inputs(cfg_u, 2, 71, 1.0)
+    h0 = np.ascontiguousarray(np.repeat(h, cfg_u.upsampling_factor, axis=1))          # (n_aux, T): one feature column per sample
+    y = m0.batch_fast_generate(torch.from_numpy(x[None]).to(cuda), torch.from_numpy(h0[None]).to(cuda), [n], d[None], mode="argmax")[0]
+    assert m0.last_decode_plan.startswith("coopb G=64 "), m0.last_decode_plan
+    np.testing.assert_array_equal(y, oracle.decode(cfg0, flat0, h0, d, x, n)["samples"])
 
 
 def test_batched_cooperative_launch_that_gives_up_is_rerun_per_utterance(cuda):

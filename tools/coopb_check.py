@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--frames", type=int, default=6)
     ap.add_argument("--time-frames", type=int, default=200)
     ap.add_argument("--batches", default="4,5,20,37")
+    ap.add_argument("--time-batches", dest="time_batches", default="4,8,16,20,32,64")
     args = ap.parse_args()
     import torch
     from qpnet_amd import synth
@@ -45,7 +46,7 @@ def main():
         xb, hb = torch.from_numpy(bx).to(dev), torch.from_numpy(bh).to(dev)
         for mode in ("argmax", "sampling"):
             res = {}
-            for name, knob in (("coopb", None), ("coop", 0)):
+            for name, knob in (("coopb", 1), ("coop", 0)):
                 m = build(cfg, flat, dev, knob)
                 m.sampling_seed = 5
                 outs = m.batch_fast_generate(xb, hb, list(ns), bd, mode=mode)
@@ -61,12 +62,12 @@ def main():
             print("B=%d %s: %s  [%s | %.2f ms] vs [%s | %.2f ms]%s" % (B, mode, "same" if same else "DIFFERENT", res["coopb"][1], res["coopb"][2],
                                                                  res["coop"][1], res["coop"][2], first), flush=True)
     # timing: equal-length utterances
-    for B in (4, 8, 16, 20, 32, 64):
+    for B in [int(b) for b in args.time_batches.split(",")]:
         utts = [(100 + b, args.time_frames, 1.0) for b in range(B)]
         bx, bh, bd, ns = synth.decode_batch(cfg, utts)
         xb, hb = torch.from_numpy(bx).to(dev), torch.from_numpy(bh).to(dev)
         line = "B=%d x %d samples:" % (B, ns[0])
-        for name, knob in (("coopb", None), ("coop", 0)):
+        for name, knob in (("coopb", 1), ("coop", 0)):
             m = build(cfg, flat, dev, knob)
             m.batch_fast_generate(xb, hb, list(ns), bd, mode="argmax")
             torch.cuda.synchronize(); t0 = time.perf_counter()

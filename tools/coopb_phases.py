@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    os.environ.setdefault("QPN_DECODE_COOPB", "1")      # (the batched kernel at every batch size)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     import torch
