@@ -900,6 +900,10 @@ extern "C" int qpn_create(const qpn_config* cfg, qpn_handle** out) {
         //  8: 115 / 123, 16: 137 / 143, 20: 147 / 200, 32: 165 / 204, 64: 216 / 357 -- profiles/r06_coopb_batches.txt)
         k.coopb = 1; if (const char* e = getenv("QPN_DECODE_COOPB")) k.coopb = atoi(e) > 0 ? atoi(e) : 0;
         k.coopb_per = 0; if (const char* e = getenv("QPN_DECODE_COOPB_PER")) k.coopb_per = atoi(e);
+        k.coopb_delay[0] = 8; k.coopb_delay[1] = 4; k.coopb_delay[2] = 0;
+        if (const char* e = getenv("QPN_COOPB_DELAY_G")) k.coopb_delay[0] = atoi(e);
+        if (const char* e = getenv("QPN_COOPB_DELAY_X")) k.coopb_delay[1] = atoi(e);
+        if (const char* e = getenv("QPN_COOPB_DELAY_T")) k.coopb_delay[2] = atoi(e);
         k.pipe = 1; if (const char* e = getenv("QPN_DECODE_PIPE")) k.pipe = atoi(e) != 0 ? 1 : 0;
         k.hybrid = getenv("QPN_DECODE_HYBRID") != nullptr;
         k.stamps = getenv("QPN_STAMPS") != nullptr;

@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct CoopbParams {
     u64* xch; long utt_stride;
     int o_ring[QPN_MAX_LAYERS]; int o_g, o_y1, o_y2, o_lg;
-    int* abort; unsigned wpk_bytes; long long base4; int per_w, dev_nostream, dev_nocheck;      // workgroup w's fragments: per_w float4 from base4 + w * per_w
+    int* abort; unsigned wpk_bytes; long long base4; int per_w, dev_nostream, dev_nocheck, poll_delay_g, poll_delay_x, poll_delay_t;      // workgroup w's fragments: per_w float4 from base4 + w * per_w
     int G, SB, QB, NBper, B;          // workgroups of a group (8 channels each); skip / logit rows per workgroup; utterances per group; utterances of the call
     int RC, RS;                       // 16-deep chunks of K = n_resch / K = n_skipch
     int zc[QPN_MAX_LAYERS], zp[QPN_MAX_LAYERS], rs[QPN_MAX_LAYERS], p1, p2;      // float4 offsets of the A-operand tiles inside the workgroup's fragment block: word chunk * 64 + lane
@@ -448,6 +448,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 float aux_p = 0.0f, aux_q = 0.0f;      // the next layer's aux term: requested AFTER the gather (loads return in order: in front of it they would hold it up -- the
                 {                                      // weight stream evicts those rows from L2 every step), consumed after the next gather
                     const GSrc sa = {c.o_g + l * C, ustride, nullptr, tags, hC, NOCHK, 0};
+                    for (int i = 0; i < c.poll_delay_g; ++i) __builtin_amdgcn_s_sleep(2);
                     gather1<true>(rs, sa, sm + o_gv, C, nb, xt, c.abort, p.status);
                     if (has_res && ak < nb && tags[ak]) { aux_p = p.pproj[(size_t)(smi[o_fr + ak] + l + 1) * (2 * C) + anat]; aux_q = p.qb[(l + 1) * 2 * C + anat]; }
                 }
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 CB_T(7);
                 if (has_res) {
                     const GSrc sa = {LT(l + 1, 6), ustride, nullptr, tags, hC, NOCHK, 0};
+                    for (int i = 0; i < c.poll_delay_x; ++i) __builtin_amdgcn_s_sleep(2);
                     gather1<true>(rs, sa, sm + o_x, C, nb, xt, c.abort, p.status);
                     sm[o_auxz + ((l + 1) & 1) * 256 + xt] = (ak < nb && tags[ak]) ? __builtin_fmaf(wj, aux_p, aux_q) : 0.0f;
                 }
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             }
             {
                 const GSrc sa = {c.o_y1, ustride, nullptr, tags, hS, NOCHK, 0};
+                for (int i = 0; i < c.poll_delay_t; ++i) __builtin_amdgcn_s_sleep(2);
                 gather1<true>(rs, sa, sm + o_xp, S, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T1
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 const int m = xv >> 4, n = xv & 15;
                 if (m < SB && n < nb && tags[n]) { const float v = close_elem(sm + o_part, m, n) + sm[o_bp1 + m]; gb_store1(rs, n * ustride + c.o_y2 + s0 + m, tag, v > 0.0f ? v : 0.0f); }
                 const GSrc sa = {c.o_y2, ustride, nullptr, tags, hS, NOCHK, 0};
+                for (int i = 0; i < c.poll_delay_t; ++i) __builtin_amdgcn_s_sleep(2);
                 gather1<true>(rs, sa, sm + o_gv, S, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T3
@@ -507,6 +511,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 if (m < QB && n < nb && tags[n]) gb_store1(rs, n * ustride + c.o_lg + q0 + m, tag, close_elem(sm + o_part, m, n) + sm[o_bp2 + m]);
                 // all logits of all utterances -> LDS [nb][Q] (plain): every workgroup derives the same next samples
                 const GSrc sa = {c.o_lg, ustride, nullptr, tags, hQ, NOCHK, 0};
+                for (int i = 0; i < c.poll_delay_t; ++i) __builtin_amdgcn_s_sleep(2);
                 gather1<false>(rs, sa, sm + o_lg, Q, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // T5
@@ -588,6 +593,10 @@ int qpn_launch_decode_coopb(qpn_handle* h, DecodeParams& p, int B, hipStream_t s
     }
     c.xch = h->d_xch + 16; c.abort = (int*)h->d_xch;
     const size_t lds_bytes = (size_t)cbb_lds_floats(C, L) * sizeof(float);
+    // first poll of an edge's gather: 8 / 4 x 128 clocks after the exchange waves reach it (QPN_COOPB_DELAY_G / _X / _T, dev).  Polls sent before anything can have been
+    // published return stale a round trip later and load the memory side the publishes go through: B = 20: 151 -> 113 us per step, B = 4: 98.6 -> 91.3, B = 64: 220 -> 189
+    // (tools/coopb_delay_sweep.py, profiles/r06_coopb_poll_delay.txt)
+    c.poll_delay_g = h->dk.coopb_delay[0]; c.poll_delay_x = h->dk.coopb_delay[1]; c.poll_delay_t = h->dk.coopb_delay[2];
 #ifdef QPN_ENABLE_STAMPS
     c.dev_nostream = getenv("QPN_COOPB_NOSTREAM") ? 1 : 0; c.dev_nocheck = getenv("QPN_COOPB_NOCHECK") ? 1 : 0;
 #endif

@@ -12,6 +12,7 @@ struct DecodeKnobs {
     bool no_resl;          // QPN_DECODE_NO_RESL: no LDS-resident residual tiles in the one-CU kernel
     int coop;              // QPN_DECODE_COOP=<G>: cooperative decode with up to G workgroups per utterance (0: only where one CU cannot hold the state)
     int coopb;             // QPN_DECODE_COOPB: smallest batch that takes the utterance-batched cooperative kernel (decode_coopb.hip) where it applies (default 1: always; 0 = never -- the per-utterance kernel decode_coop.hip)
+    int coopb_delay[3];    // QPN_COOPB_DELAY_G / _X / _T (dev): first poll of the gate / block-output / post-net gathers of that kernel, x 128 clocks after the exchange waves reach it (8 / 4 / 0)
     int coopb_per;         // QPN_DECODE_COOPB_PER (dev): utterances per group of that kernel (default: the batch spread over as many groups as fit the chip)
     int pipe;              // QPN_DECODE_PIPE: 0 = one-CU kernels, 1 / unset = the five-role pipelined kernel where it applies
     bool hybrid;           // QPN_DECODE_HYBRID (dev): rows beyond the pipelined capacity on one-CU kernels beside the launch
