@@ -48,6 +48,10 @@ __device__ __forceinline__ void pst(u64* g, unsigned tag, float v) {
     __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 pld(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef PIPE_POLL_SLEEP
+#define PIPE_POLL_SLEEP 0             // s_sleep between two polls of a wait (x 64 clocks; dev: -DPIPE_POLL_SLEEP=<n> build variants, tools/pipe_poll_sleep.sh)
+#endif
+__device__ __forceinline__ void ppause() { if (PIPE_POLL_SLEEP) __builtin_amdgcn_s_sleep(PIPE_POLL_SLEEP); }
 // wait for ONE granule of step `tag`; returns its value (on timeout / abort: raises the flag and returns what is there)
 __device__ __forceinline__ float pwait(const u64* g, unsigned tag, int* abort, int* status) {
     u64 v = pld(g);
@@ -58,6 +62,7 @@ __device__ __forceinline__ float pwait(const u64* g, unsigned tag, int* abort, i
             atomicOr(status, 4);
             break;
         }
+        ppause();
         v = pld(g);
     }
     return __uint_as_float((unsigned)v);
@@ -72,6 +77,7 @@ __device__ __forceinline__ float2 pwait2(const u64* g0, const u64* g1, unsigned 
             atomicOr(status, 4);
             break;
         }
+        ppause();
         v0 = pld(g0); v1 = pld(g1);
     }
     return make_float2(__uint_as_float((unsigned)v0), __uint_as_float((unsigned)v1));
@@ -506,6 +512,7 @@ __device__ __forceinline__ void post2_pick_role(const DecodeParams& p, const Fas
                         atomicOr(p.status, 4);
                         break;
                     }
+                    ppause();
                     v0 = pld(g); v1 = pld(g + 64); v2 = pld(g + 128); v3 = pld(g + 192);
                 }
                 sm[vb + o_y2 + lane] = __uint_as_float((unsigned)v0); sm[vb + o_y2 + 64 + lane] = __uint_as_float((unsigned)v1);
