@@ -125,14 +125,17 @@ __device__ __forceinline__ void gather2_n(__amdgpu_buffer_rsrc_t rs, const GSrc&
     g_finish<NK, true>(a, rs, sa, da, count, nb, xt, kb, abort, status);
     if (two) g_finish<NK, true>(b, rs, sb, db, count, nb, xt, kb, abort, status);
 }
-// (the poll loop's instruction count is on the critical path of every exchange: it is compiled for exactly 1 .. 8 items per thread; larger groups take two rounds)
+// (the poll loop's instruction count is on the critical path of every exchange: it is compiled for exactly 1 .. 8 items per thread, and for 10 and 12; 13 .. 16 take two rounds)
 #define CBB_BY_ITEMS(n_, kb_, CALL) do { switch (n_) { case 1: CALL(1, kb_); break; case 2: CALL(2, kb_); break; case 3: CALL(3, kb_); break; case 4: CALL(4, kb_); break; \
     case 5: CALL(5, kb_); break; case 6: CALL(6, kb_); break; case 7: CALL(7, kb_); break; default: CALL(8, kb_); break; } } while (0)
 template <bool IMG>
 __device__ __forceinline__ void gather1(__amdgpu_buffer_rsrc_t rs, const GSrc& sa, float* da, int count, int nb, int xt, int* abort, int* status) {
     const int per = CBB_XT >> sa.hshift, iters = (nb - sa.nlo + per - 1) / per;
 #define CBB_G1(NK, KB) gather1_n<NK, IMG>(rs, sa, da, count, nb, xt, KB, abort, status)
-    for (int kb = 0; kb < iters; kb += 8) { const int m = iters - kb; CBB_BY_ITEMS(m, kb, CBB_G1); }
+    if (iters <= 8) { CBB_BY_ITEMS(iters, 0, CBB_G1); }
+    else if (iters <= 10) CBB_G1(10, 0);      // (groups of 9..16 utterances: still one round -- a second one costs a round trip per edge)
+    else if (iters <= 12) CBB_G1(12, 0);
+    else { CBB_G1(8, 0); const int m = iters - 8; CBB_BY_ITEMS(m, 8, CBB_G1); }      // (16 in flight spill)
 #undef CBB_G1
 }
 // two vectors of the same length at once (the second only if `two`)

@@ -451,7 +451,7 @@ def test_batched_cooperative_decode_vs_oracle(cuda, oracle, monkeypatch):
     assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
 
 
-@pytest.mark.parametrize("B", [20, 37])
+@pytest.mark.parametrize("B", [20, 37, 6])
 def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, monkeypatch):
     """The reference's decode batch (20, runQP.py:66) and one that needs ten utterances per group: the batched kernel (the default plan)
     draws the same samples as the per-utterance cooperative kernel (QPN_DECODE_COOPB=0), which the tests above pin to the oracle
@@ -460,7 +460,8 @@ def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, mon
     from qpnet_amd.config import DEFAULT
     cfg = DEFAULT
     flat = synth.make_weights(cfg, 23)
-    bx, bh, bd, ns = util.decode_batch(cfg, [(500 + b, 4 + b % 5, 0.5 + 0.25 * (b % 5)) for b in range(B)])
+    frames = (lambda b: 30 + 3 * b) if B == 6 else (lambda b: 4 + b % 5)      # (B = 6: up to 4 949 samples a row -- every pitch ring wraps several times)
+    bx, bh, bd, ns = util.decode_batch(cfg, [(500 + b, frames(b), 0.5 + 0.25 * (b % 5)) for b in range(B)])
     xb, hb = torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda)
     res = {}
     for name, knob in (("coopb", None), ("coop", "0")):
