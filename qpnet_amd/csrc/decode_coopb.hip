@@ -47,7 +47,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CBB_FRESH(x) asm volatile("" : "+v"(x))
 
 __host__ __device__ static inline int cbb_lds_floats(int C, int L) {
-    return 4 * C * CBB_NU + 4 * 256 + 2 * 4 * 256 + 2 * 256 + 2 * 8 * CBB_NU + 2 * L * 8 + 8 + 16 + L * CBB_NU + L * CBB_LT + 2 * CBB_NU + 3 * CBB_NU + 2 * CBB_NU + CBB_NU + 4 + 32;
+    return 4 * C * CBB_NU + 4 * 256 + 2 * 4 * 256 + 2 * 256 + 2 * 8 * CBB_NU + 2 * L * 8 + 8 + 16 + L * CBB_NU + L * CBB_LT + 2 * CBB_NU + 3 * CBB_NU + 2 * CBB_NU + CBB_NU + 4 + 32 + 1 + CBB_NU * 22;
 }
 // float offset, inside a B-operand image, of element (channel ch, utterance n)
 __device__ __forceinline__ int img_idx(int ch, int n) { return (((((ch >> 4) << 2) + (ch & 3)) * CBB_NU + n) << 2) + ((ch >> 2) & 3); }
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
     const int o_fr = o; o += CBB_NU;                          // (int) the step's aux frame of every utterance: its layer-0 row of pproj (rows of 2 C floats)
     const int o_ctl = o; o += 4;
     const int o_prof = o; o += 32;                            // (dev: phase times, -DQPN_ENABLE_STAMPS builds)
+    const int o_ud = (o + 1) & ~1; o = o_ud + CBB_NU * 22;                     // the group's utterance descriptors (UttDesc, 88 bytes each): read every step, a dependent global load otherwise
     const int o_lg = o_x;                                     // logits [nb][Q] (the images are free by then)
     for (int i = tid; i < o; i += CBB_NT) sm[i] = 0.0f;
     __syncthreads();
@@ -241,6 +242,9 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
         int* e = smi + o_lt + tid * CBB_LT;
         e[0] = c.o_ring[tid]; e[1] = p.rings[tid].len; e[2] = c.adaptive[tid]; e[3] = wblk + c.zc[tid]; e[4] = wblk + c.zp[tid]; e[5] = wblk + c.rs[tid];
     }
+    static_assert(sizeof(UttDesc) == 88, "the LDS copy of the descriptors assumes 22 ints");
+    for (int i = tid; i < nb * 22; i += CBB_NT) smi[o_ud + i] = ((const int*)(p.utts + b0))[i];
+    const UttDesc* const uds = (const UttDesc*)(smi + o_ud);
     int Tmax = 0;
     for (int k = 0; k < nb; ++k) { const UttDesc ud = p.utts[b0 + k]; const int tt = ud.n0 + ud.n_samples; Tmax = tt > Tmax ? tt : Tmax; }
     if (tid < nb) { const UttView u = make_view(p, p.utts[b0 + tid]); smi[o_samp + 2 * tid] = u.known[0]; smi[o_samp + 2 * tid + 1] = u.n0 + u.n_samples >= 3 ? u.known[1] : 0; }
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             if (xt < CBB_NU) {
                 unsigned tg = 0u; int fr = 0;
                 if (xt < nb) {
-                    const UttDesc ud = p.utts[b0 + xt];
+                    const UttDesc ud = uds[xt];
                     const UttView u = make_view(p, ud);
                     if (t + 1 < u.n0 + u.n_samples) {
                         tg = tag;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             // aux time's upsampling weight: the same for every utterance of the call (one t, one n_pad)
             float wj = 1.0f;
             if (p.U > 0) {
-                const UttDesc ud = p.utts[b0];
+                const UttDesc& ud = uds[0];
                 const int ut = t - ud.n_pad - (t < ud.n0 - 1 ? 1 : 0);
                 wj = p.flat[p.up_w + (ut >= 0 ? ut - (int)((unsigned)ut / (unsigned)p.U) * p.U : 0)];
             }
@@ -432,20 +436,26 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             for (int l = 0; l < L; ++l) {
                 const bool has_res = l + 1 < L;               // the last block's residual output is unused (qpnet.py:505)
                 if (l + 2 < L) past_rows(l + 2, 0);
+                // one (channel, utterance) per thread of the first two exchange waves.  What does not depend on this layer's current-row dot is read while it runs:
+                // the past-tap dot product (closed from its partial tiles), the aux terms, the layer input of my channel (the gather after C overwrites it)
+                int xv = xt; CBB_FRESH(xv);
+                const int gm = xv >> 4, gn = xv & 15;
+                const bool gate_thread = gm < 8 && gn < nb && tags[gn];
+                const float* Pp = sm + o_pp + (l & 1) * 1024; const float* Ax = sm + o_auxz + (l & 1) * 256;
+                float aps = 0.0f, apt = 0.0f, axs = 0.0f, axt = 0.0f, xres = 0.0f;
+                if (gate_thread) {
+                    axs = Ax[gm * 16 + gn]; axt = Ax[(gm + 8) * 16 + gn]; xres = sm[o_x + img_idx(c0 + gm, gn)];
+                    if (l > 0) { aps = close_elem(Pp, gm, gn); apt = close_elem(Pp, gm + 8, gn); }      // (layer 0's: computed in this very phase)
+                }
                 __syncthreads();      // A: the partial tiles of this layer's current-row dot are in LDS
                 CB_T(3);
                 // ---------------- gate of my channels -> all-gather; beside it the aux terms of layer l + 1 (the past rows of layer l + 2: the compute waves, between C and D)
-                float xres = 0.0f;
-                {      // one (channel, utterance) per thread of the first two exchange waves
-                    int xv = xt; CBB_FRESH(xv);
-                    const int m = xv >> 4, n = xv & 15;
-                    if (m < 8 && n < nb && tags[n]) {
-                        const float* Pc = sm + o_part; const float* Pp = sm + o_pp + (l & 1) * 1024; const float* Ax = sm + o_auxz + (l & 1) * 256;
-                        const float zs = (close_elem(Pc, m, n) + close_elem(Pp, m, n)) + Ax[m * 16 + n];
-                        const float zt = (close_elem(Pc, m + 8, n) + close_elem(Pp, m + 8, n)) + Ax[(m + 8) * 16 + n];
-                        gb_store1(rs, n * ustride + c.o_g + l * C + c0 + m, tag, qgate(zs, zt));
-                        xres = sm[o_x + img_idx(c0 + m, n)];          // (the layer input of my channel: the gather after C overwrites it)
-                    }
+                if (gate_thread) {
+                    const float* Pc = sm + o_part;
+                    if (l == 0) { aps = close_elem(Pp, gm, gn); apt = close_elem(Pp, gm + 8, gn); }
+                    const float zs = (close_elem(Pc, gm, gn) + aps) + axs;
+                    const float zt = (close_elem(Pc, gm + 8, gn) + apt) + axt;
+                    gb_store1(rs, gn * ustride + c.o_g + l * C + c0 + gm, tag, qgate(zs, zt));
                 }
                 CB_T(4);
                 float aux_p = 0.0f, aux_q = 0.0f;      // the next layer's aux term: requested AFTER the gather (loads return in order: in front of it they would hold it up -- the
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             // ---------------- pick (qpnet.py:505-516): exchange wave k takes utterances k, k + 4, ...
             for (int k = wave - 4; k < nb; k += 4) {
                 if (!tags[k]) continue;
-                const UttView u = make_view(p, p.utts[b0 + k]);
+                const UttView u = make_view(p, uds[k]);
                 float bv = -INFINITY; int bi = 0x7fffffff;
                 for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + k * Q + i]; if (v > bv) { bv = v; bi = i; } }
                 bi = wave_argmax(bv, bi);
