@@ -563,6 +563,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
 // geometries this kernel takes: 8 channels per workgroup make the gate tile; S / G and Q / G rows fit their tiles; K = 256 or 512 chunks trees
 bool qpn_coopb_supported(const Geom& g) {
     if (g.L < 2 || g.C % 8 || g.C < 128 || g.S > g.C || g.Q > g.C) return false;      // (the skip / logit vectors reuse the channel images)
+    if ((g.C & (g.C - 1)) || (g.S & (g.S - 1)) || (g.Q & (g.Q - 1)) || g.Q < 64) return false;      // (the gathers split a vector's granule pairs over the threads by shifts)
     const int G = g.C / 8;
     if (g.S % G || g.Q % G || g.S / G < 1 || g.S / G > 8 || g.Q / G < 1 || g.Q / G > 16) return false;
     const int RC = g.Cp / 16, RS = g.Sp / 16;
