@@ -41,13 +41,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CBB_SC1 16                    // cache-policy bit of the buffer accesses: sc1 (agent scope -- what the atomic accesses of the granules compile to)
 #define CBB_XT 256                    // threads of the exchange waves
 
-#define CBB_LT 8                      // ints per layer of the LDS layer table: granule offset of the ring, its length, adaptive?, fragment blocks zc / zp / rs, this step's slot
+#define CBB_LT 10                     // ints per layer of the LDS layer table: granule offset of the ring, its length, adaptive?, fragment blocks zc / zp / rs, the step's slot (either parity), dilation
 // (CBB_FRESH: a thread index made opaque, so that the compiler recomputes what derives from it at every use instead of keeping dozens of
 //  loop-invariant offsets alive across the whole step -- they spilled)
 #define CBB_FRESH(x) asm volatile("" : "+v"(x))
 
 __host__ __device__ static inline int cbb_lds_floats(int C, int L) {
-    return 4 * C * CBB_NU + 4 * 256 + 2 * 4 * 256 + 2 * 256 + 2 * 8 * CBB_NU + 2 * L * 8 + 8 + 16 + L * CBB_NU + L * CBB_LT + 2 * CBB_NU + 3 * CBB_NU + 2 * CBB_NU + CBB_NU + 4 + 32 + 1 + CBB_NU * 22;
+    return 4 * C * CBB_NU + 4 * 256 + 2 * 4 * 256 + 2 * 256 + 2 * 8 * CBB_NU + 2 * L * 8 + 8 + 16 + 2 * L * CBB_NU + L * CBB_LT + 2 * CBB_NU + 4 * CBB_NU + 2 * CBB_NU + 2 * CBB_NU + 4 + 32 + 1 + CBB_NU * 22;
 }
 // float offset, inside a B-operand image, of element (channel ch, utterance n)
 __device__ __forceinline__ int img_idx(int ch, int n) { return (((((ch >> 4) << 2) + (ch & 3)) * CBB_NU + n) << 2) + ((ch >> 2) & 3); }
@@ -222,12 +222,12 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
     const int o_auxz = o; o += 2 * 256;                       // aux terms of my gate rows, layers of either parity: [16 rows][16 utterances]
     const int o_acc = o; o += 2 * 8 * CBB_NU;                 // skip totals of the fixed / adaptive stacks: [2][8 rows][16 utterances]
     const int o_bres = o; o += L * 8; const int o_bsk = o; o += L * 8; const int o_bp1 = o; o += 8; const int o_bp2 = o; o += 16;
-    const int o_off = o; o += L * CBB_NU;                     // (int) tap distances of the step
+    const int o_off = o; o += 2 * L * CBB_NU;                 // (int) tap distances of the step (steps of either parity: the next step's are computed during this step's post-net)
     const int o_lt = o; o += L * CBB_LT;                      // (int) layer table
     const int o_samp = o; o += 2 * CBB_NU;                    // (int) the two newest samples of every utterance
-    const int o_tag = o; o += 3 * CBB_NU;                     // (unsigned) tags: [0] this step's (0: inactive), [1], [2] of the past rows being gathered
+    const int o_tag = o; o += 4 * CBB_NU;                     // (unsigned) tags: [0], [1] the step's (either parity; 0: inactive), [2], [3] of the past rows being gathered
     const int o_so = o; o += 2 * CBB_NU;                      // (int) ring slots (granule offsets) of the past rows being gathered
-    const int o_fr = o; o += CBB_NU;                          // (int) the step's aux frame of every utterance: its layer-0 row of pproj (rows of 2 C floats)
+    const int o_fr = o; o += 2 * CBB_NU;                      // (int, either parity) the step's aux frame of every utterance: its layer-0 row of pproj (rows of 2 C floats)
     const int o_ctl = o; o += 4;
     const int o_prof = o; o += 32;                            // (dev: phase times, -DQPN_ENABLE_STAMPS builds)
     const int o_ud = (o + 1) & ~1; o = o_ud + CBB_NU * 22;                     // the group's utterance descriptors (UttDesc, 88 bytes each): read every step, a dependent global load otherwise
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
     if (tid < QB) sm[o_bp2 + tid] = p.flat[c.f_p2b + q0 + tid];
     if (tid < L) {
         int* e = smi + o_lt + tid * CBB_LT;
-        e[0] = c.o_ring[tid]; e[1] = p.rings[tid].len; e[2] = c.adaptive[tid]; e[3] = wblk + c.zc[tid]; e[4] = wblk + c.zp[tid]; e[5] = wblk + c.rs[tid];
+        e[0] = c.o_ring[tid]; e[1] = p.rings[tid].len; e[2] = c.adaptive[tid]; e[3] = wblk + c.zc[tid]; e[4] = wblk + c.zp[tid]; e[5] = wblk + c.rs[tid]; e[8] = p.rings[tid].mult;
     }
     static_assert(sizeof(UttDesc) == 88, "the LDS copy of the descriptors assumes 22 ints");
     for (int i = tid; i < nb * 22; i += CBB_NT) smi[o_ud + i] = ((const int*)(p.utts + b0))[i];
@@ -250,7 +250,8 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
     if (tid < nb) { const UttView u = make_view(p, p.utts[b0 + tid]); smi[o_samp + 2 * tid] = u.known[0]; smi[o_samp + 2 * tid + 1] = u.n0 + u.n_samples >= 3 ? u.known[1] : 0; }
     __syncthreads();
     if (Tmax < 3) return;
-    unsigned* const tags = (unsigned*)(smi + o_tag);
+    unsigned* const tagbuf = (unsigned*)(smi + o_tag);
+    unsigned* const ptags = tagbuf + 2 * CBB_NU;             // the two rows of past-row tags
     const int j4 = wave & 3;
     const bool cw = wave < 4;
     const int xt = tid - CBB_XT;                              // index among the exchange threads (negative: a compute thread)
@@ -276,6 +277,45 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
 #define CB_C0() do { } while (0)
 #define CB_C(k) do { } while (0)
 #endif
+    // the state of step ts that does not depend on its samples -- per utterance: active?, aux frame, tap distances; per layer: the ring slot -- into the buffers of
+    // parity ts & 1; computed by the compute waves while the exchange waves gather the last layer's gate vector (nothing else for them to do there) (qpnet.py:450-452, 592-624)
+    auto step_state = [&](int ts) {
+        const int pr_ = ts & 1;
+        const int k = tid & 15;      // (the 256 threads of the compute waves: utterance k, layers tid >> 4, + 16, ...)
+        {
+            unsigned tg = 0u; int fr = 0;
+            if (k < nb) {
+                const UttDesc ud = uds[k];
+                const UttView u = make_view(p, ud);
+                if (ts + 1 < u.n0 + u.n_samples) {
+                    tg = (unsigned)ts + 1u;
+                    const int ut = aux_time(u, ts);
+                    int f = 0;
+                    if (ut >= 0) f = p.U > 0 ? (int)((unsigned)ut / (unsigned)p.U) : ut;
+                    fr = (int)(ud.pproj / (2 * C)) + f * L;
+                    const int widx = ts < u.n0 - 1 ? ts - (u.n0 - 1) : 0;
+                    for (int l = tid >> 4; l < L; l += 16) {
+                        const int* e = smi + o_lt + l * CBB_LT;
+                        RingDesc r; r.base = 0; r.len = e[1]; r.mult = e[8]; r.adaptive = e[2];
+                        int off = tap_offset(r, u, ut, widx);
+                        if (off < 1 || off >= r.len) { atomicOr(p.status, 1); off = off < 1 ? 1 : r.len - 1; }
+                        smi[o_off + pr_ * L * CBB_NU + l * CBB_NU + k] = off;
+                    }
+                }
+            }
+            if (tid < CBB_NU) { tagbuf[pr_ * CBB_NU + k] = tg; smi[o_fr + pr_ * CBB_NU + k] = fr; }
+        }
+        if (wave == 3 && lane < L) { int* e = smi + o_lt + lane * CBB_LT; e[6 + pr_] = e[0] + (int)((unsigned)ts % (unsigned)e[1]) * C; }
+        if (tid == 255) {      // aux time's upsampling weight: the same for every utterance of the call (one t, one n_pad)
+            float wv = 1.0f;
+            if (p.U > 0) {
+                const UttDesc& ud = uds[0];
+                const int ut = ts - ud.n_pad - (ts < ud.n0 - 1 ? 1 : 0);
+                wv = p.flat[p.up_w + (ut >= 0 ? ut - (int)((unsigned)ut / (unsigned)p.U) * p.U : 0)];
+            }
+            sm[o_ctl + 2 + pr_] = wv;
+        }
+    };
     // The two roles run their OWN loop nests (the register sets of one never meet the other's in a merge); both execute the same sequence of barriers:
     //   per step: P1 | P2 | P3 | per layer: A | B | C | D | tail: T1 .. T6
     if (cw) {
@@ -286,14 +326,15 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
         load_frags(an_c, rw, (unsigned)LT(0, 3), RC, j4, lane);
         load_frags(an_p, rw, (unsigned)LT(0, 4), RC, j4, lane);
         load_frags(an_r, rw, (unsigned)LT(0, 5), RC, j4, lane);
+        step_state(1);
+        __syncthreads();          // (the first step's state)
         for (int t = 1; t + 1 < Tmax; ++t) {
 #ifdef QPN_ENABLE_STAMPS      // dev (QPN_COOPB_NOSTREAM=1): the fragments are loaded in the first steps and never again -- wrong samples, the time without the weight stream
             const __amdgpu_buffer_rsrc_t rw = (c.dev_nostream && t > 3) ? rw0 : rw_;
 #endif
-            __syncthreads();      // P1
             __syncthreads();      // P2
             {      // (idle until P3: the past rows of layers 0 and 1, beside the exchange waves' gather of layer 0's input)
-                const GSrc sa = {LT(0, 0), ustride, smi + o_so, tags + CBB_NU, hC, NOCHK, 0}, sb = {LT(1, 0), ustride, smi + o_so + CBB_NU, tags + 2 * CBB_NU, hC, NOCHK, 0};
+                const GSrc sa = {LT(0, 0), ustride, smi + o_so, ptags, hC, NOCHK, 0}, sb = {LT(1, 0), ustride, smi + o_so + CBB_NU, ptags + CBB_NU, hC, NOCHK, 0};
                 gather2(rs, sa, sm + o_xp, sb, sm + o_xp + IMG, true, C, nb, tid, c.abort, p.status);
             }
             __syncthreads();      // P3: layer 0's input and the past rows of layers 0, 1 are in LDS
@@ -316,7 +357,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                     const f32x4 part = wave_dot(an_p, sm + o_xp + ((l + 1) & 1) * IMG, RC, j4, lane);
                     load_frags(an_p, rw, l + 2 < L ? (unsigned)LT(l + 2, 4) : p2blk, l + 2 < L ? RC : RS, j4, lane);
                     *(f32x4*)(sm + o_pp + ((l + 1) & 1) * 1024 + j4 * 256 + lane * 4) = part;
-                }
+                } else step_state(t + 1);      // (the last layer has no successor whose past-tap dot would run here)
                 __syncthreads();      // B: the gate vector is in LDS
                 {      // residual 1x1 rows of my channels and my skip 1x1 rows, one tile
                     CB_C0();
@@ -330,7 +371,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 load_frags(an_r, rw, (unsigned)LT(has_res ? l + 1 : 0, 5), RC, j4, lane);
                 CB_C(12);
                 if (l + 2 < L) {      // (idle until D: the past rows of layer l + 2 -- rows of earlier steps, nothing to wait for -- so that the exchange waves gather one vector per edge)
-                    const GSrc sb = {LT(l + 2, 0), ustride, smi + o_so, tags + CBB_NU, hC, NOCHK, 0};
+                    const GSrc sb = {LT(l + 2, 0), ustride, smi + o_so, ptags, hC, NOCHK, 0};
                     gather1<true>(rs, sb, sm + o_xp + (l & 1) * IMG, C, nb, tid, c.abort, p.status);
                 }
                 __syncthreads();      // D: the next layer's input is in LDS
@@ -355,40 +396,14 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
         }
     } else {
         // =========================================================================== exchange waves
+        __syncthreads();          // (the first step's state: the compute waves)
         for (int t = 1; t + 1 < Tmax; ++t) {
             const unsigned tag = (unsigned)t + 1u;
-            // ---------------- P1. per utterance: active?, the step's aux frame and tap distances; per layer: the step's ring slot
-            if (xt < CBB_NU) {
-                unsigned tg = 0u; int fr = 0;
-                if (xt < nb) {
-                    const UttDesc ud = uds[xt];
-                    const UttView u = make_view(p, ud);
-                    if (t + 1 < u.n0 + u.n_samples) {
-                        tg = tag;
-                        const int ut = aux_time(u, t);
-                        int f = 0;
-                        if (ut >= 0) f = p.U > 0 ? (int)((unsigned)ut / (unsigned)p.U) : ut;
-                        fr = (int)(ud.pproj / (2 * C)) + f * L;
-                        const int widx = t < u.n0 - 1 ? t - (u.n0 - 1) : 0;
-                        for (int l = 0; l < L; ++l) {
-                            const RingDesc r = p.rings[l];
-                            int off = tap_offset(r, u, ut, widx);
-                            if (off < 1 || off >= r.len) { atomicOr(p.status, 1); off = off < 1 ? 1 : r.len - 1; }
-                            smi[o_off + l * CBB_NU + xt] = off;
-                        }
-                    }
-                }
-                tags[xt] = tg; smi[o_fr + xt] = fr;
-            }
-            if (xt >= 64 && xt < 64 + L) { int* e = smi + o_lt + (xt - 64) * CBB_LT; e[6] = e[0] + (int)((unsigned)t % (unsigned)e[1]) * C; }
-            // aux time's upsampling weight: the same for every utterance of the call (one t, one n_pad)
-            float wj = 1.0f;
-            if (p.U > 0) {
-                const UttDesc& ud = uds[0];
-                const int ut = t - ud.n_pad - (t < ud.n0 - 1 ? 1 : 0);
-                wj = p.flat[p.up_w + (ut >= 0 ? ut - (int)((unsigned)ut / (unsigned)p.U) * p.U : 0)];
-            }
-            __syncthreads();      // P1
+            // (P1 -- per utterance: active?, aux frame, tap distances; per layer: the ring slot -- was computed during the previous step's post-net)
+            const int par = t & 1;
+            unsigned* const tags = tagbuf + par * CBB_NU;
+            const int ofr = o_fr + par * CBB_NU, ooff = o_off + par * L * CBB_NU, sl = 6 + par;
+            const float wj = sm[o_ctl + 2 + par];
             CB_T(0);
             // tags and ring slots of the past rows of layer l (rows of EARLIER steps: published long ago; time 0 and before: never written, zeros) -> set `which`
             auto past_rows = [&](int l, int which) {
@@ -396,10 +411,10 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 if (k >= 0 && k < CBB_NU) {
                     unsigned tg = 0u; int so = 0;
                     if (tags[k]) {
-                        const int tp = t - smi[o_off + l * CBB_NU + k];
+                        const int tp = t - smi[ooff + l * CBB_NU + k];
                         if (tp >= 1) { tg = (unsigned)tp + 1u; so = (int)((unsigned)tp % (unsigned)smi[o_lt + l * CBB_LT + 1]) * C; }
                     }
-                    tags[(1 + which) * CBB_NU + k] = tg; smi[o_so + which * CBB_NU + k] = so;
+                    ptags[which * CBB_NU + k] = tg; smi[o_so + which * CBB_NU + k] = so;
                 }
             };
             // ---------------- P2. my channels of layer 0's input (two rows of the causal table, qpnet.py:110-132) -> ring 0; layer 0's aux terms; the past rows of layers 0 and 1
@@ -416,19 +431,19 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                         v[i] = p.flat[p.causal_w + ((size_t)ch * Q + s_prev) * 2] + p.flat[p.causal_w + ((size_t)ch * Q + s_cur) * 2 + 1];
                         v[i] = v[i] + p.flat[p.causal_b + ch];
                     }
-                    gb_store2(rs, k * ustride + smi[o_lt + 6] + c0 + 2 * m2, tag, v[0], v[1]);
+                    gb_store2(rs, k * ustride + smi[o_lt + sl] + c0 + 2 * m2, tag, v[0], v[1]);
                 }
             }
             {
                 float v = 0.0f;
-                if (ak < nb && tags[ak]) v = __builtin_fmaf(wj, p.pproj[(size_t)smi[o_fr + ak] * (2 * C) + anat], p.qb[anat]);
+                if (ak < nb && tags[ak]) v = __builtin_fmaf(wj, p.pproj[(size_t)smi[ofr + ak] * (2 * C) + anat], p.qb[anat]);
                 sm[o_auxz + xt] = v;
                 sm[o_acc + xt] = 0.0f;
             }
             __syncthreads();      // P2
             CB_T(1);
             {
-                const GSrc sx = {LT(0, 6), ustride, nullptr, tags, hC, NOCHK, 0};
+                const GSrc sx = {LT(0, sl), ustride, nullptr, tags, hC, NOCHK, 0};
                 gather1<true>(rs, sx, sm + o_x, C, nb, xt, c.abort, p.status);
             }
             __syncthreads();      // P3
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                     const GSrc sa = {c.o_g + l * C, ustride, nullptr, tags, hC, NOCHK, 0};
                     for (int i = 0; i < c.poll_delay_g; ++i) __builtin_amdgcn_s_sleep(2);
                     gather1<true>(rs, sa, sm + o_gv, C, nb, xt, c.abort, p.status);
-                    if (has_res && ak < nb && tags[ak]) { aux_p = p.pproj[(size_t)(smi[o_fr + ak] + l + 1) * (2 * C) + anat]; aux_q = p.qb[(l + 1) * 2 * C + anat]; }
+                    if (has_res && ak < nb && tags[ak]) { aux_p = p.pproj[(size_t)(smi[ofr + ak] + l + 1) * (2 * C) + anat]; aux_q = p.qb[(l + 1) * 2 * C + anat]; }
                 }
                 __syncthreads();      // B
                 CB_T(5);
@@ -476,7 +491,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                     if (n < nb && tags[n]) {
                         const float acc = close_elem(sm + o_part, m, n);
                         if (m < 8) {
-                            if (has_res) gb_store1(rs, n * ustride + smi[o_lt + (l + 1) * CBB_LT + 6] + c0 + m, tag, (acc + sm[o_bres + l * 8 + m]) + xres);
+                            if (has_res) gb_store1(rs, n * ustride + smi[o_lt + (l + 1) * CBB_LT + sl] + c0 + m, tag, (acc + sm[o_bres + l * 8 + m]) + xres);
                         } else if (m - 8 < SB) {
                             const int a = o_acc + (smi[o_lt + l * CBB_LT + 2] ? 8 * CBB_NU : 0) + (m - 8) * CBB_NU + n;
                             sm[a] = sm[a] + (acc + sm[o_bsk + l * 8 + (m - 8)]);
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
                 }
                 CB_T(7);
                 if (has_res) {
-                    const GSrc sa = {LT(l + 1, 6), ustride, nullptr, tags, hC, NOCHK, 0};
+                    const GSrc sa = {LT(l + 1, sl), ustride, nullptr, tags, hC, NOCHK, 0};
                     for (int i = 0; i < c.poll_delay_x; ++i) __builtin_amdgcn_s_sleep(2);
                     gather1<true>(rs, sa, sm + o_x, C, nb, xt, c.abort, p.status);
                     sm[o_auxz + ((l + 1) & 1) * 256 + xt] = (ak < nb && tags[ak]) ? __builtin_fmaf(wj, aux_p, aux_q) : 0.0f;
