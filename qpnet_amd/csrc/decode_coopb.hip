@@ -316,6 +316,27 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             sm[o_ctl + 2 + pr_] = wv;
         }
     };
+    // ---------------- pick (qpnet.py:505-516) from the logits in LDS: a wave per utterance, utterances kfirst, kfirst + 8, ...
+    auto pick_utts = [&](int t, int kfirst) {
+        const unsigned* tg = tagbuf + (t & 1) * CBB_NU;
+        for (int k = kfirst; k < nb; k += 8) {
+            if (!tg[k]) continue;
+            const UttView u = make_view(p, uds[k]);
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + k * Q + i]; if (v > bv) { bv = v; bi = i; } }
+            bi = wave_argmax(bv, bi);
+            const int i = t - (u.n0 - 1);
+            if (i >= 0 && u.logits && w == 0) for (int q = lane; q < Q; q += 64) u.logits[(size_t)i * Q + q] = sm[o_lg + k * Q + q];
+            int next;
+            if (i >= 0) {
+                if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg + k * Q, Q, p.seed, (unsigned)u.row, (unsigned)i, lane);
+                next = bi;
+                if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
+                if (lane == 0 && w == 0) u.out[i] = bi;
+            } else next = u.known[t + 1];
+            if (lane == 0) { smi[o_samp + 2 * k] = smi[o_samp + 2 * k + 1]; smi[o_samp + 2 * k + 1] = next; }
+        }
+    };
     // The two roles run their OWN loop nests (the register sets of one never meet the other's in a merge); both execute the same sequence of barriers:
     //   per step: P1 | P2 | P3 | per layer: A | B | C | D | tail: T1 .. T6
     if (cw) {
@@ -390,7 +411,8 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             }
             __syncthreads();          // T4
             load_frags(an_p, rw, (unsigned)LT(0, 4), RC, j4, lane);
-            __syncthreads();          // T5
+            __syncthreads();          // T5: the logits of every utterance are in LDS
+            pick_utts(t, wave + 4);
             __syncthreads();          // T6
             if (smi[o_ctl + 1]) break;            // a peer gave up: leave together
         }
@@ -544,24 +566,7 @@ __global__ __launch_bounds__(CBB_NT) void k_decode_coopb(const DecodeParams p, c
             }
             __syncthreads();      // T5
             CB_T(9);
-            // ---------------- pick (qpnet.py:505-516): exchange wave k takes utterances k, k + 4, ...
-            for (int k = wave - 4; k < nb; k += 4) {
-                if (!tags[k]) continue;
-                const UttView u = make_view(p, uds[k]);
-                float bv = -INFINITY; int bi = 0x7fffffff;
-                for (int i = lane; i < Q; i += 64) { const float v = sm[o_lg + k * Q + i]; if (v > bv) { bv = v; bi = i; } }
-                bi = wave_argmax(bv, bi);
-                const int i = t - (u.n0 - 1);
-                if (i >= 0 && u.logits && w == 0) for (int q = lane; q < Q; q += 64) u.logits[(size_t)i * Q + q] = sm[o_lg + k * Q + q];
-                int next;
-                if (i >= 0) {
-                    if (p.mode == QPN_MODE_SAMPLING) bi = sample_wave(o_lg + k * Q, Q, p.seed, (unsigned)u.row, (unsigned)i, lane);
-                    next = bi;
-                    if (u.teacher) { const int64_t sv = u.teacher[i] % Q; next = (int)(sv < 0 ? sv + Q : sv); }
-                    if (lane == 0 && w == 0) u.out[i] = bi;
-                } else next = u.known[t + 1];
-                if (lane == 0) { smi[o_samp + 2 * k] = smi[o_samp + 2 * k + 1]; smi[o_samp + 2 * k + 1] = next; }
-            }
+            pick_utts(t, wave - 4);      // (utterances 0..3 mod 8; the compute waves: 4..7 mod 8)
             if (xt == 0) smi[o_ctl + 1] = __hip_atomic_load(c.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();      // T6
             CB_T(10);
