@@ -367,9 +367,13 @@ def runner_loop_rate(m, tr, cfg, dev, steps=300, sync_loss=False):
     tr.flush_loss()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     total, got = 0.0, 0
+    w_batch = w_step = 0.0
     for i in range(steps):
+        ta = time.perf_counter()
         bx, bh, bt, bd, bb, maxd = next(stream)
+        tb = time.perf_counter()
         v = tr.step(bx, bh, bt, bd, bb, want_loss=mode, maxd=maxd)
+        w_batch += tb - ta; w_step += time.perf_counter() - tb
         if v is not None:
             total += v; got += 1
         if not sync_loss and (i + 1) % 100 == 0:          # (run_train's default reporting interval)
@@ -381,7 +385,11 @@ def runner_loop_rate(m, tr, cfg, dev, steps=300, sync_loss=False):
         total += v; got += 1
     torch.cuda.synchronize()
     assert got == steps and np.isfinite(total)
-    return steps / (time.perf_counter() - t0)
+    dt = time.perf_counter() - t0
+    # where the main thread's iteration went (us): waiting for the loader thread's batch / inside step() -- on a box whose host is busy the loop falls from ~1440 to
+    # ~1185 steps/s (five runs on five boxes in round 6; tools/runner_loop_split.py has the loader thread's side)
+    runner_loop_rate.split = {"wait_batch_us": w_batch / steps * 1e6, "in_step_us": w_step / steps * 1e6, "iteration_us": dt / steps * 1e6}
+    return steps / dt
 
 
 def run_train(args, rank, local, world):
@@ -536,6 +544,11 @@ def run_train(args, rank, local, world):
         # the loop `python -m qpnet_amd.run_train` runs: generator + pinned staging + prefetch thread + step(want_loss="lagged"): every step's loss
         # reaches the host one step late; ..._sync_loss: read inside the step, the reference's literal order (QPN_RUN_TRAIN_SYNC_LOSS=1)
         out["runner_loop_steps_per_s"] = runner_loop_rate(m, tr, cfg, dev)
+        out["runner_loop_split"] = dict(runner_loop_rate.split)
+        try:
+            out["runner_loop_split"]["host_loadavg"] = open("/proc/loadavg").read().split()[:3]
+        except OSError:
+            pass
         out["runner_loop_sync_loss_steps_per_s"] = runner_loop_rate(m, tr, cfg, dev, steps=150, sync_loss=True)
         out["dropin_loop_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=False)
         out["dropin_loop_flat_adam_steps_per_s"] = dropin_loop_rate(m, cfg, batches, nchunks, flat_adam=True)
