@@ -527,6 +527,27 @@ def test_batched_cooperative_decode_other_widths_vs_oracle(cuda, oracle, monkeyp
     np.testing.assert_array_equal(y, oracle.decode(cfg0, flat0, h0, d, x, n)["samples"])
 
 
+def test_batched_cooperative_decode_degenerate_lengths(cuda, oracle, monkeypatch):
+    """Utterances of 0, 1 and 2 samples next to longer ones in one group of the batched kernel (rows that go inactive while their
+    neighbours run on; a whole group with nothing but the warm-up to do): no hang, shortest-first retirement, the oracle's streams."""
+    import torch
+    from qpnet_amd.config import QPNetConfig
+    monkeypatch.setenv("QPN_DECODE_COOP", "32")
+    monkeypatch.delenv("QPN_DECODE_COOPB", raising=False)
+    cfg = QPNetConfig(n_resch=256, n_skipch=256, dilationF_depth=2, dilationF_repeat=1, dilationA_depth=2, dilationA_repeat=1)
+    flat = synth.make_weights(cfg, 37)
+    m = util.build_model(cfg, flat, cuda)
+    for ns in ([5, 1, 2], [1], [2], [0, 3], [130, 1, 0, 2, 7]):
+        bx, bh, bd, _ = synth.decode_batch(cfg, [(100 + b, 2, 1.0) for b in range(len(ns))])
+        nlist = list(ns)
+        outs = m.batch_fast_generate(torch.from_numpy(bx).to(cuda), torch.from_numpy(bh).to(cuda), nlist, bd, mode="argmax")
+        assert m.last_decode_plan.startswith("coopb "), m.last_decode_plan
+        refs = oracle.batch_fast_generate(cfg, flat, bx, bh, list(ns), bd)
+        assert [len(o) for o in outs] == sorted(ns) == [len(r) for r in refs]
+        for o, r in zip(outs, refs):
+            np.testing.assert_array_equal(o, r)
+
+
 def test_batched_cooperative_launch_that_gives_up_is_rerun_per_utterance(cuda):
     """tests/giveup_child.py `coopb` (the -DQPN_TESTING build's injected give-up): the batch is decoded again by decode_coop.hip."""
     util.run_giveup_child("coopb", "QPN_TEST_PIPE_GIVES_UP")
