@@ -1066,8 +1066,9 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     if (!h->single_cu_ok && coopG == 0) coopG = h->n_cus >= 128 ? h->n_cus / 2 : h->n_cus;
     if (force_one_cu && h->single_cu_ok) coopG = 0;
     // wide geometries, batches: the utterances batched into the contractions (decode_coopb.hip) -- up to 16 per group of n_resch / 8 workgroups
-    const bool coopb = coopG > 0 && !force_one_cu && coop_limit == 0 && h->cb_ok && h->dk.coopb > 0 && B >= h->dk.coopb &&
-                       B <= 16 * (h->n_cus / (g.C / 8) > 0 ? h->n_cus / (g.C / 8) : 1) && h->n_cus >= g.C / 8;
+    // (a launch holds 16 utterances per group and as many groups as fit the chip: larger batches take several launches of equal size, longest rows first)
+    const bool coopb = coopG > 0 && !force_one_cu && coop_limit == 0 && h->cb_ok && h->dk.coopb > 0 && B >= h->dk.coopb && h->n_cus >= g.C / 8;
+    const int cb_cap = 16 * (h->n_cus / (g.C / 8) > 0 ? h->n_cus / (g.C / 8) : 1), cb_launches = (B + cb_cap - 1) / cb_cap, cb_rows = (B + cb_launches - 1) / cb_launches;
     if (coopG > 0) {
         int cap = coopG; if (B < h->n_cus && h->n_cus / B < cap) cap = h->n_cus / B;       // the whole batch in one launch when it fits the chip
         if (coop_limit > 0 && cap > coop_limit) cap = coop_limit;                          // retry with fewer workgroups per utterance
@@ -1138,10 +1139,17 @@ static int decode_enqueue_impl(qpn_handle* h, int B, int n_x, int64_t F, int64_t
     p.pproj = h->d_pproj; p.dfac = d_dfac; p.known = h->d_known; p.teacher = d_teacher; p.out = d_out; p.logits = d_logits; p.ring = h->d_ring;
     QPN_HIP(hipEventRecord(h->ev0, stream));
     char plan[160];
-    rc = coopb ? qpn_launch_decode_coopb(h, p, B, stream) : 1;      // (1: does not apply to this call)
+    rc = 1;                                                           // (1: the batched kernel does not apply to this call)
+    if (coopb)
+        for (int first = 0; first < B; first += cb_rows) {
+            DecodeParams pw = p; pw.utts = h->d_utts + first;
+            rc = qpn_launch_decode_coopb(h, pw, std::min(cb_rows, B - first), stream);
+            if (rc) break;                                            // (what makes it not apply does not depend on the rows: the first launch decides)
+        }
     if (rc < 0) return rc;
     if (rc == 0) {
-        snprintf(plan, sizeof(plan), "coopb G=%d groups=%d x %d rows=%d", g.C / 8, h->cb_groups, h->cb_per, B);
+        if (cb_launches > 1) snprintf(plan, sizeof(plan), "coopb G=%d launches=%d x %d rows=%d", g.C / 8, cb_launches, cb_rows, B);
+        else snprintf(plan, sizeof(plan), "coopb G=%d groups=%d x %d rows=%d", g.C / 8, h->cb_groups, h->cb_per, B);
         h->call.multi_wg = 2; h->call.coopG = coopG > 2 ? coopG : 2;      // (a launch that gives up is re-run per utterance: decode_coop.hip)
     } else if (coopG) {
         rc = qpn_launch_decode_coop(h, p, B, coopG, stream); if (rc) return rc;

@@ -451,9 +451,9 @@ def test_batched_cooperative_decode_vs_oracle(cuda, oracle, monkeypatch):
     assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), r["logits"].view(np.uint32))
 
 
-@pytest.mark.parametrize("B", [20, 37, 6])
+@pytest.mark.parametrize("B", [20, 37, 6, 70])
 def test_batched_cooperative_decode_equals_the_per_utterance_kernel(B, cuda, monkeypatch):
-    """The reference's decode batch (20, runQP.py:66) and one that needs ten utterances per group: the batched kernel (the default plan)
+    """The reference's decode batch (20, runQP.py:66) one that needs ten utterances per group, one of two launches (70 rows on a 256-CU chip): the batched kernel (the default plan)
     draws the same samples as the per-utterance cooperative kernel (QPN_DECODE_COOPB=0), which the tests above pin to the oracle
     and to the reference's own streams -- sampling mode, ragged lengths, rows finishing at different steps."""
     import torch
